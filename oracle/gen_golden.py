@@ -1,0 +1,269 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference/DS_NeRF) on CPU.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python oracle/gen_golden.py
+
+Only the resulting .npz data files are committed; no reference source is copied.  Missing
+third-party modules of the reference (cv2, torchvision, diffusers, tinycudann, ...) are replaced
+by MagicMock entries before import; none of them is on the code paths
+exercised here.
+
+Network weights are NOT stored in the fixtures (2.4 MB per network): they are regenerated from
+`np.random.RandomState(seed)` (numpy's frozen legacy generator, bit-stable across versions) by
+`oracle/weights.py::seeded_state_dict`, and loaded into the reference's `NeRF` module here.
+"""
+import os
+import sys
+import importlib
+import argparse
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+
+
+def import_reference():
+    from transformers import CLIPTextModel, CLIPTokenizer, logging  # noqa: F401  (must precede the stubs)
+    for n in ['cv2', 'torchvision', 'torchvision.utils', 'imageio', 'tkinter', 'lpips', 'tinycudann',
+              'tensorboard', 'torch.utils.tensorboard', 'configargparse',
+              'diffusers', 'diffusers.pipelines', 'diffusers.pipelines.stable_diffusion',
+              'diffusers.utils', 'diffusers.utils.import_utils']:
+        try:
+            importlib.import_module(n)
+        except Exception:
+            sys.modules[n] = mock.MagicMock(name=n)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, '/root/reference/DS_NeRF')
+    import run
+    import run_nerf_helpers
+    return run, run_nerf_helpers
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def grad_summary(named_grads, n_sample=256, seed=7):
+    """Per-tensor (sum, abs-sum, l2) + a fixed random sample of entries; keeps fixtures small."""
+    out = {}
+    rs = np.random.RandomState(seed)
+    for name, g in named_grads.items():
+        g = npy(g).astype(np.float64).ravel()
+        idx = rs.randint(0, g.size, size=min(n_sample, g.size))
+        out[f'gstat/{name}'] = np.array([g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum())])
+        out[f'gidx/{name}'] = idx.astype(np.int64)
+        out[f'gval/{name}'] = g[idx].astype(np.float32)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    run, H = import_reference()
+    from oracle.weights import seeded_state_dict, bench_like_rays
+    torch.set_num_threads(8)
+
+    def want(name):
+        return args.only is None or args.only in name
+
+    def save(name, **kw):
+        path = os.path.join(OUT, name + '.npz')
+        np.savez_compressed(path, **kw)
+        print(f'{name}: {os.path.getsize(path) / 1024:.1f} KB')
+
+    def ref_nerf(seed):
+        m = H.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
+        return m
+
+    embed_fn, _ = H.get_embedder(10, 0)
+    embeddirs_fn, _ = H.get_embedder(4, 0)
+
+    def query(inputs, viewdirs, fn):
+        return run.run_network(inputs, viewdirs, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                               netchunk=65536)
+
+    # ------------------------------------------------------------------ rays
+    if want('rays'):
+        for tag, c2w in (('identity', np.concatenate([np.eye(3), np.zeros((3, 1))], 1)),
+                         ('rot', None)):
+            if c2w is None:
+                th, ph = 0.7, -0.3
+                Ry = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+                Rx = np.array([[1, 0, 0], [0, np.cos(ph), -np.sin(ph)], [0, np.sin(ph), np.cos(ph)]])
+                c2w = np.concatenate([Ry @ Rx, np.array([[0.3], [-0.2], [1.5]])], 1)
+            c2w = c2w.astype(np.float32)
+            Hh, Ww, f = 9, 13, 11.5
+            ro, rd = H.get_rays(Hh, Ww, f, torch.from_numpy(c2w))
+            ro_np, rd_np = H.get_rays_np(Hh, Ww, f, c2w)
+            save(f'rays_{tag}', c2w=c2w, H=Hh, W=Ww, focal=f, rays_o=npy(ro), rays_d=npy(rd),
+                 rays_o_np=ro_np.astype(np.float32), rays_d_np=rd_np.astype(np.float32))
+
+    # ------------------------------------------------------------------ posenc
+    if want('posenc'):
+        rs = np.random.RandomState(11)
+        pts = (rs.uniform(-4, 4, size=(257, 3))).astype(np.float32)
+        pts[0] = 0.0
+        pts[1] = [7.74, -7.74, 3.0]
+        dirs = rs.normal(size=(65, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+        save('posenc_pts', x=pts, y=npy(embed_fn(torch.from_numpy(pts))))
+        save('posenc_dirs', x=dirs, y=npy(embeddirs_fn(torch.from_numpy(dirs))))
+
+    # ------------------------------------------------------------------ MLP fwd/bwd
+    if want('mlp'):
+        seed = 101
+        m = ref_nerf(seed)
+        rs = np.random.RandomState(12)
+        pts = rs.uniform(-3, 3, size=(256, 3)).astype(np.float32)
+        dirs = rs.normal(size=(256, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+        emb = torch.cat([embed_fn(torch.from_numpy(pts)), embeddirs_fn(torch.from_numpy(dirs))], -1)
+        out = m(emb)
+        gout = rs.normal(size=(256, 4)).astype(np.float32)
+        (out * torch.from_numpy(gout)).sum().backward()
+        gs = grad_summary({k: p.grad for k, p in m.named_parameters()})
+        save('mlp_fwd_bwd', seed=seed, pts=pts, dirs=dirs, emb=npy(emb), out=npy(out), gout=gout, **gs)
+
+    # ------------------------------------------------------------------ compositing
+    if want('composite'):
+        rs = np.random.RandomState(13)
+        B, S = 48, 64
+        for tag, kw in (('train', dict(white=False, noise_std=1.0, detach=False)),
+                        ('test', dict(white=False, noise_std=0.0, detach=False)),
+                        ('white', dict(white=True, noise_std=0.0, detach=False)),
+                        ('detach', dict(white=True, noise_std=1.0, detach=True))):
+            raw = (rs.normal(size=(B, S, 4)) * 2.0).astype(np.float32)
+            raw[0, :, 3] = -5.0           # an empty ray: acc = 0 -> disp = nan in the reference
+            raw[1, :, 3] = 50.0           # an opaque ray
+            z = np.sort(rs.uniform(1.2, 7.74, size=(B, S)), -1).astype(np.float32)
+            d = rs.normal(size=(B, 3)).astype(np.float32)
+            noise = (rs.normal(size=(B, S)) * kw['noise_std']).astype(np.float32)
+            g = {k: rs.normal(size=s).astype(np.float32) for k, s in
+                 (('rgb', (B, 3)), ('disp', (B,)), ('acc', (B,)), ('depth', (B,)), ('w', (B, S)))}
+            raw_t = torch.from_numpy(raw).requires_grad_(True)
+            # the reference draws its own noise; pre-add ours and run it with raw_noise_std=0
+            raw_in = torch.cat([raw_t[..., :3], raw_t[..., 3:] + torch.from_numpy(noise)[..., None]], -1)
+            rgb, disp, acc, w, depth, alpha = H.raw2outputs(
+                raw_in, torch.from_numpy(z), torch.from_numpy(d), 0., kw['white'], pytest=False,
+                need_alpha=True, detach_weights=kw['detach'])
+            ok = torch.isfinite(disp)
+            loss = ((rgb * torch.from_numpy(g['rgb'])).sum() + (acc * torch.from_numpy(g['acc'])).sum()
+                    + (depth * torch.from_numpy(g['depth'])).sum() + (w * torch.from_numpy(g['w'])).sum()
+                    + (torch.where(ok, disp, torch.zeros_like(disp)) * torch.from_numpy(g['disp'])).sum())
+            loss.backward()
+            save(f'composite_{tag}', raw=raw, z=z, rays_d=d, noise=noise, white=kw['white'],
+                 detach=kw['detach'], rgb=npy(rgb), disp=npy(disp), acc=npy(acc), weights=npy(w),
+                 depth=npy(depth), alpha=npy(alpha), d_raw=npy(raw_t.grad),
+                 **{'g_' + k: v for k, v in g.items()})
+
+    # ------------------------------------------------------------------ inverse-CDF sampling
+    if want('sample_pdf'):
+        rs = np.random.RandomState(14)
+        B, Nb, Ns = 40, 63, 64
+        bins = np.sort(rs.uniform(1.2, 7.74, size=(B, Nb)), -1).astype(np.float32)
+        w = rs.uniform(0, 1, size=(B, Nb - 1)).astype(np.float32) ** 4
+        w[0] = 0.0                        # all-zero weights
+        w[1] = 0.0; w[1, 17] = 1.0        # a single spike
+        w[2] = 0.0; w[2, :3] = 1e-7       # mass only at the start
+        w[3] = 0.0; w[3, -1] = 5.0        # mass only in the last bin
+        w[4] = 1.0                        # uniform (ties between u and cdf entries possible)
+        samples_det = H.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ns, det=True, pytest=False)
+        samples_py = H.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ns, det=False, pytest=True)
+        np.random.seed(0)
+        u_py = np.random.rand(B, Ns).astype(np.float32)
+        u_det = np.broadcast_to(torch.linspace(0., 1., steps=Ns).numpy(), (B, Ns))   # what det=True draws
+        # the reference does not return inds; recompute them with the very same torch expressions
+        def inds_of(u):
+            ww = torch.from_numpy(w) + 1e-5
+            pdf = ww / torch.sum(ww, -1, keepdim=True)
+            cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+            return torch.searchsorted(cdf, torch.from_numpy(np.ascontiguousarray(u)), right=True), cdf
+        i_det, cdf = inds_of(u_det)
+        i_py, _ = inds_of(u_py)
+        save('sample_pdf', bins=bins, weights=w, u_det=np.ascontiguousarray(u_det), u_pytest=u_py,
+             samples_det=npy(samples_det), samples_pytest=npy(samples_py), inds_det=npy(i_det),
+             inds_pytest=npy(i_py), cdf=npy(cdf))
+
+    # ------------------------------------------------------------------ render_rays
+    if want('render_rays'):
+        mc, mf = ref_nerf(201), ref_nerf(202)
+        rays = bench_like_rays(64, seed=15)
+        rb = torch.from_numpy(rays)
+        common = dict(network_fn=mc, network_query_fn=query, N_samples=64, N_importance=64,
+                      network_fine=mf, lindisp=True, retraw=True, need_alpha=True)
+        with torch.no_grad():
+            r_test = run.render_rays(rb, white_bkgd=True, perturb=0., raw_noise_std=0., **common)
+        save('render_rays_test', rays=rays, seed_coarse=201, seed_fine=202,
+             **{k: npy(v) for k, v in r_test.items()})
+        # train mode with the reference's deterministic pytest hooks (np.random.seed(0) draws)
+        for p in list(mc.parameters()) + list(mf.parameters()):
+            p.grad = None
+        r_tr = run.render_rays(rb, white_bkgd=True, perturb=1., raw_noise_std=1., pytest=True, **common)
+        rs = np.random.RandomState(16)
+        g_rgb = rs.normal(size=(64, 3)).astype(np.float32)
+        g_rgb0 = rs.normal(size=(64, 3)).astype(np.float32)
+        g_disp = rs.normal(size=(64,)).astype(np.float32)
+        g_depth = rs.normal(size=(64,)).astype(np.float32)
+        loss = ((r_tr['rgb_map'] * torch.from_numpy(g_rgb)).sum() + (r_tr['rgb0'] * torch.from_numpy(g_rgb0)).sum()
+                + (r_tr['disp_map'] * torch.from_numpy(g_disp)).sum()
+                + (r_tr['depth_map'] * torch.from_numpy(g_depth)).sum())
+        loss.backward()
+        gs = grad_summary({'coarse.' + k: p.grad for k, p in mc.named_parameters()})
+        gs.update(grad_summary({'fine.' + k: p.grad for k, p in mf.named_parameters()}))
+        save('render_rays_pytest_train', rays=rays, seed_coarse=201, seed_fine=202, g_rgb=g_rgb,
+             g_rgb0=g_rgb0, g_disp=g_disp, g_depth=g_depth, loss=float(loss),
+             **{k: npy(v) for k, v in r_tr.items()}, **gs)
+
+    # ------------------------------------------------------------------ render() full frame via c2w
+    if want('render_fullframe'):
+        mc, mf = ref_nerf(301), ref_nerf(302)
+        th = np.radians(12.0)
+        c2w = np.array([[np.cos(th), 0, np.sin(th), 0.3 * np.sin(th)], [0, 1, 0, 0.],
+                        [-np.sin(th), 0, np.cos(th), 0.3 * np.cos(th)]], dtype=np.float32)
+        Hh, Ww, f = 15, 20, 383.65 * 20 / 504
+        kw = dict(network_query_fn=query, perturb=0., N_importance=64, network_fine=mf, N_samples=64,
+                  network_fn=mc, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=True)
+        with torch.no_grad():
+            rgb, disp, acc, depth, extras = run.render(Hh, Ww, f, chunk=128, c2w=torch.from_numpy(c2w),
+                                                       near=1.2, far=7.74, retraw=True, **kw)
+        save('render_fullframe_15x20', c2w=c2w, H=Hh, W=Ww, focal=f, near=1.2, far=7.74,
+             seed_coarse=301, seed_fine=302, rgb=npy(rgb), disp=npy(disp), acc=npy(acc), depth=npy(depth),
+             **{'extras/' + k: npy(v) for k, v in extras.items()})
+
+    # ------------------------------------------------------------------ normal fit
+    if want('normal_fit'):
+        rs = np.random.RandomState(17)
+        Hh, Ww = 54, 72
+        yy, xx = np.mgrid[0:Hh, 0:Ww]
+        depth = (3.0 + 0.02 * xx - 0.015 * yy + 0.3 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+                 + 0.02 * rs.normal(size=(Hh, Ww))).astype(np.float32)
+        focal_r = 383.65 / 7
+        K = np.array([[focal_r, 0, Ww / 2], [0, focal_r, Hh / 2], [0, 0, 1]], dtype=np.float32)
+        dt = torch.from_numpy(depth).requires_grad_(True)
+        pts = run.depth2xyz_torch(dt, torch.from_numpy(K))
+        pts_t = pts.unsqueeze(0).transpose(2, 3).transpose(1, 2)
+        n = run.depth2normal_geo(pts_t)
+        g = rs.normal(size=(1, 3, Hh, Ww)).astype(np.float32)
+        (n * torch.from_numpy(g)).sum().backward()
+        save('normal_fit_54x72', depth=depth, K=K, points=npy(pts), normals=npy(n), g=g, d_depth=npy(dt.grad))
+
+    # ------------------------------------------------------------------ losses / psnr helpers
+    if want('misc'):
+        rs = np.random.RandomState(18)
+        a = rs.uniform(0, 1, size=(33, 3)).astype(np.float32)
+        b = rs.uniform(0, 1, size=(33, 3)).astype(np.float32)
+        mse = H.img2mse(torch.from_numpy(a), torch.from_numpy(b))
+        save('misc', a=a, b=b, mse=npy(mse), psnr=npy(H.mse2psnr(mse)), to8b=H.to8b(a * 1.3 - 0.1))
+
+
+if __name__ == '__main__':
+    main()
