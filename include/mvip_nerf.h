@@ -1,0 +1,171 @@
+/*
+ * mvip_nerf.h — C ABI of libmvipnerf.so, the MI355X (gfx950) implementation of MVIP-NeRF's
+ * volume-rendering + SDS hot path.
+ *
+ * The reference has no FFI on this path (it is stock PyTorch ops called from Python, SURVEY.md
+ * §8b), so each entry point below names the reference Python call site it replaces
+ * (paths relative to the reference checkout).  A maintainer binds these with ctypes; the binding
+ * is shown in INTEGRATION.md and shipped in mvip_nerf_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless the name ends in _host or the type
+ *     says otherwise; tensors are dense row-major with the shapes given in the comments;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     on it, nothing synchronises, nothing allocates, no global mutable state: re-entrant per
+ *     stream and capturable into a hipGraph;
+ *   - return value: MVIP_OK (0) or a negative MVIP_E* code; mvip_strerror() names it.  Launch
+ *     errors are read back with hipGetLastError() and reported as MVIP_ELAUNCH.
+ *   - "nullable" arguments switch an optional input/output off.
+ */
+#ifndef MVIP_NERF_H
+#define MVIP_NERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVIP_OK        0
+#define MVIP_EINVAL   -1   /* bad size / null pointer / unsupported configuration */
+#define MVIP_ELAUNCH  -2   /* hipLaunch / runtime error (see mvip_last_hip_error) */
+#define MVIP_EUNSUP   -3   /* shape outside what the kernels are built for */
+
+#define MVIP_ABI_VERSION 1
+
+int         mvip_abi_version(void);
+const char *mvip_strerror(int code);
+const char *mvip_last_hip_error(void);      /* text of the last HIP error seen by this thread */
+int         mvip_device_info(int *n_cu, int *lds_bytes, char *arch_out, int arch_cap);
+
+/* ------------------------------------------------------------------------------------------
+ * a1  get_rays                         DS_NeRF/run_nerf_helpers.py:249-260
+ * c2w [3,4].  Writes the (y0..y0+h, x0..x0+w) window of the H x W frame (the `patch` crop of
+ * DS_NeRF/run.py:1174-1177; pass 0,0,H,W for the full frame): rays_o, rays_d [h,w,3].
+ */
+int mvip_get_rays(const float *c2w, int H, int W, float focal, int y0, int x0, int h, int w,
+                  float *rays_o, float *rays_d, void *stream);
+
+/* a2  ray-row assembly of render()     DS_NeRF/run.py:1182-1207
+ * rays_o, rays_d [B,3] -> rows [B,11] = (o, d, near, far, d/|d|).  viewdirs_src nullable: when
+ * given ([B,3]) viewdirs come from it instead of rays_d (the c2w_staticcam case, run.py:1185). */
+int mvip_ray_rows(const float *rays_o, const float *rays_d, const float *viewdirs_src,
+                  float near, float far, int64_t B, float *rows, void *stream);
+
+/* a1+a2 fused: rows straight from a pose; selects pixels by an optional int64 index list
+ * (`sel` [B] flat y*W+x indices, nullable -> all H*W pixels in raster order).  Replaces
+ * get_rays + the masked gather of DS_NeRF/run.py:869-884 + the row assembly. */
+int mvip_ray_rows_from_pose(const float *c2w, int H, int W, float focal, float near, float far,
+                            const int64_t *sel, int64_t B, float *rows, void *stream);
+
+/* a3  stratified depths                DS_NeRF/run.py:1759-1781
+ * rows [B,ncols] (near, far in columns 6,7); t_vals [S] = torch.linspace(0,1,S) (passed in so
+ * it is bit-identical to torch's); t_rand [B,S] uniforms, nullable (perturb == 0). z [B,S]. */
+int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S, const float *t_vals,
+                      int lindisp, const float *t_rand, float *z, void *stream);
+
+/* a4  Embedder.embed                   DS_NeRF/run_nerf_helpers.py:22-52
+ * x [N,3] -> y [N, 3+6L]  (x, then per octave: sin(x*2^k) xyz, cos(x*2^k) xyz). */
+int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a5/a6  NeRF.forward behind run_network   DS_NeRF/run_nerf_helpers.py:104-127, run.py:1108-1124
+ *
+ * The 8x256 MLP (D=8, W=256, skip at 4, 63+27 encoded inputs, use_viewdirs) evaluated by ONE
+ * kernel per call: encoding, all 11 linear layers and the activations stay on chip; weights are
+ * streamed from a packed image (2.3 MB) through LDS.
+ *
+ * mvip_mlp_packed_floats(): size of the packed image in floats.
+ * mvip_mlp_pack(): params_host is a HOST array of 24 device pointers in state-dict order
+ *   pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias}, feature_linear.{weight,bias},
+ *   alpha_linear.{weight,bias}, rgb_linear.{weight,bias}   (run_nerf_helpers.py:86-100).
+ * mvip_mlp_unpack_grads(): the inverse mapping for gradients (packed gradient image ->
+ *   24 gradient tensors, += when accumulate != 0).
+ */
+int64_t mvip_mlp_packed_floats(void);
+int mvip_mlp_pack(const float *const *params_host, float *packed, void *stream);
+
+/* Forward from geometry: rows [B,11], z [B,S] -> raw [B,S,4]; points are o + d*z, view dirs
+ * are rows[:,8:11] (run.py:1783, :1787).  precision: 0 = exact fp32 MFMA. */
+int mvip_mlp_forward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
+                          float *raw, int precision, void *stream);
+
+/* Forward from explicit points: pts [P,3], dirs [P,3] (already normalised) -> raw [P,4]; this is
+ * network_query_fn / run_network for arbitrary inputs (run.py:1530-1533). */
+int mvip_mlp_forward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
+                            float *raw, int precision, void *stream);
+
+/* Backward: d_raw [P,4] -> gradient image (packed layout, fp32, accumulated with +=).  Inputs
+ * are re-encoded and activations recomputed on chip in tiles of `tile_points`; `workspace` must
+ * hold mvip_mlp_backward_workspace_bytes(tile_points) bytes.  Gradients w.r.t. pts/dirs are not
+ * produced (the reference never needs them: SURVEY.md §8b "Autograd"). */
+int64_t mvip_mlp_backward_workspace_bytes(int64_t tile_points);
+int mvip_mlp_backward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
+                           const float *d_raw, float *grad_packed, void *workspace,
+                           int64_t tile_points, int precision, void *stream);
+int mvip_mlp_backward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
+                             const float *d_raw, float *grad_packed, void *workspace,
+                             int64_t tile_points, int precision, void *stream);
+int mvip_mlp_unpack_grads(const float *grad_packed, float *const *grads_host, int accumulate,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7  raw2outputs                      DS_NeRF/run_nerf_helpers.py:350-404
+ * raw [B,S,4], z [B,S], rows [B,ncols] (direction in columns 3..5), noise [B,S] nullable
+ * (already multiplied by raw_noise_std).  Outputs: rgb [B,3], disp/acc/depth [B], weights [B,S],
+ * alpha [B,S] nullable.  flags: bit0 white_bkgd.
+ */
+#define MVIP_COMP_WHITE   1
+#define MVIP_COMP_DETACHW 2   /* detach_weights: no gradient from rgb_map into the weights */
+int mvip_composite_forward(const float *raw, const float *z, const float *rows, int ncols,
+                           const float *noise, int64_t B, int S, int flags, float *rgb, float *disp,
+                           float *acc, float *depth, float *weights, float *alpha, void *stream);
+/* Backward of the above.  Upstream gradients (each nullable = zero): g_rgb [B,3], g_disp, g_acc,
+ * g_depth [B], g_weights [B,S], g_alpha [B,S].  Output d_raw [B,S,4]. */
+int mvip_composite_backward(const float *raw, const float *z, const float *rows, int ncols,
+                            const float *noise, int64_t B, int S, int flags, const float *g_rgb,
+                            const float *g_disp, const float *g_acc, const float *g_depth,
+                            const float *g_weights, const float *g_alpha, float *d_raw, void *stream);
+
+/* a8+a9  sample_pdf + sort(cat)        DS_NeRF/run_nerf_helpers.py:304-347, run.py:1809-1816, :1836
+ * z [B,Nc] coarse depths, weights [B,Nc] coarse weights (the kernel forms the Nc-1 midpoints
+ * and uses weights[:,1:-1] itself), u [B,Nf] uniforms or, when u_is_row != 0, one row [Nf]
+ * shared by all rays (det: torch.linspace(0,1,Nf)).  Outputs: z_samples [B,Nf], z_merged
+ * [B,Nc+Nf] ascending, z_std [B] (population std of z_samples), inds int64 [B,Nf] nullable
+ * (= #{cdf <= u}, searchsorted right=True), cdf [B,Nc-1] nullable. */
+int mvip_sample_pdf_merge(const float *z, const float *weights, const float *u, int u_is_row,
+                          int64_t B, int Nc, int Nf, float *z_samples, float *z_merged,
+                          float *z_std, int64_t *inds, float *cdf, void *stream);
+/* Standalone sample_pdf for arbitrary bins/weights (bins [B,Nb], weights [B,Nb-1]). */
+int mvip_sample_pdf(const float *bins, const float *weights, const float *u, int u_is_row,
+                    int64_t B, int Nb, int Nf, float *samples, int64_t *inds, float *cdf,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a12  depth2xyz_torch + depth2normal_geo   DS_NeRF/run.py:1909-1940
+ * depth [H,W]; intrinsics fx,fy,cx,cy; k odd window (31).  normals [3,H,W]:
+ * n = (A^T A)^-1 A^T 1 over the zero-padded k x k window of back-projected points.
+ * `moments` is a [9,H,W] workspace (kept for the backward). */
+int mvip_normal_fit_forward(const float *depth, int H, int W, float fx, float fy, float cx, float cy,
+                            int k, float *points /*[H,W,3] nullable*/, float *moments,
+                            float *normals, void *stream);
+int mvip_normal_fit_backward(const float *depth, const float *moments, const float *normals,
+                             const float *g_normals, int H, int W, float fx, float fy, float cx,
+                             float cy, int k, float *scratch /*[9,H,W]*/, float *d_depth,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a13/a14  elementwise core of the SDS step   DS_NeRF/guidance/sd_utils.py:406-413, :29-37
+ * latents = sqrt(abar)*x0 + sqrt(1-abar)*noise                       (scheduler.add_noise)
+ * grad    = nan_to_num((1-abar) * (e_u + s*(e_c - e_u) - noise))     (CFG + SDS weight)
+ * all [n] fp32. */
+int mvip_sds_add_noise(const float *x0, const float *noise, float sqrt_abar, float sqrt_1m_abar,
+                       int64_t n, float *latents, void *stream);
+int mvip_sds_grad(const float *eps_uncond, const float *eps_cond, const float *noise,
+                  float guidance_scale, float w, int64_t n, int accumulate, float *grad,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVIP_NERF_H */

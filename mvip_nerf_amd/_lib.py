@@ -1,0 +1,116 @@
+"""ctypes binding of libmvipnerf.so (the C ABI declared in include/mvip_nerf.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this raises.
+PyTorch is used above this layer only for device memory, streams and autograd plumbing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmvipnerf.so')
+
+_c_f = ctypes.c_void_p      # device pointers travel as integers
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_flt = ctypes.c_float
+
+_SIGNATURES = {
+    'mvip_abi_version': (_int, []),
+    'mvip_strerror': (ctypes.c_char_p, [_int]),
+    'mvip_last_hip_error': (ctypes.c_char_p, []),
+    'mvip_device_info': (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.c_char_p, _int]),
+    'mvip_get_rays': (_int, [_c_f, _int, _int, _flt, _int, _int, _int, _int, _c_f, _c_f, _c_f]),
+    'mvip_ray_rows': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _c_f, _c_f]),
+    'mvip_ray_rows_from_pose': (_int, [_c_f, _int, _int, _flt, _flt, _flt, _c_f, _i64, _c_f, _c_f]),
+    'mvip_stratified_z': (_int, [_c_f, _int, _i64, _int, _c_f, _int, _c_f, _c_f, _c_f]),
+    'mvip_posenc': (_int, [_c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_mlp_packed_floats': (_i64, []),
+    'mvip_mlp_pack': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f]),
+    'mvip_mlp_forward_rays': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _int, _c_f]),
+    'mvip_mlp_forward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _int, _c_f]),
+    'mvip_mlp_backward_workspace_bytes': (_i64, [_i64]),
+    'mvip_mlp_backward_rays': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_f, _i64, _int, _c_f]),
+    'mvip_mlp_backward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f, _c_f, _i64, _int, _c_f]),
+    'mvip_mlp_unpack_grads': (_int, [_c_f, ctypes.POINTER(ctypes.c_void_p), _int, _c_f]),
+    'mvip_composite_forward': (_int, [_c_f, _c_f, _c_f, _int, _c_f, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f,
+                                      _c_f, _c_f, _c_f]),
+    'mvip_composite_backward': (_int, [_c_f, _c_f, _c_f, _int, _c_f, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f,
+                                       _c_f, _c_f, _c_f, _c_f]),
+    'mvip_sample_pdf_merge': (_int, [_c_f, _c_f, _c_f, _int, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                     _c_f]),
+    'mvip_sample_pdf': (_int, [_c_f, _c_f, _c_f, _int, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_normal_fit_forward': (_int, [_c_f, _int, _int, _flt, _flt, _flt, _flt, _int, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_normal_fit_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _int, _int, _flt, _flt, _flt, _flt, _int, _c_f,
+                                        _c_f, _c_f]),
+    'mvip_sds_add_noise': (_int, [_c_f, _c_f, _flt, _flt, _i64, _c_f, _c_f]),
+    'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
+}
+
+# every symbol include/mvip_nerf.h declares; tests check the built library exports all of them
+DECLARED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class MvipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvipError(
+            f'{LIB_PATH} not found: build it with `python -m mvip_nerf_amd.csrc.build` '
+            '(or __graft_entry__.build()).  There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvip_abi_version() != 1:
+        raise MvipError('libmvipnerf.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        lib = load()
+        msg = lib.mvip_strerror(code).decode()
+        if code == -2:
+            msg += ': ' + lib.mvip_last_hip_error().decode()
+        raise MvipError(f'{what or "mvip call"} failed: {msg}')
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a dense tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise MvipError('expected a CUDA/HIP tensor (the HIP path has no CPU fallback)')
+    if t.dtype != dtype:
+        raise MvipError(f'expected dtype {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise MvipError('expected a contiguous tensor')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t).value
+    return arr
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

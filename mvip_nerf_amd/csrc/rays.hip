@@ -1,0 +1,155 @@
+// Ray generation, ray-row assembly, stratified depths and the materialised sinusoidal encoding.
+// All HBM-bound, one element per thread, arithmetic written in the reference's operation order
+// (the library is built with -ffp-contract=off so a*b+c stays two roundings like torch's).
+#include "common.h"
+
+namespace mvip {
+
+// dirs = ((x - W/2)/f, -(y - H/2)/f, -1); d[c] = sum_k dirs[k] * R[c][k]   (run_nerf_helpers.py:254-257)
+__device__ __forceinline__ void pixel_ray(const float *__restrict__ c2w, int H, int W, float focal,
+                                          int y, int x, float o[3], float d[3]) {
+    const float dx = ((float)x - (float)W * .5f) / focal;
+    const float dy = -(((float)y - (float)H * .5f) / focal);
+    const float dz = -1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d[c] = (dx * c2w[c * 4 + 0] + dy * c2w[c * 4 + 1]) + dz * c2w[c * 4 + 2];
+        o[c] = c2w[c * 4 + 3];
+    }
+}
+
+__global__ void get_rays_kernel(const float *__restrict__ c2w, int H, int W, float focal, int y0,
+                                int x0, int h, int w, float *__restrict__ ro, float *__restrict__ rd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)h * w) return;
+    const int y = y0 + (int)(i / w), x = x0 + (int)(i % w);
+    float o[3], d[3];
+    pixel_ray(c2w, H, W, focal, y, x, o, d);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ro[i * 3 + c] = o[c]; rd[i * 3 + c] = d[c]; }
+}
+
+__device__ __forceinline__ void write_row(float *__restrict__ row, const float o[3], const float d[3],
+                                          const float v[3], float near, float far) {
+    // viewdirs = v / ||v||   (run.py:1188)
+    const float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    row[0] = o[0]; row[1] = o[1]; row[2] = o[2];
+    row[3] = d[0]; row[4] = d[1]; row[5] = d[2];
+    row[6] = near; row[7] = far;
+    row[8] = v[0] / n; row[9] = v[1] / n; row[10] = v[2] / n;
+}
+
+__global__ void ray_rows_kernel(const float *__restrict__ ro, const float *__restrict__ rd,
+                                const float *__restrict__ vsrc, float near, float far, int64_t B,
+                                float *__restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float o[3], d[3], v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = ro[i * 3 + c]; d[c] = rd[i * 3 + c]; v[c] = vsrc ? vsrc[i * 3 + c] : d[c]; }
+    write_row(rows + i * 11, o, d, v, near, far);
+}
+
+__global__ void ray_rows_pose_kernel(const float *__restrict__ c2w, int H, int W, float focal,
+                                     float near, float far, const int64_t *__restrict__ sel, int64_t B,
+                                     float *__restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t p = sel ? sel[i] : i;
+    float o[3], d[3];
+    pixel_ray(c2w, H, W, focal, (int)(p / W), (int)(p % W), o, d);
+    write_row(rows + i * 11, o, d, d, near, far);
+}
+
+// run.py:1759-1781
+__device__ __forceinline__ float z_at(float near, float far, float t, int lindisp) {
+    if (lindisp) return 1.f / ((1.f / near) * (1.f - t) + (1.f / far) * t);
+    return near * (1.f - t) + far * t;
+}
+
+__global__ void stratified_z_kernel(const float *__restrict__ rows, int ncols, int64_t B, int S,
+                                    const float *__restrict__ t_vals, int lindisp,
+                                    const float *__restrict__ t_rand, float *__restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    const int64_t r = i / S;
+    const int s = (int)(i % S);
+    const float near = rows[r * ncols + 6], far = rows[r * ncols + 7];
+    const float zc = z_at(near, far, t_vals[s], lindisp);
+    if (!t_rand) { z[i] = zc; return; }
+    const float zl = s > 0 ? z_at(near, far, t_vals[s - 1], lindisp) : zc;
+    const float zr = s < S - 1 ? z_at(near, far, t_vals[s + 1], lindisp) : zc;
+    const float upper = s < S - 1 ? .5f * (zr + zc) : zc;
+    const float lower = s > 0 ? .5f * (zc + zl) : zc;
+    z[i] = lower + (upper - lower) * t_rand[i];
+}
+
+// run_nerf_helpers.py:27-52: channel c<3: x[c]; else m=c-3: octave m/6, fn (m%6)/3, dim m%3
+__global__ void posenc_kernel(const float *__restrict__ x, int64_t N, int L, float *__restrict__ y) {
+    const int C = 3 + 6 * L;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int64_t n = i / C;
+    const int c = (int)(i % C);
+    float out;
+    if (c < 3) out = x[n * 3 + c];
+    else {
+        const int m = c - 3, oct = m / 6, rem = m % 6;
+        const float a = x[n * 3 + rem % 3] * (float)(1 << oct);
+        out = rem < 3 ? sinf(a) : cosf(a);
+    }
+    y[i] = out;
+}
+
+static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace mvip
+
+using namespace mvip;
+
+extern "C" int mvip_get_rays(const float *c2w, int H, int W, float focal, int y0, int x0, int h, int w,
+                             float *rays_o, float *rays_d, void *stream) {
+    if (!c2w || !rays_o || !rays_d || H <= 0 || W <= 0 || h < 0 || w < 0 || y0 < 0 || x0 < 0 ||
+        y0 + h > H || x0 + w > W || !(focal > 0.f)) return MVIP_EINVAL;
+    const int64_t n = (int64_t)h * w;
+    if (n == 0) return MVIP_OK;
+    hipLaunchKernelGGL(get_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), c2w, H, W,
+                       focal, y0, x0, h, w, rays_o, rays_d);
+    return check_launch();
+}
+
+extern "C" int mvip_ray_rows(const float *rays_o, const float *rays_d, const float *viewdirs_src, float near,
+                             float far, int64_t B, float *rows, void *stream) {
+    if (B < 0 || (B > 0 && (!rays_o || !rays_d || !rows))) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    hipLaunchKernelGGL(ray_rows_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, as_stream(stream), rays_o,
+                       rays_d, viewdirs_src, near, far, B, rows);
+    return check_launch();
+}
+
+extern "C" int mvip_ray_rows_from_pose(const float *c2w, int H, int W, float focal, float near, float far,
+                                       const int64_t *sel, int64_t B, float *rows, void *stream) {
+    if (!c2w || H <= 0 || W <= 0 || !(focal > 0.f) || B < 0 || (B > 0 && !rows)) return MVIP_EINVAL;
+    if (!sel && B != (int64_t)H * W) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    hipLaunchKernelGGL(ray_rows_pose_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, as_stream(stream), c2w, H,
+                       W, focal, near, far, sel, B, rows);
+    return check_launch();
+}
+
+extern "C" int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S, const float *t_vals,
+                                 int lindisp, const float *t_rand, float *z, void *stream) {
+    if (B < 0 || S <= 0 || ncols < 8 || !t_vals || (B > 0 && (!rows || !z))) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    hipLaunchKernelGGL(stratified_z_kernel, dim3(blocks_for(B * S, 256)), dim3(256), 0, as_stream(stream), rows,
+                       ncols, B, S, t_vals, lindisp, t_rand, z);
+    return check_launch();
+}
+
+extern "C" int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream) {
+    if (N < 0 || L < 0 || L > 16 || (N > 0 && (!x || !y))) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(N * (3 + 6 * L), 256)), dim3(256), 0, as_stream(stream),
+                       x, N, L, y);
+    return check_launch();
+}

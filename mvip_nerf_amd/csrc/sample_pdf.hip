@@ -1,0 +1,246 @@
+// Hierarchical inverse-CDF sampling fused with the coarse+fine depth merge
+// (DS_NeRF/run_nerf_helpers.py:304-347 sample_pdf; DS_NeRF/run.py:1809-1816 mids / sort(cat);
+//  :1836 z_std).
+//
+// One wavefront per ray.  Element e of a per-ray vector lives in lane e%64, register e/64
+// ("strided"), so every global access is a contiguous 256-byte run per register.
+//   * pdf normaliser and CDF are accumulated in index order (k = 0,1,2,...) like torch's CPU
+//     cumsum, with the running value held wave-uniformly; the same pass counts, per sample,
+//     #{cdf <= u} -- searchsorted(right=True) without a search;
+//   * the 2-point gathers of cdf/bins are cross-lane shuffles;
+//   * sort(cat[z, z_samples]) is a bitonic network over registers + shuffles.
+// HBM traffic per ray (Nc=Nf=64): 512 B in (z, weights) + 256 B (u) and 512+256+4 B out.
+#include "common.h"
+#include <math.h>
+
+namespace mvip {
+
+template <int IT>
+__device__ __forceinline__ float strided_get(const float (&v)[IT], int e) {
+    float out = 0.f;
+    const int src = e & 63, item = e >> 6;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const float t = __shfl(v[i], src, 64);
+        if (item == i) out = t;
+    }
+    return out;
+}
+
+// bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
+// Produces samples (strided) and inds; cdf_out strided (nb entries).
+template <int IT>
+__device__ __forceinline__ void inverse_cdf(const float (&bins)[IT], const float (&wts)[IT], int nb,
+                                            const float (&u)[IT], int nf, float (&samples)[IT],
+                                            int (&inds)[IT], float (&cdf)[IT]) {
+    const int l = lane_id();
+    const int nw = nb - 1;
+    // weights + 1e-5, total in index order
+    float w5[IT];
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) w5[i] = wts[i] + 1e-5f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        for (int k = 0; k < 64; ++k) {
+            if (i * 64 + k >= nw) break;
+            total += __shfl(w5[i], k, 64);
+        }
+    // cdf[0] = 0; cdf[k+1] = cdf[k] + pdf[k]; count cdf entries <= u on the fly
+    float run = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { inds[i] = 0; cdf[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) inds[i] += (0.f <= u[i]) ? 1 : 0;          // cdf[0] = 0
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        for (int k = 0; k < 64; ++k) {
+            const int e = i * 64 + k;                  // weight index; writes cdf[e+1]
+            if (e >= nw) break;
+            const float pdf = __shfl(w5[i], k, 64) / total;
+            run += pdf;
+            const int dst = e + 1;
+#pragma unroll
+            for (int ii = 0; ii < IT; ++ii) {
+                if ((dst >> 6) == ii && (dst & 63) == l) cdf[ii] = run;
+                inds[ii] += (run <= u[ii]) ? 1 : 0;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int below = max(0, inds[i] - 1);
+        const int above = min(nb - 1, inds[i]);
+        const float cb = strided_get<IT>(cdf, below), ca = strided_get<IT>(cdf, above);
+        const float bb = strided_get<IT>(bins, below), ba = strided_get<IT>(bins, above);
+        float den = ca - cb;
+        den = den < 1e-5f ? 1.f : den;
+        const float t = (u[i] - cb) / den;
+        samples[i] = bb + t * (ba - bb);
+    }
+    (void)nf;
+}
+
+// Bitonic sort, ascending, of 64*M values in strided layout (index e = i*64 + lane).
+template <int M>
+__device__ __forceinline__ void bitonic_sort(float (&v)[M]) {
+    const int l = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 64 * M; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dj = j >> 6;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    if ((i & dj) == 0) {
+                        const int e = i * 64 + l;
+                        const bool up = (e & k) == 0;
+                        const float a = v[i], b = v[i | dj];
+                        const bool sw = up ? (a > b) : (a < b);
+                        v[i] = sw ? b : a;
+                        v[i | dj] = sw ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const int e = i * 64 + l;
+                    const bool up = (e & k) == 0;
+                    const float other = __shfl_xor(v[i], j, 64);
+                    const bool lower = (l & j) == 0;
+                    const float mn = fminf(v[i], other), mx = fmaxf(v[i], other);
+                    v[i] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <int IT>
+__global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
+    const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u, int u_is_row,
+    int64_t B, int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
+    float *__restrict__ z_std, int64_t *__restrict__ inds_out, float *__restrict__ cdf_out) {
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= B) return;
+    const int l = lane_id();
+    const int nb = Nc - 1;                           // midpoints
+    float zc[IT], bins[IT], wts[IT], uu[IT], smp[IT], cdf[IT];
+    int inds[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        zc[i] = e < Nc ? z[ray * Nc + e] : 0.f;
+        // weights[..., 1:-1]: weight e of the pdf is coarse weight e+1
+        wts[i] = e < nb - 1 ? weights[ray * Nc + e + 1] : 0.f;
+        uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
+    }
+    // mids[e] = .5 * (z[e+1] + z[e])
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        float nxt = __shfl_down(zc[i], 1, 64);
+        const float wrap = __shfl(zc[(i + 1) % IT], 0, 64);      // all lanes take part in the shuffle
+        if (l == 63) nxt = (i + 1 < IT) ? wrap : 0.f;
+        bins[i] = .5f * (nxt + zc[i]);
+    }
+    inverse_cdf<IT>(bins, wts, nb, uu, Nf, smp, inds, cdf);
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        if (e < Nf) {
+            z_samples[ray * Nf + e] = smp[i];
+            if (inds_out) inds_out[ray * Nf + e] = inds[i];
+            s1 += smp[i];
+        }
+        if (cdf_out && e < nb) cdf_out[ray * nb + e] = cdf[i];
+    }
+    // population std of the new samples (torch.std(unbiased=False))
+    const float mean = wave_sum(s1) / (float)Nf;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        if (e < Nf) { const float d = smp[i] - mean; s2 += d * d; }
+    }
+    s2 = wave_sum(s2);
+    if (l == 0) z_std[ray] = sqrtf(s2 / (float)Nf);
+    // merge: sort(cat[z, z_samples])
+    constexpr int M = 2 * IT;
+    float v[M];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        v[i] = e < Nc ? zc[i] : INFINITY;
+        v[IT + i] = e < Nf ? smp[i] : INFINITY;
+    }
+    bitonic_sort<M>(v);
+    const int N = Nc + Nf;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const int e = i * 64 + l;
+        if (e < N) z_merged[ray * N + e] = v[i];
+    }
+}
+
+template <int IT>
+__global__ __launch_bounds__(256) void sample_pdf_kernel(
+    const float *__restrict__ bins_in, const float *__restrict__ weights, const float *__restrict__ u,
+    int u_is_row, int64_t B, int Nb, int Nf, float *__restrict__ samples, int64_t *__restrict__ inds_out,
+    float *__restrict__ cdf_out) {
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= B) return;
+    const int l = lane_id();
+    float bins[IT], wts[IT], uu[IT], smp[IT], cdf[IT];
+    int inds[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        bins[i] = e < Nb ? bins_in[ray * Nb + e] : 0.f;
+        wts[i] = e < Nb - 1 ? weights[ray * (Nb - 1) + e] : 0.f;
+        uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
+    }
+    inverse_cdf<IT>(bins, wts, Nb, uu, Nf, smp, inds, cdf);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        if (e < Nf) {
+            samples[ray * Nf + e] = smp[i];
+            if (inds_out) inds_out[ray * Nf + e] = inds[i];
+        }
+        if (cdf_out && e < Nb) cdf_out[ray * Nb + e] = cdf[i];
+    }
+}
+
+}  // namespace mvip
+
+using namespace mvip;
+
+extern "C" int mvip_sample_pdf_merge(const float *z, const float *weights, const float *u, int u_is_row,
+                                     int64_t B, int Nc, int Nf, float *z_samples, float *z_merged, float *z_std,
+                                     int64_t *inds, float *cdf, void *stream) {
+    if (B < 0 || Nc < 3 || Nf < 1) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!z || !weights || !u || !z_samples || !z_merged || !z_std) return MVIP_EINVAL;
+    const int mx = Nc > Nf ? Nc : Nf;
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define CALL(I) hipLaunchKernelGGL(sample_pdf_merge_kernel<I>, grid, block, 0, as_stream(stream), z, weights, u, \
+                                   u_is_row, B, Nc, Nf, z_samples, z_merged, z_std, inds, cdf)
+    if (mx <= 64) { CALL(1); } else if (mx <= 128) { CALL(2); } else if (mx <= 256) { CALL(4); } else return MVIP_EUNSUP;
+#undef CALL
+    return check_launch();
+}
+
+extern "C" int mvip_sample_pdf(const float *bins, const float *weights, const float *u, int u_is_row, int64_t B,
+                               int Nb, int Nf, float *samples, int64_t *inds, float *cdf, void *stream) {
+    if (B < 0 || Nb < 2 || Nf < 1) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!bins || !weights || !u || !samples) return MVIP_EINVAL;
+    const int mx = Nb > Nf ? Nb : Nf;
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define CALL(I) hipLaunchKernelGGL(sample_pdf_kernel<I>, grid, block, 0, as_stream(stream), bins, weights, u, \
+                                   u_is_row, B, Nb, Nf, samples, inds, cdf)
+    if (mx <= 64) { CALL(1); } else if (mx <= 128) { CALL(2); } else if (mx <= 256) { CALL(4); } else return MVIP_EUNSUP;
+#undef CALL
+    return check_launch();
+}

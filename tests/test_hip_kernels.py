@@ -1,0 +1,223 @@
+"""GPU parity tests: every HIP kernel (called through the C ABI) against
+  (1) the golden vectors captured from the real reference (tests/golden), and
+  (2) the CPU oracle (oracle/nerf_oracle.py) on fresh seeded inputs.
+Tolerances are stated per test; integer outputs are compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from oracle.weights import seeded_state_dict, bench_like_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def params_np(seed):
+    return seeded_state_dict(int(seed))
+
+
+def params_dev(seed, dev):
+    from mvip_nerf_amd import ops
+    sd = params_np(seed)
+    return [T(sd[k], dev) for k in ops.PARAM_ORDER]
+
+
+# ---------------------------------------------------------------------------------------------- rays
+@pytest.mark.parametrize('tag', ['identity', 'rot'])
+def test_get_rays_golden(golden, cuda, tag):
+    from mvip_nerf_amd import ops
+    g = golden(f'rays_{tag}')
+    ro, rd = ops.get_rays(int(g['H']), int(g['W']), float(g['focal']), T(g['c2w'], cuda))
+    np.testing.assert_array_equal(N(ro), g['rays_o'])
+    np.testing.assert_allclose(N(rd), g['rays_d'], rtol=0, atol=2e-7)      # same op order; <=1 ulp at |d|~1
+
+
+def test_get_rays_patch_and_rows(cuda):
+    from mvip_nerf_amd import ops
+    H, W, f = 37, 53, 41.25
+    c2w = O.bench_poses(7)[5]
+    ro_ref, rd_ref = O.get_rays(H, W, f, c2w)
+    ro, rd = ops.get_rays(H, W, f, c2w.to(cuda), patch=(5, 9, 20, 31))
+    np.testing.assert_allclose(N(rd), rd_ref[5:25, 9:40].numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(N(ro), ro_ref[5:25, 9:40].numpy())
+    rows_ref = O.assemble_ray_batch(ro_ref, rd_ref, 1.2, 7.74).numpy()
+    rows = ops.ray_rows_from_pose(c2w.to(cuda), H, W, f, 1.2, 7.74)
+    np.testing.assert_allclose(N(rows), rows_ref, rtol=0, atol=3e-7)
+    sel = torch.tensor([0, 5, W * 3 + 7, H * W - 1], device=cuda, dtype=torch.int64)
+    rows_sel = ops.ray_rows_from_pose(c2w.to(cuda), H, W, f, 1.2, 7.74, sel=sel)
+    np.testing.assert_array_equal(N(rows_sel), N(rows)[N(sel)])
+    rows2 = ops.ray_rows(ro_ref.to(cuda), rd_ref.to(cuda), 1.2, 7.74)
+    np.testing.assert_allclose(N(rows2), rows_ref, rtol=0, atol=3e-7)
+    # empty input is legal
+    assert ops.ray_rows(torch.zeros(0, 3, device=cuda), torch.zeros(0, 3, device=cuda), 0., 1.).shape == (0, 11)
+
+
+# ---------------------------------------------------------------------------------------------- z
+@pytest.mark.parametrize('lindisp', [True, False])
+@pytest.mark.parametrize('perturb', [True, False])
+def test_stratified_z(cuda, lindisp, perturb):
+    from mvip_nerf_amd import ops
+    rows = torch.from_numpy(bench_like_rays(77, seed=3))
+    g = torch.Generator().manual_seed(5)
+    t_rand = torch.rand(77, 64, generator=g) if perturb else None
+    ref = O.stratified_z(rows[:, 6:7], rows[:, 7:8], 64, lindisp, t_rand)
+    z = ops.stratified_z(rows.to(cuda), 64, lindisp, None if t_rand is None else t_rand.to(cuda))
+    # identical IEEE ops in identical order; torch.linspace on the GPU may differ from the CPU's by 1 ulp
+    np.testing.assert_allclose(N(z), ref.numpy(), rtol=3e-7, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------- posenc
+@pytest.mark.parametrize('name,L', [('posenc_pts', 10), ('posenc_dirs', 4)])
+def test_posenc_golden(golden, cuda, name, L):
+    from mvip_nerf_amd import ops
+    g = golden(name)
+    y = ops.posenc(T(g['x'], cuda), L)
+    # sin/cos of arguments up to 2^9*|x| ~ 4e3: device libm vs host libm, a few ulp of the result
+    np.testing.assert_allclose(N(y), g['y'], rtol=0, atol=5e-7)
+
+
+# ---------------------------------------------------------------------------------------------- composite
+@pytest.mark.parametrize('tag', ['train', 'test', 'white', 'detach'])
+def test_composite_golden(golden, cuda, tag):
+    from mvip_nerf_amd import ops
+    g = golden(f'composite_{tag}')
+    B, S = g['z'].shape
+    rows = np.zeros((B, 11), np.float32)
+    rows[:, 3:6] = g['rays_d']
+    raw = T(g['raw'], cuda).requires_grad_(True)
+    rgb, disp, acc, w, depth, alpha = ops.composite(raw, T(g['z'], cuda), T(rows, cuda), T(g['noise'], cuda),
+                                                    white_bkgd=bool(g['white']), detach_weights=bool(g['detach']),
+                                                    need_alpha=True)
+    for name, val in (('rgb', rgb), ('acc', acc), ('weights', w), ('depth', depth), ('alpha', alpha)):
+        np.testing.assert_allclose(N(val), g[name], rtol=2e-5, atol=2e-6, err_msg=name)
+    np.testing.assert_allclose(N(disp), g['disp'], rtol=2e-5, equal_nan=True)
+    assert np.isnan(N(disp)[0])
+    ok = torch.isfinite(disp)
+    loss = ((rgb * T(g['g_rgb'], cuda)).sum() + (acc * T(g['g_acc'], cuda)).sum()
+            + (depth * T(g['g_depth'], cuda)).sum() + (w * T(g['g_w'], cuda)).sum()
+            + (torch.where(ok, disp, torch.zeros_like(disp)) * T(g['g_disp'], cuda)).sum())
+    loss.backward()
+    d_raw = N(raw.grad)
+    scale = np.nanmax(np.abs(g['d_raw']))
+    np.testing.assert_allclose(d_raw, g['d_raw'], rtol=2e-4, atol=2e-6 * scale, equal_nan=True)
+
+
+@pytest.mark.parametrize('S', [1, 7, 64, 128, 192, 300])
+def test_composite_vs_oracle_sizes(cuda, S):
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(S)
+    B = 19
+    raw = (rs.normal(size=(B, S, 4)) * 1.5).astype(np.float32)
+    z = np.sort(rs.uniform(1.2, 7.7, size=(B, S)), -1).astype(np.float32)
+    rows = bench_like_rays(B, seed=S)
+    noise = rs.normal(size=(B, S)).astype(np.float32)
+    ref = O.raw2outputs(torch.from_numpy(raw), torch.from_numpy(z), torch.from_numpy(rows[:, 3:6]),
+                        torch.from_numpy(noise), True)
+    out = ops.composite(T(raw, cuda), T(z, cuda), T(rows, cuda), T(noise, cuda), white_bkgd=True, need_alpha=True)
+    for a, b, name in zip(out, ref, ('rgb', 'disp', 'acc', 'weights', 'depth', 'alpha')):
+        np.testing.assert_allclose(N(a), b.numpy(), rtol=3e-5, atol=3e-6, err_msg=name)
+
+
+# ---------------------------------------------------------------------------------------------- sample_pdf
+def test_sample_pdf_golden(golden, cuda):
+    from mvip_nerf_amd import ops
+    g = golden('sample_pdf')
+    for mode in ('det', 'pytest'):
+        u = g[f'u_{mode}']
+        s, inds, cdf = ops.sample_pdf(T(g['bins'], cuda), T(g['weights'], cuda), T(u, cuda), want_inds=True,
+                                      want_cdf=True)
+        cdf_h, inds_h = N(cdf), N(inds)
+        np.testing.assert_allclose(cdf_h, g['cdf'], rtol=0, atol=2.5e-7)              # <= 2 ulp at 1.0
+        # integer semantics of the search are exact given the kernel's own cdf ...
+        want = np.stack([np.searchsorted(cdf_h[b], u[b], side='right') for b in range(u.shape[0])])
+        np.testing.assert_array_equal(inds_h, want)
+        # ... and equal the reference's indices except where u sits within 2 ulp of a cdf knot
+        diff = inds_h != g[f'inds_{mode}']
+        if diff.any():
+            bb, jj = np.nonzero(diff)
+            gap = np.min(np.abs(g['cdf'][bb] - u[bb, jj][:, None]), axis=1)
+            assert gap.max() <= 2.5e-7, f'{diff.sum()} index mismatches away from ties'
+        np.testing.assert_allclose(N(s), g[f'samples_{mode}'], rtol=1e-5, atol=2e-6)
+    # a single shared row of uniforms (the det=True fast path) equals the broadcast form
+    s_row, _, _ = ops.sample_pdf(T(g['bins'], cuda), T(g['weights'], cuda), T(g['u_det'][0], cuda))
+    s_full, _, _ = ops.sample_pdf(T(g['bins'], cuda), T(g['weights'], cuda), T(g['u_det'], cuda))
+    np.testing.assert_array_equal(N(s_row), N(s_full))
+
+
+@pytest.mark.parametrize('Nc,Nf', [(64, 64), (64, 128), (33, 17), (128, 64)])
+def test_sample_pdf_merge_vs_oracle(cuda, Nc, Nf):
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(Nc * 1000 + Nf)
+    B = 23
+    z = np.sort(rs.uniform(1.2, 7.7, size=(B, Nc)), -1).astype(np.float32)
+    w = (rs.uniform(0, 1, size=(B, Nc)) ** 3).astype(np.float32)
+    w[0] = 0
+    u = rs.uniform(0, 1, size=(B, Nf)).astype(np.float32)
+    zt, wt, ut = torch.from_numpy(z), torch.from_numpy(w), torch.from_numpy(u)
+    mids = .5 * (zt[:, 1:] + zt[:, :-1])
+    s_ref, inds_ref = O.sample_pdf(mids, wt[:, 1:-1], ut)
+    zm_ref, _ = torch.sort(torch.cat([zt, s_ref], -1), -1)
+    zs, zm, zstd, inds, cdf = ops.sample_pdf_merge(T(z, cuda), T(w, cuda), T(u, cuda), want_inds=True, want_cdf=True)
+    np.testing.assert_allclose(N(zs), s_ref.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(N(zm), zm_ref.numpy(), rtol=1e-5, atol=2e-6)
+    assert (np.diff(N(zm), axis=-1) >= 0).all()                                    # sortedness
+    np.testing.assert_array_equal(np.sort(np.concatenate([z, N(zs)], -1), -1), N(zm))   # a permutation of its inputs
+    np.testing.assert_allclose(N(zstd), torch.std(s_ref, dim=-1, unbiased=False).numpy(), rtol=1e-4, atol=1e-6)
+    assert (N(inds) != inds_ref.numpy()).mean() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- MLP
+def test_mlp_pack_roundtrip(cuda):
+    """pack -> unpack(grad path) is the identity on every real parameter element."""
+    from mvip_nerf_amd import ops
+    ps = params_dev(5, cuda)
+    packed = ops.mlp_pack(ps)
+    back = ops.mlp_unpack_grads(packed, None)
+    for a, b, name in zip(ps, back, ops.PARAM_ORDER):
+        np.testing.assert_array_equal(N(a), N(b), err_msg=name)
+
+
+def test_mlp_forward_points_golden(golden, cuda):
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    ps = params_dev(g['seed'], cuda)
+    packed = ops.mlp_pack(ps)
+    raw = ops.mlp_points(T(g['pts'], cuda), T(g['dirs'], cuda), packed, ps)
+    # fp32 fma chains in a different association than the host BLAS: ~1e-6 relative
+    np.testing.assert_allclose(N(raw), g['out'], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('P', [1, 31, 128, 129, 1000])
+def test_mlp_forward_points_ragged(cuda, P):
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(P)
+    pts = rs.uniform(-3, 3, size=(P, 3)).astype(np.float32)
+    dirs = rs.normal(size=(P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    sd = {k: torch.from_numpy(v) for k, v in params_np(77).items()}
+    emb = torch.cat([O.posenc(torch.from_numpy(pts), 10), O.posenc(torch.from_numpy(dirs), 4)], -1)
+    ref = O.mlp_forward(sd, emb).numpy()
+    ps = params_dev(77, cuda)
+    raw = ops.mlp_points(T(pts, cuda), T(dirs, cuda), ops.mlp_pack(ps), ps)
+    np.testing.assert_allclose(N(raw), ref, rtol=2e-5, atol=2e-6)
+
+
+def test_mlp_forward_rays_matches_points(cuda):
+    from mvip_nerf_amd import ops
+    rows = T(bench_like_rays(50, seed=9), cuda)
+    z = ops.stratified_z(rows, 64, True)
+    ps = params_dev(78, cuda)
+    packed = ops.mlp_pack(ps)
+    raw = ops.mlp_rays(rows, z, packed, ps)
+    pts = rows[:, None, 0:3] + rows[:, None, 3:6] * z[:, :, None]
+    dirs = rows[:, None, 8:11].expand(50, 64, 3)
+    raw_p = ops.mlp_points(pts.reshape(-1, 3), dirs.reshape(-1, 3), packed, ps)
+    np.testing.assert_array_equal(N(raw).reshape(-1, 4), N(raw_p))
