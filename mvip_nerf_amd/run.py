@@ -1,0 +1,278 @@
+"""Host-side mirror of the renderer half of the reference's `DS_NeRF/run.py`: `batchify`,
+`run_network`, `batchify_rays`, `render`, `render_path_4view`, `create_nerf`, `render_rays`,
+`depth2xyz_torch`, `depth2normal_geo` -- same names, positional orders, defaults and return
+structures, executed by the HIP kernels behind `mvip_nerf_amd.ops`.
+
+Randomness: the reference draws `torch.rand(z_vals.shape)`, `torch.randn(raw[...,3].shape)` and
+`torch.rand(cdf.shape[:-1] + [N])` from the default device generator, in that order, once per
+ray chunk.  This module draws the same shapes in the same order from the same generator, so a
+seeded run consumes the RNG stream exactly as the reference does on the same device; the draws
+are passed to the kernels as inputs (which is also what the reference's `pytest=True` hooks do).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .run_nerf_helpers import (NeRF, get_embedder, get_rays, ndc_rays, _density_noise, _uniforms)
+
+DEBUG = False
+
+
+def batchify(fn, chunk):
+    """DS_NeRF/run.py:1096-1105."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+
+    return ret
+
+
+def run_network(inputs2, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """DS_NeRF/run.py:1108-1124.  With the HIP-backed NeRF the encoding is fused into the MLP
+    kernel, so nothing is materialised; any other `fn` gets the reference's embed/cat/chunk flow."""
+    if isinstance(fn, NeRF) and viewdirs is not None:
+        flat = torch.reshape(inputs2, [-1, inputs2.shape[-1]])
+        dirs = viewdirs[:, None].expand(inputs2.shape).reshape(-1, 3)
+        out = fn.query_points(flat, dirs)
+        return torch.reshape(out, list(inputs2.shape[:-1]) + [out.shape[-1]])
+    inputs_flat = torch.reshape(inputs2, [-1, inputs2.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs2.shape)
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs2.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, need_alpha=False, detach_weights=False, **kwargs):
+    """DS_NeRF/run.py:1127-1140."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], need_alpha=need_alpha, detach_weights=detach_weights, **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, depths=None, need_alpha=False, detach_weights=False, patch=None, **kwargs):
+    """DS_NeRF/run.py:1143-1219.  Returns [rgb_map, disp_map, acc_map, depth_map, extras]."""
+    scalar_bounds = not torch.is_tensor(near) and not torch.is_tensor(far)
+    fast = use_viewdirs and not ndc and depths is None and c2w_staticcam is None and scalar_bounds
+    if c2w is not None:
+        c2w = torch.as_tensor(c2w)
+        if fast and patch is None:
+            sh = (H, W, 3)
+            rows = ops.ray_rows_from_pose(c2w, H, W, focal, near, far)
+        else:
+            rays_o, rays_d = ops.get_rays(H, W, focal, c2w, patch)
+    else:
+        rays_o, rays_d = rays
+    if not (c2w is not None and fast and patch is None):
+        sh = tuple(rays_d.shape)
+        if fast:
+            rows = ops.ray_rows(rays_o, rays_d, near, far)
+        else:
+            rows = _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_viewdirs,
+                                          c2w_staticcam, depths)
+    all_ret = batchify_rays(rows, chunk, need_alpha=need_alpha, detach_weights=detach_weights, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map', 'depth_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_viewdirs, c2w_staticcam, depths):
+    """The uncommon branches of render()'s row assembly (ndc, static camera, per-ray bounds,
+    depth column), DS_NeRF/run.py:1182-1207, as tensor algebra."""
+    viewdirs = None
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = ops.get_rays(H, W, focal, torch.as_tensor(c2w_staticcam))
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near_t = near * torch.ones_like(rays_d[..., :1])
+    far_t = far * torch.ones_like(rays_d[..., :1])
+    cols = [rays_o, rays_d, near_t, far_t]
+    if depths is not None:
+        cols.append(depths.reshape(-1, 1))
+    if use_viewdirs:
+        cols.append(viewdirs)
+    return torch.cat(cols, -1).contiguous()
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., pytest=False,
+                sigma_loss=None, verbose=False, need_alpha=False, detach_weights=False):
+    """DS_NeRF/run.py:1703-1847: stratified depths -> coarse MLP -> compositing -> inverse-CDF
+    resampling + merge -> fine MLP -> compositing.  Five kernel launches per chunk on the native
+    path (z, MLP, composite, sample+merge, MLP, composite) instead of ~150 torch ops."""
+    ray_batch = ray_batch.float() if ray_batch.dtype != torch.float32 else ray_batch
+    ray_batch = ray_batch.contiguous()
+    N_rays, ncols = ray_batch.shape
+    dev = ray_batch.device
+    has_dirs = ncols > 9
+    if ncols == 11:
+        rows = ray_batch
+    elif has_dirs:
+        rows = torch.cat([ray_batch[:, :8], ray_batch[:, -3:]], -1).contiguous()
+    else:
+        rows = ray_batch
+
+    def query(z, net):
+        if has_dirs and isinstance(net, NeRF) and getattr(network_query_fn, '_mvip_native', False):
+            return net.query_rays(rows, z)
+        pts = rows[:, None, 0:3] + rows[:, None, 3:6] * z[:, :, None]
+        return network_query_fn(pts, rows[:, 8:11] if has_dirs else None, net)
+
+    t_rand = None
+    if perturb > 0.:
+        t_rand = torch.rand((N_rays, N_samples), device=dev)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.tensor(np.random.rand(N_rays, N_samples), dtype=torch.float32, device=dev)
+    z_vals = ops.stratified_z(rows, N_samples, lindisp, t_rand)
+
+    coarse_net = network_fn if network_fn is not None else (
+        network_fine.alpha_model if getattr(network_fine, 'alpha_model', None) is not None else network_fine)
+    raw = query(z_vals, coarse_net)
+    noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
+    rgb_map, disp_map, acc_map, weights, depth_map, alpha = ops.composite(
+        raw, z_vals, rows, noise, white_bkgd, detach_weights, need_alpha)
+
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0, alpha0 = rgb_map, disp_map, acc_map, alpha
+        u = _uniforms((N_rays,), N_importance, perturb == 0., pytest, dev)
+        z_samples, z_vals, z_std, _, _ = ops.sample_pdf_merge(z_vals, weights, u)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = query(z_vals, run_fn)
+        noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev)
+        rgb_map, disp_map, acc_map, weights, depth_map, alpha = ops.composite(
+            raw, z_vals, rows, noise, white_bkgd, detach_weights, need_alpha)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map,
+           'weights': weights, 'z_vals': z_vals}
+    if retraw:
+        ret['raw'] = raw
+    if need_alpha:
+        ret['alpha'] = alpha
+        ret['alpha0'] = alpha0          # NameError without N_importance, like the reference (run.py:1831)
+    if N_importance > 0:
+        ret['rgb0'] = rgb_map_0
+        ret['disp0'] = disp_map_0
+        ret['acc0'] = acc_map_0
+        ret['z_std'] = z_std
+    if sigma_loss is not None and ncols > 11:
+        depths = ray_batch[:, 8]
+        ret['sigma_loss'] = sigma_loss.calculate_loss(rows[:, 0:3], rows[:, 3:6], rows[:, 8:11],
+                                                      rows[:, 6:7], rows[:, 7:8], depths, network_query_fn,
+                                                      network_fine)
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def render_path_4view(iter, all_masks, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None,
+                      render_factor=0, disp_require_grad=False, need_alpha=False, rgb_require_grad=False,
+                      detach_weights=False, patch_len=None, masks=None):
+    """DS_NeRF/run.py:1365-1401: the <=5 neighbour views [max(0,it-4) : it+5 : 2], it = iter % 60."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+    neighborhood_size = 4
+    iter = iter % 60
+    lo, hi = max(0, iter - neighborhood_size), min(len(render_poses), iter + neighborhood_size + 1)
+    selected_poses = render_poses[lo:hi:2]
+    selected_masks = all_masks[max(0, iter - neighborhood_size):min(len(all_masks), iter + neighborhood_size + 1):2]
+    rgbs, disps = [], []
+    for c2w in selected_poses:
+        rgb, disp, _, _, _ = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], retraw=True, need_alpha=need_alpha,
+                                    **render_kwargs)
+        disps.append(disp)
+        rgbs.append(rgb)
+    return torch.stack(rgbs, 0), torch.stack(disps, 0), selected_masks
+
+
+def create_nerf(args, device=None):
+    """DS_NeRF/run.py:1474-1599 for the `--no_tcnn`, `alpha_model_path is None` configuration:
+    returns (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer).
+    The reference wraps both MLPs in nn.DataParallel; here scaling is one process per GPU
+    (mvip_nerf_amd.trainer), so the modules are bare and checkpoints are read with or without
+    the `module.` key prefix."""
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    if getattr(args, 'alpha_model_path', None) is not None:
+        raise NotImplementedError('alpha_model_path (NeRF_RGB) is outside the hot-path scope')
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+        grad_vars += list(model_fine.parameters())
+
+    def network_query_fn(inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           netchunk=args.netchunk)
+    network_query_fn._mvip_native = True
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    basedir, expname = args.basedir, args.expname
+    if getattr(args, 'ft_path', None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(basedir, expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f] if os.path.isdir(d) else []
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt = torch.load(ckpts[-1], map_location=device)
+        start = ckpt['global_step']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(_strip_module_prefix(ckpt['network_fn_state_dict']))
+        if model_fine is not None:
+            model_fine.load_state_dict(_strip_module_prefix(ckpt['network_fine_state_dict']))
+
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    else:
+        render_kwargs_train['ndc'] = True
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    if getattr(args, 'sigma_loss', False):
+        raise NotImplementedError('--sigma_loss (DS_NeRF/loss.py) is off in the shipped config and out of scope')
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
+def _strip_module_prefix(sd):
+    return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}

@@ -110,7 +110,7 @@ def test_composite_golden(golden, cuda, tag):
     np.testing.assert_allclose(d_raw, g['d_raw'], rtol=2e-4, atol=2e-6 * scale, equal_nan=True)
 
 
-@pytest.mark.parametrize('S', [1, 7, 64, 128, 192, 300])
+@pytest.mark.parametrize('S', [2, 7, 64, 128, 192, 300])   # S=1 is degenerate in the reference itself (empty dists)
 def test_composite_vs_oracle_sizes(cuda, S):
     from mvip_nerf_amd import ops
     rs = np.random.RandomState(S)
