@@ -45,11 +45,11 @@ def orbit_pose(k, device):
                         device=device)
 
 
-def cpu_baseline(n_rays=4096):
+def cpu_baseline(n_rays=8192, threads=None):
     """The oracle (a torch-CPU restatement of the reference, oracle/nerf_oracle.py) timed on the
     host cores over a bounded sample of the same workload: `n_rays` rays of frame 0."""
     from oracle import nerf_oracle as O
-    cores = os.cpu_count() or 1
+    cores = threads or min(os.cpu_count() or 1, 32)   # more threads than this only adds sync overhead here
     torch.set_num_threads(cores)
     pc, pf = O.mlp_init(0), O.mlp_init(1)
     ro, rd = O.get_rays(H, W, FOCAL, O.bench_poses(1)[0])

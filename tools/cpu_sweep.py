@@ -1,0 +1,6 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+import bench
+for th in (8, 16, 32, 64, 128):
+    r = bench.cpu_baseline(n_rays=512, threads=th)
+    print(th, r['value'], r['sample'], flush=True)
