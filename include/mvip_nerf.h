@@ -79,8 +79,7 @@ int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream);
  * mvip_mlp_pack(): params_host is a HOST array of 24 device pointers in state-dict order
  *   pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias}, feature_linear.{weight,bias},
  *   alpha_linear.{weight,bias}, rgb_linear.{weight,bias}   (run_nerf_helpers.py:86-100).
- * mvip_mlp_unpack_grads(): the inverse mapping for gradients (packed gradient image ->
- *   24 gradient tensors, += when accumulate != 0).
+ * mvip_mlp_unpack_grads(): the inverse mapping (packed-layout image -> 24 tensors).
  */
 int64_t mvip_mlp_packed_floats(void);
 int mvip_mlp_pack(const float *const *params_host, float *packed, void *stream);
@@ -95,17 +94,20 @@ int mvip_mlp_forward_rays(const float *packed, const float *rows, const float *z
 int mvip_mlp_forward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
                             float *raw, int precision, void *stream);
 
-/* Backward: d_raw [P,4] -> gradient image (packed layout, fp32, accumulated with +=).  Inputs
- * are re-encoded and activations recomputed on chip in tiles of `tile_points`; `workspace` must
- * hold mvip_mlp_backward_workspace_bytes(tile_points) bytes.  Gradients w.r.t. pts/dirs are not
- * produced (the reference never needs them: SURVEY.md §8b "Autograd"). */
+/* Backward: d_raw [P,4] -> the 24 parameter gradients.  grads_host is a HOST array of 24 device
+ * pointers (state-dict order, natural [out][in] shapes) that are ACCUMULATED into with fp32
+ * atomics (zero them, or pass .grad buffers).  Inputs are re-encoded and activations recomputed
+ * on chip in tiles of `tile_points` (>=128); `workspace` must hold
+ * mvip_mlp_backward_workspace_bytes(tile_points) bytes.  Gradients w.r.t. pts/dirs are not
+ * produced (the reference never needs them: SURVEY.md 8b "Autograd"). */
 int64_t mvip_mlp_backward_workspace_bytes(int64_t tile_points);
 int mvip_mlp_backward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
-                           const float *d_raw, float *grad_packed, void *workspace,
+                           const float *d_raw, float *const *grads_host, void *workspace,
                            int64_t tile_points, int precision, void *stream);
 int mvip_mlp_backward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
-                             const float *d_raw, float *grad_packed, void *workspace,
+                             const float *d_raw, float *const *grads_host, void *workspace,
                              int64_t tile_points, int precision, void *stream);
+/* packed-layout image -> 24 tensors (inverse of mvip_mlp_pack; += when accumulate != 0). */
 int mvip_mlp_unpack_grads(const float *grad_packed, float *const *grads_host, int accumulate,
                           void *stream);
 

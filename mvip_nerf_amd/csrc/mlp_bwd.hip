@@ -1,7 +1,455 @@
-// placeholder: replaced by the real backward in the next milestone
+// Backward of the fused NeRF MLP: gradients of the 24 parameter tensors given d_raw.
+// (Autograd through run_network / NeRF.forward, DS_NeRF/run.py:1108-1124,
+//  DS_NeRF/run_nerf_helpers.py:104-127; the reference needs no gradient w.r.t. points.)
+//
+// Per tile of `tile_points` points, three kernels:
+//   R  mlp_forward_kernel<STASH>  re-encodes the inputs and recomputes every activation, written
+//      once to a tile-blocked stash ([row_tile][point_tile][32][32], 4 KB blocks);
+//   B1 mlp_delta_kernel           back-propagates pre-activation gradients G_l = relu'(h_l) .
+//      W_{l+1}^T G_{l+1}.  Same structure as the forward: each wave owns 32 points, a
+//      [256 x 32] gradient matrix lives in accumulator registers and is fed straight back as the
+//      B operand of the next v_mfma_f32_32x32x2_f32 chain; the TRANSPOSED weights stream
+//      through the LDS ring from a second packed image;
+//   B2 mlp_wgrad_kernel           dW_l = G_l . Act_{l-1}^T: MFMA with the POINT index as the K
+//      dimension.  A workgroup owns a slab of points and a whole 256x256 (or 256x64 / 128x288)
+//      gradient: 4 waves x (2 x 8) accumulator tiles; [32 x 32] operand blocks arrive by LDS-DMA
+//      with a source-side XOR swizzle so the per-lane ds_read_b128 of 4 consecutive points is
+//      bank-conflict free; results leave as fp32 atomics shaped as two 128-B row segments per
+//      wave instruction, directly into the natural [out][in] gradient tensors.  Bias, sigma-row
+//      and rgb-row gradients ride along on the VALU from the operands already in registers.
+// FLOPs: R + B1 + B2 ~= 2.9x the forward.  HBM: ~20 KB/point of stash traffic each way, i.e.
+// ~90 FLOP/B -- still MFMA-bound at fp32 rates.
 #include "common.h"
-extern "C" int64_t mvip_mlp_backward_workspace_bytes(int64_t) { return 0; }
-extern "C" int mvip_mlp_backward_rays(const float *, const float *, const float *, int64_t, int, const float *,
-                                      float *, void *, int64_t, int, void *) { return MVIP_EUNSUP; }
-extern "C" int mvip_mlp_backward_points(const float *, const float *, const float *, int64_t, const float *,
-                                        float *, void *, int64_t, int, void *) { return MVIP_EUNSUP; }
+#include "mlp_layout.h"
+#include "mlp_device.h"
+
+namespace mvip {
+using namespace mlp;
+
+int mlp_forward_launch(const float *packed, const float *a, const float *b, int64_t p_begin, int64_t p_count,
+                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream);
+
+// ------------------------------------------------------------------------------------------------
+// transposed weight image for B1
+// stream order: views^T (feature part), feature^T, then layers 7,6,5(h4 part),4,3,2,1 transposed
+// ------------------------------------------------------------------------------------------------
+constexpr int T_VIEWS_BLOCKS = 8 * 16;                 // out tiles: 256 feature units; K = 128 view units
+constexpr int T_LAYER_BLOCKS = 8 * 32;
+constexpr int T_TOTAL_BLOCKS = T_VIEWS_BLOCKS + 8 * T_LAYER_BLOCKS;      // 2176
+constexpr int T_TOTAL_CHUNKS = T_TOTAL_BLOCKS / CHUNK_BLOCKS;            // 136
+constexpr int T_FLOATS = T_TOTAL_BLOCKS * BLOCK_FLOATS;
+static_assert(T_VIEWS_BLOCKS % (NSLOT * CHUNK_BLOCKS) == 0, "ring phase");
+
+__device__ __forceinline__ float packed_w(const float *__restrict__ packed, int blk_off, int KG, int out, int k) {
+    const int blk = blk_off + (out >> 5) * KG + (k >> 3);
+    return packed[(int64_t)blk * BLOCK_FLOATS + ((k & 7) >> 2) * 128 + (out & 31) * 4 + (k & 3)];
+}
+
+__global__ void mlp_pack_transposed_kernel(const float *__restrict__ packed, float *__restrict__ pt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T_FLOATS) return;
+    const int blk = idx / BLOCK_FLOATS, r = idx % BLOCK_FLOATS;
+    const int h = r / 128, i = (r % 128) / 4, s = r % 4;
+    float v;
+    if (blk < T_VIEWS_BLOCKS) {
+        const int ti = blk / 16, kg = blk % 16;
+        v = packed_w(packed, OFF_VIEWS, LV_KG, 8 * kg + 4 * h + s, 32 * ti + i);
+    } else {
+        const int m = (blk - T_VIEWS_BLOCKS) / T_LAYER_BLOCKS;      // 0: feature, 1..7: layers 7..1
+        const int local = (blk - T_VIEWS_BLOCKS) % T_LAYER_BLOCKS;
+        const int ti = local / 32, kg = local % 32;
+        const int out = 8 * kg + 4 * h + s, in = 32 * ti + i;
+        if (m == 0) v = packed_w(packed, OFF_FEAT, LH_KG, out, in);
+        else {
+            const int l = 8 - m;
+            if (l >= 6) v = packed_w(packed, OFF_L6 + (l - 6) * LH_BLOCKS, LH_KG, out, in);
+            else if (l == 5) v = packed_w(packed, OFF_L5, L5_KG, out, 64 + in);
+            else v = packed_w(packed, OFF_L1 + (l - 1) * LH_BLOCKS, LH_KG, out, in);
+        }
+    }
+    pt[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1: delta propagation
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void mlp_delta_kernel(
+    const float *__restrict__ packed_t, const float *__restrict__ secb, const float *__restrict__ d_raw,
+    int64_t p_begin, int64_t p_count, const float *__restrict__ act, float *__restrict__ gst, int64_t n_pt) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+    const int64_t pt = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t pl = pt * 32 + j;
+    const bool live = pl < p_count;
+
+    Stream st{packed_t, lds, wave, lane};
+    st.prologue(secb, T_TOTAL_CHUNKS);
+
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) d = reinterpret_cast<const float4 *>(d_raw)[p_begin + pl];
+    {   // d_raw^T rows 0..3 of tile GT_D (units 0..3 = registers 0..3 of the lower half-wave)
+        f32x16 dt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dt[r] = 0.f;
+        if (hh == 0) { dt[0] = d.x; dt[1] = d.y; dt[2] = d.z; dt[3] = d.w; }
+        store_tile(stash_block(gst, GT_D, n_pt, pt), dt, j, hh);
+    }
+    auto act_tile = [&](int row_tile) { return load_tile(stash_block(const_cast<float *>(act), row_tile, n_pt, pt), j, hh); };
+    auto put = [&](int row_tile, const f32x16 &t) { store_tile(stash_block(gst, row_tile, n_pt, pt), t, j, hh); };
+
+    f32x16 vt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vt[t] = act_tile(AT_V + t);
+
+    __syncthreads();
+    const float *sb = lds + RING_FLOATS;
+    f32x4 a = st.first_block();
+
+    // grad wrt view-branch pre-activation: relu'(v) . (W_rgb^T d_rgb)
+    f32x16 gv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u0 = 32 * t + 8 * q + 4 * hh;
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + u0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 128 + u0);
+            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 256 + u0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float val = fmaf(w2[s], d.z, fmaf(w1[s], d.y, w0[s] * d.x));
+                gv[t][4 * q + s] = vt[t][4 * q + s] > 0.f ? val : 0.f;
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) put(GT_V + t, gv[t]);
+
+    // grad wrt feature = W_views[:, :256]^T gv   (feature_linear has no activation)
+    f32x16 g[8], gn[8];
+    run_layer<8, 16, false>(st, 0, a,
+        [&](auto kg, auto s) { return gv[kg.value >> 2][4 * (kg.value & 3) + s.value]; }, NoPre{},
+        [&](auto ti, const f32x16 &acc, int) { g[ti.value] = acc; put(GT_F + ti.value, acc); }, T_TOTAL_CHUNKS);
+
+    // G_7 = relu'(h7) . (W_feat^T g_feat + w_alpha d_sigma)
+    run_layer<8, 32, false>(st, T_VIEWS_BLOCKS / CHUNK_BLOCKS, a,
+        [&](auto kg, auto s) { return g[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
+        [&](auto ti) { return act_tile(AT_H + 56 + ti.value); },
+        [&](auto ti, const f32x16 &acc, const f32x16 &hv) {
+            f32x16 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wa = *reinterpret_cast<const f32x4 *>(sb + SB_WALPHA + 32 * ti.value + 8 * q + 4 * hh);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    o[4 * q + s] = hv[4 * q + s] > 0.f ? fmaf(wa[s], d.w, acc[4 * q + s]) : 0.f;
+            }
+            gn[ti.value] = o;
+            put(GT_G + 56 + ti.value, o);
+        }, T_TOTAL_CHUNKS);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) g[t] = gn[t];
+
+    // G_m = relu'(h_m) . W_{m+1}^T G_{m+1},  m = 6..0   (layer 5 contributes its h4 columns only)
+#pragma unroll 1
+    for (int m = 6; m >= 0; --m) {
+        run_layer<8, 32, false>(st, (T_VIEWS_BLOCKS + (7 - m) * T_LAYER_BLOCKS) / CHUNK_BLOCKS, a,
+            [&](auto kg, auto s) { return g[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
+            [&](auto ti) { return act_tile(AT_H + 8 * m + ti.value); },
+            [&](auto ti, const f32x16 &acc, const f32x16 &hv) {
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = hv[r] > 0.f ? acc[r] : 0.f;
+                gn[ti.value] = o;
+                put(GT_G + 8 * m + ti.value, o);
+            }, T_TOTAL_CHUNKS);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) g[t] = gn[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B2: weight gradients
+// ------------------------------------------------------------------------------------------------
+struct Gemm {
+    int g_tile0;            // first row tile of the G operand (gradient stash)
+    int a_tile0[2];         // activation stash row tiles: segment 0, segment 1
+    int a_count0;           // k tiles in segment 0 (the rest of KT belong to segment 1)
+    float *dW;              // natural [out][in] gradient tensor
+    int ldw;                // its row length
+    int col0[2];            // first column of each segment
+    int valid[2];           // real columns in each segment (padding columns are skipped)
+    float *db;              // bias gradient or null
+    int extra;              // 0 none, 1 sigma row (alpha_linear), 2 rgb rows (rgb_linear)
+    float *dWx, *dbx;       // gradients of the extra rows
+};
+struct GemmTable { Gemm g[11]; };
+
+constexpr int W_STAGE_BLOCKS = 18;                         // max blocks per stage (views: 4+9+4+1)
+constexpr int W_STAGE_FLOATS = W_STAGE_BLOCKS * TILE_FLOATS;
+
+// one 4 KB [32 units][32 points] block -> LDS, 16-B pieces XOR-swizzled by ((row>>1)&7) on the
+// SOURCE side (LDS-DMA writes linearly)
+__device__ __forceinline__ void stage_block_piece(const float *__restrict__ blk, float *lds_dst, int k, int lane) {
+    const int r = 8 * k + (lane >> 3), c = lane & 7;
+    glds16(blk + r * 32 + ((c ^ ((r >> 1) & 7)) << 2), lds_dst + k * 256);
+}
+__device__ __forceinline__ f32x4 read_piece(const float *tile, int row, int cw) {
+    return *reinterpret_cast<const f32x4 *>(tile + row * 32 + ((cw ^ ((row >> 1) & 7)) << 2));
+}
+
+template <int NTW, int KT>
+__device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act,
+                                           const float *__restrict__ gst, int64_t n_pt, int64_t pt0, int64_t pt1,
+                                           float *lds, int wave, int lane) {
+    constexpr int NT = 4 * NTW;
+    const int i = lane & 31, hh = lane >> 5;
+    const int nextra = G.extra == 2 ? 5 : (G.extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
+    const int nblk = NT + KT + nextra;
+
+    auto block_src = [&](int b, int64_t pt) -> const float * {
+        if (b < NT) return gst + ((int64_t)(G.g_tile0 + b) * n_pt + pt) * TILE_FLOATS;
+        b -= NT;
+        if (b < KT) {
+            const int tile = b < G.a_count0 ? G.a_tile0[0] + b : G.a_tile0[1] + (b - G.a_count0);
+            return act + ((int64_t)tile * n_pt + pt) * TILE_FLOATS;
+        }
+        b -= KT;
+        if (G.extra == 2 && b < 4) return act + ((int64_t)(AT_V + b) * n_pt + pt) * TILE_FLOATS;
+        return gst + ((int64_t)GT_D * n_pt + pt) * TILE_FLOATS;
+    };
+    auto issue_stage = [&](int64_t pt, int buf) {
+        float *dst = lds + buf * W_STAGE_FLOATS;
+        for (int q = wave; q < nblk * 4; q += 4)
+            stage_block_piece(block_src(q >> 2, pt), dst + (q >> 2) * TILE_FLOATS, q & 3, lane);
+    };
+
+    f32x16 acc[NTW][KT];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[NTW];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a) bsum[a] = 0.f;
+    float xw[12], xb[3];                               // extra-row accumulators (sigma: xw[0..7], xb[0])
+#pragma unroll
+    for (int q = 0; q < 12; ++q) xw[q] = 0.f;
+    xb[0] = xb[1] = xb[2] = 0.f;
+
+    issue_stage(pt0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t pt = pt0; pt < pt1; ++pt, buf ^= 1) {
+        if (pt + 1 < pt1) issue_stage(pt + 1, buf ^ 1);
+        const float *stg = lds + buf * W_STAGE_FLOATS;
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int cw = 2 * pg + hh;
+            f32x4 A[NTW], Bv[KT];
+#pragma unroll
+            for (int a = 0; a < NTW; ++a) {
+                A[a] = read_piece(stg + (wave * NTW + a) * TILE_FLOATS, i, cw);
+                bsum[a] += (A[a][0] + A[a][1]) + (A[a][2] + A[a][3]);
+            }
+#pragma unroll
+            for (int b = 0; b < KT; ++b) Bv[b] = read_piece(stg + (NT + b) * TILE_FLOATS, i, cw);
+#pragma unroll
+            for (int a = 0; a < NTW; ++a)
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[a][b] = mfma(A[a][s], Bv[b][s], acc[a][b]);
+            if (G.extra == 1 && wave == 0) {           // d(alpha_linear.weight)[k] = sum_p d_sigma[p] h7[k][p]
+                const f32x4 ds = read_piece(stg + (NT + KT) * TILE_FLOATS, 3, cw);
+                if constexpr (KT == 8) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) xw[b] = fmaf(ds[s], Bv[b][s], xw[b]);
+                }
+                xb[0] += (ds[0] + ds[1]) + (ds[2] + ds[3]);
+            }
+            if (G.extra == 2 && wave == 0) {           // d(rgb_linear.weight)[c][k] = sum_p d_rgb[c][p] v[k][p]
+                const float *xt = stg + (NT + KT) * TILE_FLOATS;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 dc = read_piece(xt + 4 * TILE_FLOATS, c, cw);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 vv = read_piece(xt + t * TILE_FLOATS, i, cw);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) xw[c * 4 + t] = fmaf(dc[s], vv[s], xw[c * 4 + t]);
+                    }
+                    xb[c] += (dc[0] + dc[1]) + (dc[2] + dc[3]);
+                }
+            }
+        }
+        __syncthreads();          // next stage landed (vmcnt(0)) and everyone is done with `buf`
+    }
+
+    // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
+#pragma unroll
+    for (int a = 0; a < NTW; ++a) {
+        const int n0 = 32 * (wave * NTW + a);
+#pragma unroll
+        for (int b = 0; b < KT; ++b) {
+            const int seg = b < G.a_count0 ? 0 : 1;
+            const int kcol = 32 * (seg ? b - G.a_count0 : b) + i;
+            if (kcol < G.valid[seg]) {
+                float *dst = G.dW + (int64_t)(n0 + 4 * hh) * G.ldw + G.col0[seg] + kcol;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    atomicAdd(dst + (int64_t)(8 * (r >> 2) + (r & 3)) * G.ldw, acc[a][b][r]);
+            }
+        }
+        if (G.db) {
+            const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (hh == 0) atomicAdd(G.db + n0 + i, tot);
+        }
+    }
+    if (G.extra == 1 && wave == 0) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const float tot = xw[b] + __shfl_xor(xw[b], 32, 64);
+            if (hh == 0) atomicAdd(G.dWx + 32 * b + i, tot);
+        }
+        const float tb = xb[0] + __shfl_xor(xb[0], 32, 64);
+        if (lane == 0) atomicAdd(G.dbx, tb);
+    }
+    if (G.extra == 2 && wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float tot = xw[c * 4 + t] + __shfl_xor(xw[c * 4 + t], 32, 64);
+                if (hh == 0) atomicAdd(G.dWx + c * 128 + 32 * t + i, tot);
+            }
+            const float tb = xb[c] + __shfl_xor(xb[c], 32, 64);
+            if (lane == 0) atomicAdd(G.dbx + c, tb);
+        }
+    }
+}
+
+// blockIdx.y: 0..7 the eight 256x256 products, 8..9 the two 256x64 products, 10 the view branch
+__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(GemmTable tab, const float *__restrict__ act,
+                                                          const float *__restrict__ gst, int64_t n_pt,
+                                                          int stages_per_slab) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = blockIdx.y;
+    const int64_t pt0 = (int64_t)blockIdx.x * stages_per_slab;
+    int64_t pt1 = pt0 + stages_per_slab;
+    if (pt1 > n_pt) pt1 = n_pt;
+    if (pt0 >= pt1) return;
+    const Gemm &G = tab.g[id];
+    if (id < 8) wgrad_body<2, 8>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else if (id < 10) wgrad_body<2, 2>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else wgrad_body<1, 9>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+static int64_t n_point_tiles(int64_t tile_points) { return ((tile_points + 127) / 128) * 4; }
+
+static GemmTable make_table(float *const *g) {
+    GemmTable t{};
+    auto hidden = [&](int slot, int l, int act_tile0, int col0, int ldw, bool bias) {
+        Gemm &G = t.g[slot];
+        G.g_tile0 = GT_G + 8 * l; G.a_tile0[0] = act_tile0; G.a_tile0[1] = 0; G.a_count0 = 8;
+        G.dW = g[2 * l]; G.ldw = ldw; G.col0[0] = col0; G.col0[1] = 0; G.valid[0] = 256; G.valid[1] = 0;
+        G.db = bias ? g[2 * l + 1] : nullptr; G.extra = 0; G.dWx = G.dbx = nullptr;
+    };
+    hidden(0, 1, AT_H + 0, 0, 256, true);
+    hidden(1, 2, AT_H + 8, 0, 256, true);
+    hidden(2, 3, AT_H + 16, 0, 256, true);
+    hidden(3, 4, AT_H + 24, 0, 256, true);
+    hidden(4, 5, AT_H + 32, 63, 319, true);              // layer 5, h4 columns
+    hidden(5, 6, AT_H + 40, 0, 256, true);
+    hidden(6, 7, AT_H + 48, 0, 256, true);
+    {   // feature_linear (+ the sigma row of alpha_linear)
+        Gemm &G = t.g[7];
+        G.g_tile0 = GT_F; G.a_tile0[0] = AT_H + 56; G.a_count0 = 8; G.dW = g[P_WF]; G.ldw = 256;
+        G.col0[0] = 0; G.valid[0] = 256; G.db = g[P_BF]; G.extra = 1; G.dWx = g[P_WA]; G.dbx = g[P_BA];
+    }
+    auto encoded = [&](int slot, int l, int ldw, bool bias) {   // products with the 63-channel encoding
+        Gemm &G = t.g[slot];
+        G.g_tile0 = GT_G + 8 * l; G.a_tile0[0] = AT_EMB; G.a_count0 = 2; G.dW = g[2 * l]; G.ldw = ldw;
+        G.col0[0] = 0; G.valid[0] = 63; G.db = bias ? g[2 * l + 1] : nullptr; G.extra = 0;
+    };
+    encoded(8, 0, 63, true);
+    encoded(9, 5, 319, false);
+    {   // view branch (+ the three rows of rgb_linear)
+        Gemm &G = t.g[10];
+        G.g_tile0 = GT_V; G.a_tile0[0] = AT_FEAT; G.a_tile0[1] = AT_EDIR; G.a_count0 = 8; G.dW = g[P_WV];
+        G.ldw = 283; G.col0[0] = 0; G.col0[1] = 256; G.valid[0] = 256; G.valid[1] = 27; G.db = g[P_BV];
+        G.extra = 2; G.dWx = g[P_WR]; G.dbx = g[P_BR];
+    }
+    return t;
+}
+
+static int backward_impl(const float *packed, const float *a, const float *b, int64_t P, int S,
+                         const float *d_raw, float *const *grads_host, void *workspace, int64_t tile_points,
+                         bool from_rays, void *stream) {
+    if (tile_points < 128) return MVIP_EINVAL;
+    hipStream_t s = as_stream(stream);
+    float *ws = reinterpret_cast<float *>(workspace);
+    float *packed_t = ws;
+    const int64_t n_pt_max = n_point_tiles(tile_points);
+    float *act = ws + T_FLOATS;
+    float *gst = act + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
+    hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
+    const GemmTable tab = make_table(grads_host);
+    for (int64_t p0 = 0; p0 < P; p0 += tile_points) {
+        const int64_t pc = (P - p0 < tile_points) ? (P - p0) : tile_points;
+        const int64_t n_pt = n_point_tiles(pc);
+        int rc = mlp_forward_launch(packed, a, b, p0, pc, S, nullptr, act, n_pt, from_rays, stream);
+        if (rc != MVIP_OK) return rc;
+        const dim3 grid1((unsigned)(n_pt / 4)), block(256);
+        hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
+                           gst, n_pt);
+        int sps = (int)((n_pt + 63) / 64);
+        if (sps < 1) sps = 1;
+        if (sps > 32) sps = 32;
+        const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), 11);
+        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab, act, gst, n_pt, sps);
+    }
+    return check_launch();
+}
+
+}  // namespace mvip
+
+using namespace mvip;
+
+extern "C" int64_t mvip_mlp_backward_workspace_bytes(int64_t tile_points) {
+    if (tile_points < 128) return -1;
+    const int64_t n_pt = n_point_tiles(tile_points);
+    return ((int64_t)T_FLOATS + (int64_t)(AT_TILES + GT_TILES) * n_pt * TILE_FLOATS) * 4;
+}
+
+extern "C" int mvip_mlp_backward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
+                                      const float *d_raw, float *const *grads_host, void *workspace,
+                                      int64_t tile_points, int precision, void *stream) {
+    if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (precision != 0) return MVIP_EUNSUP;
+    if (B == 0) return MVIP_OK;
+    if (!packed || !rows || !z || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
+    for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
+    return backward_impl(packed, rows, z, B * S, S, d_raw, grads_host, workspace, tile_points, true, stream);
+}
+
+extern "C" int mvip_mlp_backward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
+                                        const float *d_raw, float *const *grads_host, void *workspace,
+                                        int64_t tile_points, int precision, void *stream) {
+    if (P < 0) return MVIP_EINVAL;
+    if (precision != 0) return MVIP_EUNSUP;
+    if (P == 0) return MVIP_OK;
+    if (!packed || !pts || !dirs || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
+    for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
+    return backward_impl(packed, pts, dirs, P, 1, d_raw, grads_host, workspace, tile_points, false, stream);
+}

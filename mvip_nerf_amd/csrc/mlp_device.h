@@ -53,10 +53,10 @@ struct Stream {
         for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 4)
             glds16(secb + b * BLOCK_FLOATS + lane * 4, lds + RING_FLOATS + b * BLOCK_FLOATS);
     }
-    __device__ __forceinline__ void prologue() const {
-        load_section_b(packed + SEC_A_FLOATS);
-        issue_chunk(0, 0);
-        issue_chunk(1, 1);
+    __device__ __forceinline__ void prologue(const float *secb, int total_chunks = TOTAL_CHUNKS) const {
+        load_section_b(secb);
+        issue_chunk(0, 0, total_chunks);
+        issue_chunk(1, 1, total_chunks);
     }
     template <int BI>
     __device__ __forceinline__ f32x4 read_block() const {
@@ -71,12 +71,14 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 }
 
 // One linear layer on the wave's 32 columns: NT output tiles x KG k-groups, A from the ring,
-// B from registers through bop(kg, s); epi(ti, acc) consumes each finished 32x32 tile.
-// `g0` = chunk index of the layer's first block (a multiple of NSLOT for every layer).
-template <int NT, int KG, bool LAST, class BOp, class Epi>
-__device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BOp bop, Epi epi,
+// B from registers through bop(kg, s).  pre(ti) runs before a tile's MFMA chain (e.g. to start
+// loads the epilogue needs) and its result is handed to epi(ti, acc, pre_value), which consumes
+// each finished 32x32 tile.  `g0` = chunk index of the layer's first block (a multiple of NSLOT).
+template <int NT, int KG, bool LAST, class BOp, class Pre, class Epi>
+__device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BOp bop, Pre pre, Epi epi,
                                           int total_chunks = TOTAL_CHUNKS) {
     static_for<NT>([&](auto ti) {
+        auto pv = pre(ti);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -94,9 +96,10 @@ __device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BO
             if constexpr (bi % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
             a = an;
         });
-        epi(ti, acc);
+        epi(ti, acc, pv);
     });
 }
+struct NoPre { template <class T> __device__ __forceinline__ int operator()(T) const { return 0; } };
 
 // accumulator tile (+ bias row, natural unit order) -> activation tile
 template <bool RELU>
@@ -170,17 +173,39 @@ __device__ __forceinline__ void load_point(const float *__restrict__ a, const fl
     }
 }
 
-// activation tiles -> [unit][point] rows in global memory (128-B contiguous per half-wave)
-template <int NT>
-__device__ __forceinline__ void store_tiles(float *__restrict__ base, int64_t pitch, const f32x16 *tiles, int j,
-                                            int hh) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3);
-            base[(int64_t)row * pitch + j] = tiles[t][r];
-        }
+// Stash layout shared by the backward kernels: [row_tile][point_tile][32 units][32 points] fp32,
+// i.e. contiguous 4 KB blocks.  A wave writes/reads its own accumulator tile with 16 dword
+// accesses at compile-time offsets (128 B contiguous per half-wave); the weight-gradient GEMM
+// reads whole blocks by LDS-DMA.
+constexpr int TILE_FLOATS = 1024;
+__device__ __forceinline__ float *stash_block(float *base, int row_tile, int64_t n_pt, int64_t pt) {
+    return base + ((int64_t)row_tile * n_pt + pt) * TILE_FLOATS;
 }
+__device__ __forceinline__ void store_tile(float *__restrict__ block, const f32x16 &tile, int j, int hh) {
+    float *p = block + hh * 128 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[(8 * (r >> 2) + (r & 3)) * 32] = tile[r];
+}
+__device__ __forceinline__ f32x16 load_tile(const float *__restrict__ block, int j, int hh) {
+    const float *p = block + hh * 128 + j;
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = p[(8 * (r >> 2) + (r & 3)) * 32];
+    return t;
+}
+
+// row-tile indices of the activation stash (forward, STASH=true) ...
+constexpr int AT_H = 0;        // h_l at 8l .. 8l+7, l = 0..7
+constexpr int AT_FEAT = 64;    // feature_linear output (no activation)
+constexpr int AT_V = 72;       // view-branch hidden (4 tiles)
+constexpr int AT_EMB = 76;     // encoded point (2 tiles, 63 real channels)
+constexpr int AT_EDIR = 78;    // encoded direction (1 tile, 27 real channels)
+constexpr int AT_TILES = 79;
+// ... and of the pre-activation-gradient stash written by the delta kernel
+constexpr int GT_G = 0;        // G_l at 8l .. 8l+7
+constexpr int GT_F = 64;       // grad wrt feature
+constexpr int GT_V = 72;       // grad wrt view-branch pre-activation (4 tiles)
+constexpr int GT_D = 76;       // rows 0..3: d_raw transposed (rgb0, rgb1, rgb2, sigma)
+constexpr int GT_TILES = 77;
 
 }  // namespace mvip

@@ -26,18 +26,19 @@ using namespace mlp;
 template <bool FROM_RAYS, bool STASH>
 __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     const float *__restrict__ packed, const float *__restrict__ in_a, const float *__restrict__ in_b,
-    int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash) {
+    int64_t p_begin, int64_t p_count, int S, float *__restrict__ raw, float *__restrict__ stash, int64_t n_pt) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hh = lane >> 5;
-    const int64_t tile0 = (int64_t)blockIdx.x * 128;
-    int64_t p = tile0 + wave * 32 + j;
-    const bool live = p < P;
-    if (!live) p = P - 1;
+    const int64_t pt = (int64_t)blockIdx.x * 4 + wave;           // 32-point tile of this wave
+    int64_t pl = pt * 32 + j;                                     // index inside [0, p_count)
+    const bool live = pl < p_count;
+    if (!live) pl = p_count - 1;
+    const int64_t p = p_begin + pl;
 
     Stream st{packed, lds, wave, lane};
-    st.prologue();
+    st.prologue(packed + SEC_A_FLOATS);
 
     // ---- inputs: point and unit view direction of this lane's column ----
     float px, py, pz, vx, vy, vz;
@@ -47,41 +48,40 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     encode_tile<63>(px, py, pz, hh, 0, emb[0]);
     encode_tile<63>(px, py, pz, hh, 1, emb[1]);
     encode_tile<27>(vx, vy, vz, hh, 0, edir);
+    auto stash_tile = [&](int row_tile, const f32x16 &t) {
+        if constexpr (STASH) store_tile(stash_block(stash, row_tile, n_pt, pt), t, j, hh);
+    };
+    stash_tile(AT_EMB, emb[0]);
+    stash_tile(AT_EMB + 1, emb[1]);
+    stash_tile(AT_EDIR, edir);
 
     __syncthreads();                                  // chunks 0,1 and section B have landed
     const float *sb = lds + RING_FLOATS;
     f32x4 a = st.first_block();
 
     f32x16 h[8], o[8];
-    float *stash_pt = STASH ? stash + (tile0 + wave * 32) : nullptr;   // [unit][P] rows, column = point
-    const int64_t spitch = STASH ? ((P + 127) / 128) * 128 : 0;
-    int srow = 0;
-    auto stash_tiles = [&](const f32x16 *t, auto ntiles) {
-        if constexpr (STASH) {
-            store_tiles<decltype(ntiles)::value>(stash_pt + (int64_t)srow * spitch, spitch, t, j, hh);
-            srow += decltype(ntiles)::value * 32;
-        }
-    };
 
     // ---- layer 0: 63(+1) -> 256 ----
     run_layer<L0_NT, L0_KG, false>(st, 0, a,
         [&](auto kg, auto s) { return emb[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
-        [&](auto ti, const f32x16 &acc) { o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + 32 * ti.value, hh); });
+        NoPre{}, [&](auto ti, const f32x16 &acc, int) {
+            o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + 32 * ti.value, hh);
+            stash_tile(AT_H + ti.value, o[ti.value]);
+        });
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
-    stash_tiles(h, ic<8>{});
 
     // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         run_layer<LH_NT, LH_KG, false>(st, OFF_L1 / CHUNK_BLOCKS + (l - 1) * (LH_BLOCKS / CHUNK_BLOCKS), a,
             [&](auto kg, auto s) { return h[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
-            [&](auto ti, const f32x16 &acc) {
+            NoPre{}, [&](auto ti, const f32x16 &acc, int) {
                 o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + l * 256 + 32 * ti.value, hh);
+                stash_tile(AT_H + 8 * l + ti.value, o[ti.value]);
             });
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[t] = o[t];
-        stash_tiles(h, ic<8>{});
     }
 
     // ---- layer 5: cat[encoded point (64), h4 (256)] -> 256 ----
@@ -90,22 +90,24 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             if constexpr (kg.value < 8) return emb[kg.value >> 2][4 * (kg.value & 3) + s.value];
             else return h[(kg.value - 8) >> 2][4 * ((kg.value - 8) & 3) + s.value];
         },
-        [&](auto ti, const f32x16 &acc) { o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + 5 * 256 + 32 * ti.value, hh); });
+        NoPre{}, [&](auto ti, const f32x16 &acc, int) {
+            o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + 5 * 256 + 32 * ti.value, hh);
+            stash_tile(AT_H + 40 + ti.value, o[ti.value]);
+        });
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
-    stash_tiles(h, ic<8>{});
 
     // ---- layers 6, 7 ----
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
         run_layer<LH_NT, LH_KG, false>(st, OFF_L6 / CHUNK_BLOCKS + (l - 6) * (LH_BLOCKS / CHUNK_BLOCKS), a,
             [&](auto kg, auto s) { return h[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
-            [&](auto ti, const f32x16 &acc) {
+            NoPre{}, [&](auto ti, const f32x16 &acc, int) {
                 o[ti.value] = bias_relu<true>(acc, sb + SB_BIAS + l * 256 + 32 * ti.value, hh);
+                stash_tile(AT_H + 8 * l + ti.value, o[ti.value]);
             });
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[t] = o[t];
-        stash_tiles(h, ic<8>{});
     }
 
     // ---- sigma = alpha_linear(h7): a 256-long dot product per point, on the VALU ----
@@ -116,8 +118,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     // ---- feature = feature_linear(h7) (no activation) ----
     run_layer<LH_NT, LH_KG, false>(st, OFF_FEAT / CHUNK_BLOCKS, a,
         [&](auto kg, auto s) { return h[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
-        [&](auto ti, const f32x16 &acc) { o[ti.value] = bias_relu<false>(acc, sb + SB_BFEAT + 32 * ti.value, hh); });
-    stash_tiles(o, ic<8>{});
+        NoPre{}, [&](auto ti, const f32x16 &acc, int) {
+            o[ti.value] = bias_relu<false>(acc, sb + SB_BFEAT + 32 * ti.value, hh);
+            stash_tile(AT_FEAT + ti.value, o[ti.value]);
+        });
 
     // ---- view branch: cat[feature (256), encoded dir (27+5)] -> 128, relu ----
     f32x16 v[4];
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             if constexpr (kg.value < 32) return o[kg.value >> 2][4 * (kg.value & 3) + s.value];
             else return edir[4 * (kg.value - 32) + s.value];
         },
-        [&](auto ti, const f32x16 &acc) { v[ti.value] = bias_relu<true>(acc, sb + SB_BVIEWS + 32 * ti.value, hh); });
-    stash_tiles(v, ic<4>{});
+        NoPre{}, [&](auto ti, const f32x16 &acc, int) {
+            v[ti.value] = bias_relu<true>(acc, sb + SB_BVIEWS + 32 * ti.value, hh);
+            stash_tile(AT_V + ti.value, v[ti.value]);
+        });
 
     // ---- rgb = rgb_linear(v): three 128-long dot products ----
     float r0 = dot_tiles<4>(v, sb + SB_WRGB, hh);
@@ -136,30 +142,27 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     r0 += __shfl_xor(r0, 32, 64);
     r1 += __shfl_xor(r1, 32, 64);
     r2 += __shfl_xor(r2, 32, 64);
-    if (live && hh == 0) {
+    if (raw && live && hh == 0) {
         float4 out = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
         reinterpret_cast<float4 *>(raw)[p] = out;
     }
 }
 
-static int launch_forward(const float *packed, const float *a, const float *b, int64_t P, int S, float *raw,
-                          float *stash, bool from_rays, void *stream) {
-    if (P == 0) return MVIP_OK;
-    const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+// p_begin/p_count select a sub-range of the P points (used by the tiled backward); `stash`
+// (n_pt = p_count/32 rounded up to a multiple of 4 point tiles) receives the activations.
+int mlp_forward_launch(const float *packed, const float *a, const float *b, int64_t p_begin, int64_t p_count,
+                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream) {
+    if (p_count == 0) return MVIP_OK;
+    const dim3 grid((unsigned)((p_count + 127) / 128)), block(256);
     hipStream_t s = as_stream(stream);
     if (from_rays) {
-        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<true, true>), grid, block, 0, s, packed, a, b, P, S, raw, stash);
-        else hipLaunchKernelGGL((mlp_forward_kernel<true, false>), grid, block, 0, s, packed, a, b, P, S, raw, stash);
+        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<true, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
+        else hipLaunchKernelGGL((mlp_forward_kernel<true, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
     } else {
-        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, 0, s, packed, a, b, P, S, raw, stash);
-        else hipLaunchKernelGGL((mlp_forward_kernel<false, false>), grid, block, 0, s, packed, a, b, P, S, raw, stash);
+        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
+        else hipLaunchKernelGGL((mlp_forward_kernel<false, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
     }
     return check_launch();
-}
-
-int mlp_forward_with_stash(const float *packed, const float *a, const float *b, int64_t P, int S, float *raw,
-                           float *stash, bool from_rays, void *stream) {
-    return launch_forward(packed, a, b, P, S, raw, stash, from_rays, stream);
 }
 
 }  // namespace mvip
@@ -172,7 +175,7 @@ extern "C" int mvip_mlp_forward_rays(const float *packed, const float *rows, con
     if (precision != 0) return MVIP_EUNSUP;
     if (B == 0) return MVIP_OK;
     if (!packed || !rows || !z || !raw) return MVIP_EINVAL;
-    return launch_forward(packed, rows, z, B * S, S, raw, nullptr, true, stream);
+    return mlp_forward_launch(packed, rows, z, 0, B * S, S, raw, nullptr, 0, true, stream);
 }
 
 extern "C" int mvip_mlp_forward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
@@ -181,5 +184,5 @@ extern "C" int mvip_mlp_forward_points(const float *packed, const float *pts, co
     if (precision != 0) return MVIP_EUNSUP;
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !raw) return MVIP_EINVAL;
-    return launch_forward(packed, pts, dirs, P, 1, raw, nullptr, false, stream);
+    return mlp_forward_launch(packed, pts, dirs, 0, P, 1, raw, nullptr, 0, false, stream);
 }

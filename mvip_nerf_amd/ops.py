@@ -122,7 +122,25 @@ def mlp_unpack_grads(grad_packed, like):
 
 
 _WORKSPACE = {}
-BWD_TILE_POINTS = 32768
+BWD_TILE_POINTS = 65536          # points per recompute/backward tile (1.3 GB of stash workspace)
+
+
+def _zero_grads(device):
+    """24 zeroed gradient tensors carved from one flat allocation (one memset)."""
+    flat = torch.zeros(sum(_numel(s) for s in PARAM_SHAPES), device=device, dtype=_F32)
+    out, o = [], 0
+    for shp in PARAM_SHAPES:
+        n = _numel(shp)
+        out.append(flat[o:o + n].view(shp))
+        o += n
+    return out
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
 
 
 def _workspace(device, tile_points):
@@ -148,11 +166,11 @@ class _MLPRays(torch.autograd.Function):
     def backward(ctx, d_raw):
         rows, z, packed = ctx.saved_tensors
         B, S = z.shape
-        gp = torch.zeros(packed_floats(), device=z.device, dtype=_F32)
+        grads = _zero_grads(z.device)
         ws = _workspace(z.device, BWD_TILE_POINTS)
-        call('mvip_mlp_backward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(_f32c(d_raw)), ptr(gp), ptr(ws),
-             BWD_TILE_POINTS, 0, stream())
-        return (None, None, None, *mlp_unpack_grads(gp, None))
+        call('mvip_mlp_backward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(_f32c(d_raw)),
+             _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+        return (None, None, None, *grads)
 
 
 class _MLPPoints(torch.autograd.Function):
@@ -167,11 +185,11 @@ class _MLPPoints(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_raw):
         pts, dirs, packed = ctx.saved_tensors
-        gp = torch.zeros(packed_floats(), device=pts.device, dtype=_F32)
+        grads = _zero_grads(pts.device)
         ws = _workspace(pts.device, BWD_TILE_POINTS)
         call('mvip_mlp_backward_points', ptr(packed), ptr(pts), ptr(dirs), pts.shape[0], ptr(_f32c(d_raw)),
-             ptr(gp), ptr(ws), BWD_TILE_POINTS, 0, stream())
-        return (None, None, None, *mlp_unpack_grads(gp, None))
+             _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+        return (None, None, None, *grads)
 
 
 def mlp_rays(rows, z, packed, params):

@@ -225,3 +225,61 @@ def test_mlp_forward_rays_matches_points(cuda):
     dirs = rows[:, None, 8:11].expand(50, 64, 3)
     raw_p = ops.mlp_points(pts.reshape(-1, 3), dirs.reshape(-1, 3), packed, ps)
     np.testing.assert_array_equal(N(raw).reshape(-1, 4), N(raw_p))
+
+
+# ---------------------------------------------------------------------------------------------- MLP backward
+def _check_grads(g, prefix, named, rtol_norm, rtol_val):
+    for k, gr in named.items():
+        gr = N(gr).astype(np.float64).ravel()
+        stat = g[f'gstat/{prefix}{k}']
+        np.testing.assert_allclose(np.sqrt((gr * gr).sum()), stat[2], rtol=rtol_norm, err_msg=f'|grad {k}|')
+        np.testing.assert_allclose(gr[g[f'gidx/{prefix}{k}']], g[f'gval/{prefix}{k}'], rtol=rtol_val,
+                                   atol=rtol_val * 0.05 * stat[2], err_msg=f'grad {k}')
+
+
+def test_mlp_backward_points_golden(golden, cuda):
+    """d(sum(out*gout))/d(params) of the fused kernels vs autograd through the reference NeRF module."""
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    ps = [p.requires_grad_(True) for p in params_dev(g['seed'], cuda)]
+    raw = ops.mlp_points(T(g['pts'], cuda), T(g['dirs'], cuda), ops.mlp_pack(ps), ps)
+    (raw * T(g['gout'], cuda)).sum().backward()
+    _check_grads(g, '', {k: p.grad for k, p in zip(ops.PARAM_ORDER, ps)}, 2e-5, 2e-4)
+
+
+@pytest.mark.parametrize('P', [1, 100, 129, 700])
+def test_mlp_backward_ragged_vs_oracle(cuda, P):
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(1000 + P)
+    pts = rs.uniform(-3, 3, size=(P, 3)).astype(np.float32)
+    dirs = rs.normal(size=(P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    gout = rs.normal(size=(P, 4)).astype(np.float32)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in params_np(31).items()}
+    emb = torch.cat([O.posenc(torch.from_numpy(pts), 10), O.posenc(torch.from_numpy(dirs), 4)], -1)
+    (O.mlp_forward(sd, emb) * torch.from_numpy(gout)).sum().backward()
+    ps = [p.requires_grad_(True) for p in params_dev(31, cuda)]
+    raw = ops.mlp_points(T(pts, cuda), T(dirs, cuda), ops.mlp_pack(ps), ps)
+    (raw * T(gout, cuda)).sum().backward()
+    for k, p in zip(ops.PARAM_ORDER, ps):
+        ref = sd[k].grad.numpy()
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(N(p.grad), ref, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+
+
+def test_mlp_backward_tiled_equals_untiled(cuda):
+    """The recompute tile size is an implementation knob: results agree to fp32 summation order."""
+    from mvip_nerf_amd import ops
+    rows = T(bench_like_rays(40, seed=19), cuda)
+    z = ops.stratified_z(rows, 64, True)
+    gout = torch.randn(40, 64, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    outs = []
+    for tile in (65536, 512):
+        ops.BWD_TILE_POINTS = tile
+        ps = [p.requires_grad_(True) for p in params_dev(32, cuda)]
+        raw = ops.mlp_rays(rows, z, ops.mlp_pack(ps), ps)
+        (raw * gout).sum().backward()
+        outs.append([N(p.grad) for p in ps])
+    ops.BWD_TILE_POINTS = 65536
+    for a, b, k in zip(outs[0], outs[1], ops.PARAM_ORDER):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * (np.abs(a).max() + 1e-12), err_msg=k)

@@ -145,3 +145,25 @@ def test_train_mode_rng_stream_matches_reference_order(cuda):
                           err_msg='z_vals')
     for k in ('rgb_map', 'depth_map', 'acc_map', 'rgb0'):
         np.testing.assert_allclose(N(r[k]), ref[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+def test_render_rays_train_backward_golden(golden, cuda):
+    """Gradients of a loss on (rgb_map, rgb0, disp_map, depth_map) w.r.t. both MLPs, against autograd
+    through the reference's render_rays in pytest-deterministic train mode."""
+    from mvip_nerf_amd import run, ops
+    g = golden('render_rays_pytest_train')
+    tr, te, grad_vars, _ = build(g['seed_coarse'], g['seed_fine'], cuda)
+    r = run.render_rays(T(g['rays'], cuda), tr['network_fn'], tr['network_query_fn'], 64, retraw=True, lindisp=True,
+                        perturb=1., N_importance=64, network_fine=tr['network_fine'], white_bkgd=True,
+                        raw_noise_std=1., pytest=True, need_alpha=True)
+    loss = ((r['rgb_map'] * T(g['g_rgb'], cuda)).sum() + (r['rgb0'] * T(g['g_rgb0'], cuda)).sum()
+            + (r['disp_map'] * T(g['g_disp'], cuda)).sum() + (r['depth_map'] * T(g['g_depth'], cuda)).sum())
+    np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=2e-4)
+    loss.backward()
+    for prefix, net in (('coarse.', tr['network_fn']), ('fine.', tr['network_fine'])):
+        for k, p in net.named_parameters():
+            gr = N(p.grad).astype(np.float64).ravel()
+            stat = g[f'gstat/{prefix}{k}']
+            np.testing.assert_allclose(np.sqrt((gr * gr).sum()), stat[2], rtol=2e-3, err_msg=prefix + k)
+            np.testing.assert_allclose(gr[g[f'gidx/{prefix}{k}']], g[f'gval/{prefix}{k}'], rtol=5e-3,
+                                       atol=2e-3 * stat[2] / np.sqrt(gr.size), err_msg=prefix + k)
