@@ -35,7 +35,8 @@ def make_args():
         alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
         lrate=3e-3, basedir='/tmp/mvip_bench', expname='none', ft_path=None, no_reload=True, perturb=1.,
         N_samples=N_SAMPLES, white_bkgd=True, raw_noise_std=1., dataset_type='llff', no_ndc=True, lindisp=True,
-        sigma_loss=False)
+        sigma_loss=False, N_rand=1024, chunk=1 << 15, lrate_decay=10, depth_lambda=0.1, sds_loss_weight=1e-4,
+        no_coarse=False)
 
 
 def orbit_pose(k, device):
@@ -95,7 +96,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--mode', default='render', choices=['render'])
+    ap.add_argument('--train-steps', type=int, default=3, help='second-stage iterations timed after the render leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -151,6 +152,30 @@ def main():
                    'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
                    'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
     }
+    # ---- second leg: the training iteration (masked render + 2 supervision batches, fwd+bwd+Adam) ----
+    if args.train_steps > 0:
+        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+        torch.manual_seed(1)
+        scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+        trainer = SecondStageTrainer(make_args(), scene, device, guidance=None, world=world, rank=rank, dist=dist)
+        trainer.step(0)
+        barrier()
+        t1 = time.perf_counter()
+        n_rays = 0
+        for k in range(args.train_steps):
+            _, nr = trainer.step(1 + k)
+            n_rays += nr
+        barrier()
+        dt_tr = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([dt_tr], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_tr = float(t.item())
+        result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
+                           'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
+                           'what': 'second-stage iteration without the diffusion prior: masked-set render '
+                                   '(11,544 rays) + 1024 colour rays + 1024 depth rays, losses, backward through '
+                                   'both MLPs, gradient all-reduce, Adam'}
     if rank == 0:
         result['roofline'] = kernel_roofline(run, te, device)
         if world == 1 and not args.no_cpu_baseline:

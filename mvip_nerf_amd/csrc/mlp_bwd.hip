@@ -205,24 +205,24 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                                            float *lds, int wave, int lane) {
     constexpr int NT = 4 * NTW;
     const int i = lane & 31, hh = lane >> 5;
-    const int nextra = G.extra == 2 ? 5 : (G.extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
+    const int extra = G.extra;
+    const int nextra = extra == 2 ? 5 : (extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
     const int nblk = NT + KT + nextra;
+    const int g_tile0 = G.g_tile0, a0 = G.a_tile0[0], a1 = G.a_tile0[1], ac0 = G.a_count0;
 
-    auto block_src = [&](int b, int64_t pt) -> const float * {
-        if (b < NT) return gst + ((int64_t)(G.g_tile0 + b) * n_pt + pt) * TILE_FLOATS;
-        b -= NT;
-        if (b < KT) {
-            const int tile = b < G.a_count0 ? G.a_tile0[0] + b : G.a_tile0[1] + (b - G.a_count0);
-            return act + ((int64_t)tile * n_pt + pt) * TILE_FLOATS;
+    // wave w stages rows 8w..8w+7 of every block of the stage (one LDS-DMA per block and wave)
+    const int r = 8 * wave + (lane >> 3), c = lane & 7;
+    const int lane_off = r * 32 + ((c ^ ((r >> 1) & 7)) << 2);
+    auto issue_stage = [&](int64_t pt, float *dst) {
+        for (int b = 0; b < nblk; ++b) {
+            int tile;
+            const float *base = act;
+            if (b < NT) { tile = g_tile0 + b; base = gst; }
+            else if (b < NT + KT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
+            else if (extra == 2 && b < NT + KT + 4) tile = AT_V + (b - NT - KT);
+            else { tile = GT_D; base = gst; }
+            glds16(base + ((int64_t)tile * n_pt + pt) * TILE_FLOATS + lane_off, dst + b * TILE_FLOATS + wave * 256);
         }
-        b -= KT;
-        if (G.extra == 2 && b < 4) return act + ((int64_t)(AT_V + b) * n_pt + pt) * TILE_FLOATS;
-        return gst + ((int64_t)GT_D * n_pt + pt) * TILE_FLOATS;
-    };
-    auto issue_stage = [&](int64_t pt, int buf) {
-        float *dst = lds + buf * W_STAGE_FLOATS;
-        for (int q = wave; q < nblk * 4; q += 4)
-            stage_block_piece(block_src(q >> 2, pt), dst + (q >> 2) * TILE_FLOATS, q & 3, lane);
     };
 
     f32x16 acc[NTW][KT];
@@ -231,7 +231,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 #pragma unroll
         for (int b = 0; b < KT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
     float bsum[NTW];
 #pragma unroll
     for (int a = 0; a < NTW; ++a) bsum[a] = 0.f;
@@ -240,12 +240,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     for (int q = 0; q < 12; ++q) xw[q] = 0.f;
     xb[0] = xb[1] = xb[2] = 0.f;
 
-    issue_stage(pt0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t pt = pt0; pt < pt1; ++pt, buf ^= 1) {
-        if (pt + 1 < pt1) issue_stage(pt + 1, buf ^ 1);
-        const float *stg = lds + buf * W_STAGE_FLOATS;
+    auto compute_stage = [&](const float *stg) {
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg) {
             const int cw = 2 * pg + hh;
@@ -263,7 +258,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                 for (int b = 0; b < KT; ++b)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[a][b] = mfma(A[a][s], Bv[b][s], acc[a][b]);
-            if (G.extra == 1 && wave == 0) {           // d(alpha_linear.weight)[k] = sum_p d_sigma[p] h7[k][p]
+            if (extra == 1 && wave == 0) {             // d(alpha_linear.weight)[k] = sum_p d_sigma[p] h7[k][p]
                 const f32x4 ds = read_piece(stg + (NT + KT) * TILE_FLOATS, 3, cw);
                 if constexpr (KT == 8) {
 #pragma unroll
@@ -273,22 +268,36 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                 }
                 xb[0] += (ds[0] + ds[1]) + (ds[2] + ds[3]);
             }
-            if (G.extra == 2 && wave == 0) {           // d(rgb_linear.weight)[c][k] = sum_p d_rgb[c][p] v[k][p]
+            if (extra == 2 && wave == 0) {             // d(rgb_linear.weight)[c][k] = sum_p d_rgb[c][p] v[k][p]
                 const float *xt = stg + (NT + KT) * TILE_FLOATS;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const f32x4 dc = read_piece(xt + 4 * TILE_FLOATS, c, cw);
+                for (int cc = 0; cc < 3; ++cc) {
+                    const f32x4 dc = read_piece(xt + 4 * TILE_FLOATS, cc, cw);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const f32x4 vv = read_piece(xt + t * TILE_FLOATS, i, cw);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) xw[c * 4 + t] = fmaf(dc[s], vv[s], xw[c * 4 + t]);
+                        for (int s = 0; s < 4; ++s) xw[cc * 4 + t] = fmaf(dc[s], vv[s], xw[cc * 4 + t]);
                     }
-                    xb[c] += (dc[0] + dc[1]) + (dc[2] + dc[3]);
+                    xb[cc] += (dc[0] + dc[1]) + (dc[2] + dc[3]);
                 }
             }
         }
-        __syncthreads();          // next stage landed (vmcnt(0)) and everyone is done with `buf`
+    };
+
+    // double-buffered stages with COMPILE-TIME buffer addresses (so LDS-DMA writes into one buffer
+    // provably do not alias the ds_reads of the other and no wait is inserted between them)
+    float *buf0 = lds, *buf1 = lds + W_STAGE_FLOATS;
+    issue_stage(pt0, buf0);
+    __syncthreads();
+    for (int64_t pt = pt0; pt < pt1; pt += 2) {
+        if (pt + 1 < pt1) issue_stage(pt + 1, buf1);
+        compute_stage(buf0);
+        __syncthreads();          // stage pt+1 landed (vmcnt(0)) and everyone is done with buf0
+        if (pt + 1 >= pt1) break;
+        if (pt + 2 < pt1) issue_stage(pt + 2, buf0);
+        compute_stage(buf1);
+        __syncthreads();
     }
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
@@ -297,13 +306,13 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         const int n0 = 32 * (wave * NTW + a);
 #pragma unroll
         for (int b = 0; b < KT; ++b) {
-            const int seg = b < G.a_count0 ? 0 : 1;
-            const int kcol = 32 * (seg ? b - G.a_count0 : b) + i;
+            const int seg = b < ac0 ? 0 : 1;
+            const int kcol = 32 * (seg ? b - ac0 : b) + i;
             if (kcol < G.valid[seg]) {
                 float *dst = G.dW + (int64_t)(n0 + 4 * hh) * G.ldw + G.col0[seg] + kcol;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    atomicAdd(dst + (int64_t)(8 * (r >> 2) + (r & 3)) * G.ldw, acc[a][b][r]);
+                for (int q = 0; q < 16; ++q)
+                    atomicAdd(dst + (int64_t)(8 * (q >> 2) + (q & 3)) * G.ldw, acc[a][b][q]);
             }
         }
         if (G.db) {
@@ -311,7 +320,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
             if (hh == 0) atomicAdd(G.db + n0 + i, tot);
         }
     }
-    if (G.extra == 1 && wave == 0) {
+    if (extra == 1 && wave == 0) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const float tot = xw[b] + __shfl_xor(xw[b], 32, 64);
@@ -320,22 +329,33 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         const float tb = xb[0] + __shfl_xor(xb[0], 32, 64);
         if (lane == 0) atomicAdd(G.dbx, tb);
     }
-    if (G.extra == 2 && wave == 0) {
+    if (extra == 2 && wave == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int cc = 0; cc < 3; ++cc) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float tot = xw[c * 4 + t] + __shfl_xor(xw[c * 4 + t], 32, 64);
-                if (hh == 0) atomicAdd(G.dWx + c * 128 + 32 * t + i, tot);
+                const float tot = xw[cc * 4 + t] + __shfl_xor(xw[cc * 4 + t], 32, 64);
+                if (hh == 0) atomicAdd(G.dWx + cc * 128 + 32 * t + i, tot);
             }
-            const float tb = xb[c] + __shfl_xor(xb[c], 32, 64);
-            if (lane == 0) atomicAdd(G.dbx + c, tb);
+            const float tb = xb[cc] + __shfl_xor(xb[cc], 32, 64);
+            if (lane == 0) atomicAdd(G.dbx + cc, tb);
         }
     }
 }
 
+// The product table lives in device memory so that `tab[blockIdx.y]` is a handful of scalar loads
+// (a by-value kernel argument indexed at run time is demoted to scratch, and its reloads --
+// vector memory operations -- serialise every LDS-DMA behind an s_waitcnt vmcnt(0)).
+__global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) out[k] = tab.g[k];
+    }
+}
+
 // blockIdx.y: 0..7 the eight 256x256 products, 8..9 the two 256x64 products, 10 the view branch
-__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(GemmTable tab, const float *__restrict__ act,
+__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
+                                                          const float *__restrict__ act,
                                                           const float *__restrict__ gst, int64_t n_pt,
                                                           int stages_per_slab) {
     __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_FLOATS];
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(GemmTable tab, const 
     int64_t pt1 = pt0 + stages_per_slab;
     if (pt1 > n_pt) pt1 = n_pt;
     if (pt0 >= pt1) return;
-    const Gemm &G = tab.g[id];
+    const Gemm G = tab[id];
     if (id < 8) wgrad_body<2, 8>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
     else if (id < 10) wgrad_body<2, 2>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
     else wgrad_body<1, 9>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
@@ -356,6 +376,8 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(GemmTable tab, const 
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 static int64_t n_point_tiles(int64_t tile_points) { return ((tile_points + 127) / 128) * 4; }
+constexpr int TABLE_FLOATS = 1024;                      // room for the 11-entry product table
+static_assert(sizeof(Gemm) * 11 <= TABLE_FLOATS * 4, "table room");
 
 static GemmTable make_table(float *const *g) {
     GemmTable t{};
@@ -401,10 +423,12 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
     float *ws = reinterpret_cast<float *>(workspace);
     float *packed_t = ws;
     const int64_t n_pt_max = n_point_tiles(tile_points);
-    float *act = ws + T_FLOATS;
+    Gemm *tab_dev = reinterpret_cast<Gemm *>(ws + T_FLOATS);
+    float *act = ws + T_FLOATS + TABLE_FLOATS;
     float *gst = act + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
     hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
     const GemmTable tab = make_table(grads_host);
+    hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
     for (int64_t p0 = 0; p0 < P; p0 += tile_points) {
         const int64_t pc = (P - p0 < tile_points) ? (P - p0) : tile_points;
         const int64_t n_pt = n_point_tiles(pc);
@@ -417,7 +441,7 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         if (sps < 1) sps = 1;
         if (sps > 32) sps = 32;
         const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), 11);
-        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab, act, gst, n_pt, sps);
+        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab_dev, act, gst, n_pt, sps);
     }
     return check_launch();
 }
@@ -429,7 +453,7 @@ using namespace mvip;
 extern "C" int64_t mvip_mlp_backward_workspace_bytes(int64_t tile_points) {
     if (tile_points < 128) return -1;
     const int64_t n_pt = n_point_tiles(tile_points);
-    return ((int64_t)T_FLOATS + (int64_t)(AT_TILES + GT_TILES) * n_pt * TILE_FLOATS) * 4;
+    return ((int64_t)T_FLOATS + TABLE_FLOATS + (int64_t)(AT_TILES + GT_TILES) * n_pt * TILE_FLOATS) * 4;
 }
 
 extern "C" int mvip_mlp_backward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
