@@ -144,17 +144,22 @@ int mvip_sample_pdf(const float *bins, const float *weights, const float *u, int
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * a12  depth2xyz_torch + depth2normal_geo   DS_NeRF/run.py:1909-1940
- * depth [H,W]; intrinsics fx,fy,cx,cy; k odd window (31).  normals [3,H,W]:
- * n = (A^T A)^-1 A^T 1 over the zero-padded k x k window of back-projected points.
- * `moments` is a [9,H,W] workspace (kept for the backward). */
-int mvip_normal_fit_forward(const float *depth, int H, int W, float fx, float fy, float cx, float cy,
-                            int k, float *points /*[H,W,3] nullable*/, float *moments,
+ * a12  depth2xyz_torch                 DS_NeRF/run.py:1909-1922
+ * depth [H,W] -> points [H,W,3]: x=(w-cx)*z/fx, y=(h-cy)*z/fy, z.  Backward: g_points -> d_depth. */
+int mvip_depth2xyz(const float *depth, int H, int W, float fx, float fy, float cx, float cy,
+                   float *points, void *stream);
+int mvip_depth2xyz_backward(const float *g_points, int H, int W, float fx, float fy, float cx,
+                            float cy, float *d_depth, void *stream);
+
+/* a12  depth2normal_geo                DS_NeRF/run.py:1924-1940
+ * points PLANAR [3,H,W]; k odd window (31).  normals [3,H,W]: n = (A^T A)^-1 A^T 1 over the
+ * zero-padded k x k window.  `moments` [9,H,W] receives the window sums (kept for the backward);
+ * `scratch` is [9,H,W] for the forward and [18,H,W] for the backward. */
+int mvip_normal_fit_forward(const float *points, int H, int W, int k, float *moments, float *scratch,
                             float *normals, void *stream);
-int mvip_normal_fit_backward(const float *depth, const float *moments, const float *normals,
-                             const float *g_normals, int H, int W, float fx, float fy, float cx,
-                             float cy, int k, float *scratch /*[9,H,W]*/, float *d_depth,
-                             void *stream);
+int mvip_normal_fit_backward(const float *points, const float *moments, const float *normals,
+                             const float *g_normals, int H, int W, int k, float *scratch,
+                             float *d_points, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13/a14  elementwise core of the SDS step   DS_NeRF/guidance/sd_utils.py:406-413, :29-37

@@ -43,9 +43,10 @@ _SIGNATURES = {
     'mvip_sample_pdf_merge': (_int, [_c_f, _c_f, _c_f, _int, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f, _c_f,
                                      _c_f]),
     'mvip_sample_pdf': (_int, [_c_f, _c_f, _c_f, _int, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f]),
-    'mvip_normal_fit_forward': (_int, [_c_f, _int, _int, _flt, _flt, _flt, _flt, _int, _c_f, _c_f, _c_f, _c_f]),
-    'mvip_normal_fit_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _int, _int, _flt, _flt, _flt, _flt, _int, _c_f,
-                                        _c_f, _c_f]),
+    'mvip_depth2xyz': (_int, [_c_f, _int, _int, _flt, _flt, _flt, _flt, _c_f, _c_f]),
+    'mvip_depth2xyz_backward': (_int, [_c_f, _int, _int, _flt, _flt, _flt, _flt, _c_f, _c_f]),
+    'mvip_normal_fit_forward': (_int, [_c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_normal_fit_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f]),
     'mvip_sds_add_noise': (_int, [_c_f, _c_f, _flt, _flt, _i64, _c_f, _c_f]),
     'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
 }

@@ -1,0 +1,417 @@
+"""Stable-Diffusion-1.5-inpainting-shaped networks (UNet2DCondition 9->4, AutoencoderKL, CLIP ViT-L/14
+text tower, scaled-linear scheduler constants) written from the published architecture
+(SURVEY.md Appendix A.8), on PyTorch-ROCm.
+
+The reference obtains these from `diffusers` / `transformers` with the
+`runwayml/stable-diffusion-inpainting@fp16` weights (DS_NeRF/guidance/sd_utils.py:69-74).  Neither the
+library source nor the weights exist offline, so: the module/parameter names follow diffusers'
+state-dict layout (a real checkpoint can be loaded with `load_state_dict` once available), the
+weights are randomly initialised, and the network bodies are "parity unpinned" (DESIGN.md).  They
+exist so the SDS step can be executed and timed at its true shapes and FLOPs.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------- blocks
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb=None, groups=32, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout) if temb else None
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(F.silu(self.norm1(x)))
+        if self.time_emb_proj is not None:
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, ctx_dim=None, heads=8, bias=False):
+        super().__init__()
+        self.heads = heads
+        self.to_q = nn.Linear(dim, dim, bias=bias)
+        self.to_k = nn.Linear(ctx_dim or dim, dim, bias=bias)
+        self.to_v = nn.Linear(ctx_dim or dim, dim, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+
+    def forward(self, x, ctx=None, mask=None):
+        ctx = x if ctx is None else ctx
+        B, N, C = x.shape
+        q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
+        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.to_out[0](o.transpose(1, 2).reshape(B, N, C))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        a, g = self.proj(x).chunk(2, dim=-1)
+        return a * F.gelu(g)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, ctx_dim):
+        super().__init__()
+        self.norm1, self.attn1 = nn.LayerNorm(dim), Attention(dim, None, heads)
+        self.norm2, self.attn2 = nn.LayerNorm(dim), Attention(dim, ctx_dim, heads)
+        self.norm3, self.ff = nn.LayerNorm(dim), FeedForward(dim)
+
+    def forward(self, x, ctx):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), ctx)
+        return x + self.ff(self.norm3(x))
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, ch, heads, ctx_dim):
+        super().__init__()
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.proj_in = nn.Conv2d(ch, ch, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, ctx_dim)])
+        self.proj_out = nn.Conv2d(ch, ch, 1)
+
+    def forward(self, x, ctx):
+        B, C, H, W = x.shape
+        h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, ctx)
+        return x + self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=pad)
+        self.pad = pad
+
+    def forward(self, x):
+        if self.pad == 0:
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
+
+
+# ---------------------------------------------------------------------------------------------- UNet
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, heads, ctx_dim, attn, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb) for i in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, ctx_dim) for _ in range(2)]) if attn else None
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
+
+    def forward(self, x, temb, ctx):
+        outs = []
+        for i, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cprev, cout, skips, temb, heads, ctx_dim, attn, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D((cprev if i == 0 else cout) + skips[i], cout, temb)
+                                      for i in range(3)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, ctx_dim) for _ in range(3)]) if attn else None
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
+
+    def forward(self, x, skips, temb, ctx):
+        for i, r in enumerate(self.resnets):
+            x = r(torch.cat([x, skips.pop()], 1), temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class MidBlock(nn.Module):
+    def __init__(self, ch, temb, heads, ctx_dim):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb), ResnetBlock2D(ch, ch, temb)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ctx_dim)])
+
+    def forward(self, x, temb, ctx):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.linear_1, self.linear_2 = nn.Linear(cin, cout), nn.Linear(cout, cout)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+def timestep_sinusoid(t, dim):
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], -1)
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, in_channels=9, out_channels=4, block_out=(320, 640, 1280, 1280), heads=8, ctx_dim=768):
+        super().__init__()
+        temb = block_out[0] * 4
+        self.in_channels = in_channels
+        self.conv_in = nn.Conv2d(in_channels, block_out[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(block_out[0], temb)
+        self.down_blocks = nn.ModuleList()
+        c = block_out[0]
+        skip_ch = [c]
+        for i, co in enumerate(block_out):
+            last = i == len(block_out) - 1
+            self.down_blocks.append(DownBlock(c, co, temb, heads, ctx_dim, attn=not last, down=not last))
+            skip_ch += [co, co] + ([] if last else [co])
+            c = co
+        self.mid_block = MidBlock(c, temb, heads, ctx_dim)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(block_out))
+        for i, co in enumerate(rev):
+            skips = [skip_ch.pop() for _ in range(3)]
+            self.up_blocks.append(UpBlock(c, co, skips, temb, heads, ctx_dim, attn=i > 0, up=i < len(rev) - 1))
+            c = co
+        self.conv_norm_out = nn.GroupNorm(32, block_out[0])
+        self.conv_out = nn.Conv2d(block_out[0], out_channels, 3, padding=1)
+        self._t_dim = block_out[0]
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False):
+        t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
+        temb = self.time_embedding(timestep_sinusoid(t, self._t_dim).to(sample.dtype))
+        x = self.conv_in(sample)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, temb, encoder_hidden_states)
+            skips += outs
+        x = self.mid_block(x, temb, encoder_hidden_states)
+        for blk in self.up_blocks:
+            x = blk(x, skips, temb, encoder_hidden_states)
+        return (self.conv_out(F.silu(self.conv_norm_out(x))),)
+
+
+# ---------------------------------------------------------------------------------------------- VAE
+class VAEAttention(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(ch, ch), nn.Linear(ch, ch), nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        h = self.group_norm(x).reshape(B, C, H * W).transpose(1, 2)
+        o = F.scaled_dot_product_attention(self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None])[:, 0]
+        return x + self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W)
+
+
+class VAEMid(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, None, eps=1e-6), ResnetBlock2D(ch, ch, None, eps=1e-6)])
+        self.attentions = nn.ModuleList([VAEAttention(ch)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class Encoder(nn.Module):
+    def __init__(self, block_out=(128, 256, 512, 512), latent=4):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, block_out[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        c = block_out[0]
+        for i, co in enumerate(block_out):
+            blk = nn.Module()
+            blk.resnets = nn.ModuleList([ResnetBlock2D(c if k == 0 else co, co, None, eps=1e-6) for k in range(2)])
+            blk.downsamplers = nn.ModuleList([Downsample2D(co, pad=0)]) if i < len(block_out) - 1 else None
+            self.down_blocks.append(blk)
+            c = co
+        self.mid_block = VAEMid(c)
+        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for blk in self.down_blocks:
+            for r in blk.resnets:
+                x = r(x)
+            if blk.downsamplers is not None:
+                x = blk.downsamplers[0](x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class Decoder(nn.Module):
+    def __init__(self, block_out=(128, 256, 512, 512), latent=4):
+        super().__init__()
+        rev = list(reversed(block_out))
+        self.conv_in = nn.Conv2d(latent, rev[0], 3, padding=1)
+        self.mid_block = VAEMid(rev[0])
+        self.up_blocks = nn.ModuleList()
+        c = rev[0]
+        for i, co in enumerate(rev):
+            blk = nn.Module()
+            blk.resnets = nn.ModuleList([ResnetBlock2D(c if k == 0 else co, co, None, eps=1e-6) for k in range(3)])
+            blk.upsamplers = nn.ModuleList([Upsample2D(co)]) if i < len(rev) - 1 else None
+            self.up_blocks.append(blk)
+            c = co
+        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_out = nn.Conv2d(c, 3, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for blk in self.up_blocks:
+            for r in blk.resnets:
+                x = r(x)
+            if blk.upsamplers is not None:
+                x = blk.upsamplers[0](x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class LatentDist:
+    def __init__(self, moments):
+        self.mean, logvar = torch.chunk(moments, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+
+class _EncOut:
+    def __init__(self, d):
+        self.latent_dist = d
+
+
+class AutoencoderKL(nn.Module):
+    class Cfg:
+        scaling_factor = 0.18215
+
+    def __init__(self):
+        super().__init__()
+        self.encoder, self.decoder = Encoder(), Decoder()
+        self.quant_conv, self.post_quant_conv = nn.Conv2d(8, 8, 1), nn.Conv2d(4, 4, 1)
+        self.config = self.Cfg()
+
+    def encode(self, x):
+        return _EncOut(LatentDist(self.quant_conv(self.encoder(x))))
+
+    def decode(self, z, return_dict=False):
+        return (self.decoder(self.post_quant_conv(z)),)
+
+
+# ---------------------------------------------------------------------------------------------- CLIP text
+class CLIPLayer(nn.Module):
+    def __init__(self, d, heads):
+        super().__init__()
+        self.layer_norm1, self.layer_norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(d, d) for _ in range(4))
+        self.fc1, self.fc2 = nn.Linear(d, 4 * d), nn.Linear(4 * d, d)
+        self.heads = heads
+
+    def forward(self, x):
+        B, N, C = x.shape
+        h = self.layer_norm1(x)
+        sp = lambda t: t.view(B, N, self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(sp(self.q_proj(h)), sp(self.k_proj(h)), sp(self.v_proj(h)), is_causal=True)
+        x = x + self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+        h = self.fc1(self.layer_norm2(x))
+        return x + self.fc2(h * torch.sigmoid(1.702 * h))          # quick_gelu
+
+
+class CLIPTextModel(nn.Module):
+    def __init__(self, vocab=49408, d=768, layers=12, heads=12, ctx=77):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, d)
+        self.position_embedding = nn.Embedding(ctx, d)
+        self.layers = nn.ModuleList([CLIPLayer(d, heads) for _ in range(layers)])
+        self.final_layer_norm = nn.LayerNorm(d)
+
+    def forward(self, ids):
+        x = self.token_embedding(ids) + self.position_embedding.weight[None, :ids.shape[1]]
+        for l in self.layers:
+            x = l(x)
+        return self.final_layer_norm(x)
+
+
+class ByteTokenizer:
+    """Offline stand-in for CLIP's BPE tokenizer (its vocabulary files are not available here):
+    BOS, one id per UTF-8 byte (offset into the vocab), EOS, EOS-padding to 77 like CLIPTokenizer."""
+    BOS, EOS, CTX = 49406, 49407, 77
+
+    def __call__(self, prompt):
+        ids = [self.BOS] + [1000 + b for b in prompt.encode('utf-8')][:self.CTX - 2] + [self.EOS]
+        ids += [self.EOS] * (self.CTX - len(ids))
+        return torch.tensor([ids], dtype=torch.long)
+
+
+def scaled_linear_alphas_cumprod(n=1000, b0=0.00085, b1=0.012):
+    betas = torch.linspace(b0 ** 0.5, b1 ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class SDNetworks:
+    """Bundle used by guidance.sd_utils.StableDiffusion: vae, unet, prompt encoder, scheduler table."""
+
+    def __init__(self, device, dtype=torch.float32, seed=3):
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.vae = AutoencoderKL().to(device=device, dtype=dtype).eval()
+        self.unet = UNet2DConditionModel().to(device=device, dtype=dtype).eval()
+        self.text_encoder = CLIPTextModel().to(device=device, dtype=dtype).eval()
+        torch.random.set_rng_state(g)
+        for m in (self.vae, self.unet, self.text_encoder):
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.tokenizer = ByteTokenizer()
+        self.alphas_cumprod = scaled_linear_alphas_cumprod()
+        self.device, self.dtype = device, dtype
+        self._cache = {}
+
+    @torch.no_grad()
+    def encode_prompt(self, prompt, cfg):
+        """[2,77,768] (uncond first) when cfg else [1,77,768]; cached per prompt (the reference
+        re-encodes every step, DS_NeRF/guidance/sd_utils.py:317 -- same values, wasted work)."""
+        key = (prompt, bool(cfg))
+        if key not in self._cache:
+            cond = self.text_encoder(self.tokenizer(prompt).to(self.device))
+            if cfg:
+                cond = torch.cat([self.text_encoder(self.tokenizer('').to(self.device)), cond], 0)
+            self._cache[key] = cond
+        return self._cache[key]

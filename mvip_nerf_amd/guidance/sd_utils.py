@@ -1,0 +1,189 @@
+"""Score-distillation guidance: mirror of `DS_NeRF/guidance/sd_utils.py::StableDiffusion` (the three
+step methods the live path calls through Pretrain_Model.cal_loss) and `SpecifyGradient`.
+
+Same method names, argument orders and defaults.  What is kept from the reference, bit for bit in
+arithmetic: bilinear resize to 512^2 (align_corners=False), |mask|, masked_image = rgb*(mask<0.5)
+with NO [0,1]->[-1,1] rescale (sd_utils.py:329-330), nearest 64^2 mask, VAE posterior SAMPLE (not
+mean) scaled by 0.18215, t(i) = int(980 - 960*sqrt(i/20000)) (sd_utils.py:363-365), scheduler.add_noise,
+CFG batch [uncond, cond], w = 1 - abar_t, nan_to_num, SpecifyGradient with the 64^2 mask, and the
+colla variant's quirks (t from the VIEW index, accumulated grad, only the last view's graph gets
+gradient, doubled by the CFG-duplicated mask; sd_utils.py:442, :527, :575, :597).
+
+What is dropped because it cannot change any returned value or gradient: the unused VAE encode of
+init_image (sd_utils.py:354), the unused VAE decode + PIL conversion (:418-425), the per-step PNG
+(:416), per-step prompt re-encoding (:317, cached instead).  The dropped encode DID consume one
+randn draw; with reference_rng=True (default) that draw is still consumed so a seeded run sees
+the same random stream as the reference.
+
+Elementwise cores (add_noise; CFG + w*(eps-noise) + nan_to_num) are single HIP kernels
+(csrc/sds_elem.hip); the networks are PyTorch-ROCm modules (guidance/sd_nets.py) or any injected
+object with the diffusers call signatures.
+"""
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import ptr, stream, call
+
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+
+
+class SpecifyGradient(torch.autograd.Function):
+    """DS_NeRF/guidance/sd_utils.py:21-37: forward returns ones([1]); backward injects
+    gt_grad * upstream * mask as the gradient of the latents."""
+
+    @staticmethod
+    def forward(ctx, input_tensor, gt_grad, mask):
+        ctx.save_for_backward(gt_grad, mask)
+        return torch.ones([1], device=input_tensor.device, dtype=input_tensor.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_scale):
+        gt_grad, mask = ctx.saved_tensors
+        return gt_grad * grad_scale * mask, None, None
+
+
+class _AddNoise(torch.autograd.Function):
+    """scheduler.add_noise: sqrt(abar) x0 + sqrt(1-abar) noise, one HIP kernel; d/dx0 = sqrt(abar)."""
+
+    @staticmethod
+    def forward(ctx, x0, noise, sa, sb):
+        x0c, nc = x0.contiguous().float(), noise.contiguous().float()
+        out = torch.empty_like(x0c)
+        call('mvip_sds_add_noise', ptr(x0c), ptr(nc), sa, sb, x0c.numel(), ptr(out), stream())
+        ctx.sa = sa
+        return out.to(x0.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.sa, None, None, None
+
+
+def sds_grad(eps_uncond, eps_cond, noise, guidance_scale, w, accumulate_into=None):
+    """nan_to_num([accumulate_into +] w * (e_u + s (e_c - e_u) - noise)) in one HIP kernel."""
+    eu = eps_uncond.contiguous().float()
+    ec = None if eps_cond is None else eps_cond.contiguous().float()
+    nz = noise.contiguous().float()
+    out = accumulate_into if accumulate_into is not None else torch.empty_like(eu)
+    call('mvip_sds_grad', ptr(eu), ptr(ec), ptr(nz), float(guidance_scale), float(w), eu.numel(),
+         int(accumulate_into is not None), ptr(out), stream())
+    return out
+
+
+def seed_everything(seed):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+
+
+class StableDiffusion(nn.Module):
+    def __init__(self, device, fp16, vram_O, sd_version='2.1', hf_key=None, t_range=[0.02, 0.98], networks=None,
+                 reference_rng=True):
+        """Signature of DS_NeRF/guidance/sd_utils.py:46 plus two keyword extensions: `networks`
+        (an object with .vae, .unet, .encode_prompt(prompt, cfg), .alphas_cumprod; default = the
+        SD-1.5-inpaint-shaped modules of sd_nets with random weights, since no checkpoint exists
+        offline) and `reference_rng`."""
+        super().__init__()
+        self.device = device
+        self.sd_version = sd_version
+        self.precision_t = torch.float16 if fp16 else torch.float32
+        if networks is None:
+            from .sd_nets import SDNetworks
+            networks = SDNetworks(device, self.precision_t)
+        self.networks = networks
+        self.vae, self.unet = networks.vae, networks.unet
+        self.num_train_timesteps = 1000
+        self.min_step = int(self.num_train_timesteps * t_range[0])
+        self.max_step = int(self.num_train_timesteps * t_range[1])
+        self.alphas = networks.alphas_cumprod.to(device)
+        self._alphas_host = [float(a) for a in networks.alphas_cumprod.cpu()]   # no device sync per step
+        self.strength = 0.75
+        self.reference_rng = reference_rng
+        self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
+
+    # -- hooks (tests replay recorded draws through _randn) --------------------------------------
+    def _randn(self, shape, dtype=torch.float32):
+        return torch.randn(tuple(shape), device=self.device, dtype=dtype)
+
+    def _encode_vae_image(self, image):
+        """pipeline _encode_vae_image: scaling_factor * posterior.sample()."""
+        d = self.vae.encode(image.to(self.precision_t)).latent_dist
+        return self.scaling_factor * (d.mean + d.std * self._randn(d.mean.shape, d.mean.dtype))
+
+    def _timestep(self, frac):
+        return int(self.max_step - (self.max_step - self.min_step) * frac)
+
+    def _prepare(self, pred, mask, prompt, guidance_scale):
+        """Steps 0-4 of the reference step methods up to (not including) prepare_latents."""
+        latent_size = 512
+        pred = F.interpolate(pred, (latent_size, latent_size), mode='bilinear', align_corners=False)
+        mask = F.interpolate(torch.abs(mask), (latent_size, latent_size), mode='bilinear', align_corners=False)
+        cfg = guidance_scale > 1.0
+        prompt_embeds = self.networks.encode_prompt(prompt, cfg)
+        masked_image = pred[:, :3, :, :] * (mask < 0.5)
+        init_image = pred[:, :3, :, :]
+        mask64 = F.interpolate(mask, size=(latent_size // 8, latent_size // 8)).to(prompt_embeds.dtype)
+        masked_image_latents = self._encode_vae_image(masked_image)                  # randn draw 1
+        if cfg:
+            mask64 = torch.cat([mask64] * 2)
+            masked_image_latents = torch.cat([masked_image_latents] * 2)
+        if self.reference_rng:
+            self._randn((1, 4, latent_size // 8, latent_size // 8))                  # draw 2: the unused encode
+        return init_image, mask64, masked_image_latents, prompt_embeds, cfg
+
+    def _noise_and_predict(self, init_image, mask64, masked_image_latents, prompt_embeds, cfg, t, guidance_scale,
+                           accumulate_into=None):
+        abar = self._alphas_host[t]
+        image_latents = self._encode_vae_image(init_image)                           # draw 3 (carries grad)
+        noise = self._randn(image_latents.shape, image_latents.dtype)                # draw 4
+        latents = _AddNoise.apply(image_latents, noise, abar ** 0.5, (1.0 - abar) ** 0.5)
+        with torch.no_grad():
+            x = torch.cat([latents] * 2) if cfg else latents
+            x = torch.cat([x, mask64, masked_image_latents], dim=1)
+            noise_pred = self.unet(x.to(self.precision_t), t, encoder_hidden_states=prompt_embeds,
+                                   cross_attention_kwargs=None, return_dict=False)[0]
+            if cfg:
+                e_u, e_c = noise_pred.chunk(2)
+            else:
+                e_u, e_c = noise_pred, None
+            grad = sds_grad(e_u, e_c, noise, guidance_scale, 1.0 - abar, accumulate_into)
+        return latents, grad
+
+    # -- the three step methods ---------------------------------------------------------------------
+    def train_step_sd(self, i, mask, prompt, pred_rgb, guidance_scale=100, as_latent=False, grad_scale=1,
+                      save_guidance_path: Path = None):
+        """DS_NeRF/guidance/sd_utils.py:275-429."""
+        prep = self._prepare(pred_rgb, mask, prompt, guidance_scale)
+        t = self._timestep(np.sqrt(i / 20000))
+        latents, grad = self._noise_and_predict(*prep, t, guidance_scale)
+        return SpecifyGradient.apply(latents, grad, prep[1][0, :, :, :])
+
+    def train_step_sd_normal(self, i, mask, prompt, pred_normal_map, guidance_scale=100, normal_start=0,
+                             as_latent=False, grad_scale=1, save_guidance_path: Path = None):
+        """DS_NeRF/guidance/sd_utils.py:120-272."""
+        prep = self._prepare(pred_normal_map, mask, prompt, guidance_scale)
+        t = self._timestep(np.sqrt((i - normal_start) / 20000))
+        latents, grad = self._noise_and_predict(*prep, t, guidance_scale)
+        return SpecifyGradient.apply(latents, grad, prep[1][0, :, :, :])
+
+    def train_step_colla_sds(self, i, mask_nn, prompt, pred_rgb_nn, guidance_scale=100, as_latent=False,
+                             grad_scale=1, save_guidance_path: Path = None):
+        """DS_NeRF/guidance/sd_utils.py:432-599, reproduced as written: the loop variable shadows `i`
+        (so t = 980, 979, ... by view index), `grad` accumulates over views, `loss` is overwritten
+        each pass (only the last view receives gradient) and the CFG-duplicated [2,1,64,64] mask is
+        passed whole, so autograd sums two copies."""
+        NN = pred_rgb_nn.size(0)
+        grad = torch.zeros(1, 4, 64, 64, device=self.device)
+        loss = None
+        for k in range(NN):
+            prep = self._prepare(pred_rgb_nn[k].unsqueeze(0), mask_nn[k].unsqueeze(0), prompt, guidance_scale)
+            t = self._timestep(k / 10000)
+            latents, grad = self._noise_and_predict(*prep, t, guidance_scale, accumulate_into=grad)
+            loss = SpecifyGradient.apply(latents, grad.clone(), prep[1])
+        return loss
+
+    # `train_step` exists by name only in the reference's unused guidance/sd.py (:162, :988)
+    train_step = train_step_sd

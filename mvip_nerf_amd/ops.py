@@ -303,3 +303,58 @@ def sample_pdf(bins, weights, u, want_inds=False, want_cdf=False):
     call('mvip_sample_pdf', ptr(bins), ptr(w), ptr(u), int(u.dim() == 1), B, Nb, Nf, ptr(s),
          ptr(inds, torch.int64), ptr(cdf), stream())
     return s, inds, cdf
+
+
+# ------------------------------------------------------------------------------------------------
+# depth -> points -> plane-fit normals
+# ------------------------------------------------------------------------------------------------
+
+class _Depth2XYZ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, fx, fy, cx, cy):
+        H, W = depth.shape
+        pts = torch.empty((H, W, 3), device=depth.device, dtype=_F32)
+        call('mvip_depth2xyz', ptr(depth), H, W, fx, fy, cx, cy, ptr(pts), stream())
+        ctx.k = (H, W, fx, fy, cx, cy)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, fx, fy, cx, cy = ctx.k
+        d = torch.empty((H, W), device=g.device, dtype=_F32)
+        call('mvip_depth2xyz_backward', ptr(_f32c(g)), H, W, fx, fy, cx, cy, ptr(d), stream())
+        return d, None, None, None, None
+
+
+def depth2xyz(depth, fx, fy, cx, cy):
+    """depth [H,W] -> [H,W,3] (DS_NeRF/run.py:1909-1922), differentiable in depth."""
+    return _Depth2XYZ.apply(_f32c(depth), float(fx), float(fy), float(cx), float(cy))
+
+
+class _NormalFit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, k):
+        _, H, W = points.shape
+        dev = points.device
+        moments = torch.empty((9, H, W), device=dev, dtype=_F32)
+        scratch = torch.empty((9, H, W), device=dev, dtype=_F32)
+        normals = torch.empty((3, H, W), device=dev, dtype=_F32)
+        call('mvip_normal_fit_forward', ptr(points), H, W, k, ptr(moments), ptr(scratch), ptr(normals), stream())
+        ctx.save_for_backward(points, moments, normals)
+        ctx.k = k
+        return normals
+
+    @staticmethod
+    def backward(ctx, g):
+        points, moments, normals = ctx.saved_tensors
+        _, H, W = points.shape
+        scratch = torch.empty((18, H, W), device=g.device, dtype=_F32)
+        d = torch.empty_like(points)
+        call('mvip_normal_fit_backward', ptr(points), ptr(moments), ptr(normals), ptr(_f32c(g)), H, W, ctx.k,
+             ptr(scratch), ptr(d), stream())
+        return d, None
+
+
+def normal_fit(points, k=31):
+    """points [3,H,W] planar -> least-squares plane normals [3,H,W] (DS_NeRF/run.py:1924-1940)."""
+    return _NormalFit.apply(_f32c(points), int(k))

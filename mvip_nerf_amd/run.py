@@ -274,5 +274,17 @@ def create_nerf(args, device=None):
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
 
 
+def depth2xyz_torch(depth_map, depth_cam_matrix, depth_scale=1.0):
+    """DS_NeRF/run.py:1909-1922: tensor(h,w), 3x3 intrinsics -> tensor(h,w,3)."""
+    K = depth_cam_matrix
+    z = depth_map if depth_scale == 1.0 else depth_map / depth_scale
+    return ops.depth2xyz(z, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+
+
+def depth2normal_geo(depth, k=31):
+    """DS_NeRF/run.py:1924-1940: tensor(b,3,h,w) of points -> tensor(b,3,h,w) of plane-fit normals."""
+    return torch.stack([ops.normal_fit(depth[b], k) for b in range(depth.shape[0])], 0)
+
+
 def _strip_module_prefix(sd):
     return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}

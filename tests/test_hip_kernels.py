@@ -283,3 +283,40 @@ def test_mlp_backward_tiled_equals_untiled(cuda):
     ops.BWD_TILE_POINTS = 65536
     for a, b, k in zip(outs[0], outs[1], ops.PARAM_ORDER):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * (np.abs(a).max() + 1e-12), err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------- normals
+def test_normal_fit_golden(golden, cuda):
+    """depth2xyz_torch + depth2normal_geo forward and d/d depth vs the reference (54x72, k=31)."""
+    from mvip_nerf_amd import run
+    g = golden('normal_fit_54x72')
+    depth = T(g['depth'], cuda).requires_grad_(True)
+    pts = run.depth2xyz_torch(depth, g['K'])
+    np.testing.assert_allclose(N(pts), g['points'], rtol=1e-6, atol=1e-7)
+    pts_t = pts.unsqueeze(0).transpose(2, 3).transpose(1, 2)
+    n = run.depth2normal_geo(pts_t)
+    assert n.shape == (1, 3, 54, 72)
+    # the reference inverts A^T A in fp32 (SURVEY.md A.6: agreement ~1e-4 relative is its own noise)
+    scale = np.abs(g['normals']).max()
+    assert np.abs(N(n) - g['normals']).max() < 2e-3 * scale
+    (n * T(g['g'], cuda)).sum().backward()
+    gs = np.abs(g['d_depth']).max()
+    assert np.abs(N(depth.grad) - g['d_depth']).max() < 2e-2 * gs
+    # tighter: against the fp64 box-sum oracle (same formulation, so only fp32 storage differs)
+    d2 = torch.from_numpy(g['depth']).requires_grad_(True)
+    P = O.depth2xyz(d2, torch.from_numpy(g['K'])).permute(2, 0, 1)[None]
+    nb = O.normal_fit_boxsum(P)
+    np.testing.assert_allclose(N(n), nb.detach().numpy(), rtol=2e-4, atol=2e-5 * scale)
+    (nb * torch.from_numpy(g['g'])).sum().backward()
+    np.testing.assert_allclose(N(depth.grad), d2.grad.numpy(), rtol=2e-3, atol=2e-4 * gs)
+
+
+@pytest.mark.parametrize('H,W,k', [(5, 7, 3), (40, 33, 31), (9, 64, 5)])
+def test_normal_fit_shapes(cuda, H, W, k):
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(H * W)
+    pts = rs.normal(size=(3, H, W)).astype(np.float32)
+    pts[2] += 4.0
+    n = ops.normal_fit(T(pts, cuda), k)
+    ref = O.normal_fit_boxsum(torch.from_numpy(pts)[None], k)[0].numpy()
+    np.testing.assert_allclose(N(n), ref, rtol=5e-4, atol=5e-5 * np.abs(ref).max())

@@ -1,0 +1,136 @@
+"""SDS wrapper arithmetic (train_step_sd / _sd_normal / _colla_sds, SpecifyGradient) on the GPU against
+golden vectors produced by the reference's own wrapper running the same tiny stand-in networks
+(oracle/gen_golden_sds.py).  Random draws are replayed from the recorded CPU seed."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.sds_standin import TinyVAE, TinyUNet, TinyScheduler, prompt_embedding
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_sd(dev, seed, n_draws):
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    nets = types.SimpleNamespace(vae=TinyVAE().to(dev), unet=TinyUNet().to(dev),
+                                 encode_prompt=lambda p, cfg: prompt_embedding(p, cfg).to(dev),
+                                 alphas_cumprod=TinyScheduler().alphas_cumprod)
+    sd = StableDiffusion(dev, False, False, networks=nets)
+    torch.manual_seed(int(seed))
+    draws = [torch.randn(1, 4, 64, 64) for _ in range(n_draws)]          # the reference's CPU draws, in order
+    it = iter(draws)
+    sd._randn = lambda shape, dtype=torch.float32: next(it).to(dev)
+    return sd
+
+
+@pytest.mark.parametrize('i', [0, 100, 5000, 20000])
+def test_train_step_sd_golden(golden, cuda, i):
+    g = golden(f'sds_rgb_i{i}')
+    sd = make_sd(cuda, g['seed'], 4)
+    pred = T(g['pred'], cuda).requires_grad_(True)
+    loss = sd.train_step_sd(int(g['i']), T(g['mask'], cuda), 'a stone bench in a park', pred,
+                            guidance_scale=float(g['guidance_scale']), as_latent=True, grad_scale=1)
+    assert loss.shape == (1,) and float(loss) == 1.0
+    (float(g['upstream']) * loss).sum().backward()
+    scale = np.abs(g['d_pred']).max()
+    np.testing.assert_allclose(N(pred.grad), g['d_pred'], rtol=2e-3, atol=2e-4 * scale)
+
+
+def test_sds_internals_golden(golden, cuda):
+    """latents, the SDS gradient and the 64x64 mask handed to SpecifyGradient."""
+    from mvip_nerf_amd.guidance import sd_utils
+    g = golden('sds_rgb_i5000')
+    sd = make_sd(cuda, g['seed'], 4)
+    seen = {}
+    orig = sd_utils.SpecifyGradient.apply
+
+    def spy(latents, grad, mask):
+        seen.update(latents=latents.detach(), grad=grad.detach(), mask=mask.detach())
+        return orig(latents, grad, mask)
+    sd_utils.SpecifyGradient.apply = staticmethod(spy)
+    try:
+        sd.train_step_sd(int(g['i']), T(g['mask'], cuda), 'a stone bench in a park', T(g['pred'], cuda),
+                         guidance_scale=float(g['guidance_scale']))
+    finally:
+        sd_utils.SpecifyGradient.apply = orig
+    assert sd._timestep(np.sqrt(5000 / 20000)) == 500
+    np.testing.assert_array_equal(N(seen['mask']), g['mask64'])
+    np.testing.assert_allclose(N(seen['latents']), g['latents'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(seen['grad']), g['grad'], rtol=1e-3, atol=1e-4 * np.abs(g['grad']).max())
+
+
+def test_train_step_sd_normal_golden(golden, cuda):
+    g = golden('sds_normal')
+    sd = make_sd(cuda, g['seed'], 4)
+    pred = T(g['pred'], cuda).requires_grad_(True)
+    loss = sd.train_step_sd_normal(int(g['i']), T(g['mask'], cuda), 'a normal map of a stone bench', pred,
+                                   guidance_scale=float(g['guidance_scale']), normal_start=int(g['normal_start']))
+    (float(g['upstream']) * loss).sum().backward()
+    scale = np.abs(g['d_pred']).max()
+    np.testing.assert_allclose(N(pred.grad), g['d_pred'], rtol=2e-3, atol=2e-4 * scale)
+
+
+def test_train_step_colla_golden(golden, cuda):
+    """Reproduces the reference's behaviour as written: only the last view gets gradient, x2 from the
+    CFG-duplicated mask, accumulated grad."""
+    g = golden('sds_colla')
+    sd = make_sd(cuda, g['seed'], 12)
+    preds = T(g['preds'], cuda).requires_grad_(True)
+    loss = sd.train_step_colla_sds(1234, T(g['masks'], cuda), 'a stone bench in a park', preds,
+                                   guidance_scale=float(g['guidance_scale']))
+    (float(g['upstream']) * loss).sum().backward()
+    d = N(preds.grad)
+    assert np.abs(d[:-1]).max() == 0.0 and np.abs(g['d_preds'][:-1]).max() == 0.0
+    scale = np.abs(g['d_preds']).max()
+    np.testing.assert_allclose(d, g['d_preds'], rtol=2e-3, atol=2e-4 * scale)
+
+
+def test_sds_elementwise_kernels(cuda):
+    from mvip_nerf_amd.guidance.sd_utils import sds_grad, _AddNoise
+    gen = torch.Generator(device=cuda).manual_seed(0)
+    eu, ec, nz = (torch.randn(1, 4, 64, 64, device=cuda, generator=gen) for _ in range(3))
+    eu[0, 0, 0, 0] = float('nan'); ec[0, 0, 0, 1] = float('inf'); nz[0, 0, 0, 2] = float('inf')
+    got = sds_grad(eu, ec, nz, 7.5, 0.37)
+    ref = torch.nan_to_num(0.37 * (eu + 7.5 * (ec - eu) - nz))
+    np.testing.assert_allclose(N(got), N(ref), rtol=1e-6, atol=1e-6)
+    x0 = torch.randn(1, 4, 64, 64, device=cuda, generator=gen).requires_grad_(True)
+    out = _AddNoise.apply(x0, nz.nan_to_num(), 0.8, 0.6)
+    np.testing.assert_allclose(N(out), N(0.8 * x0 + 0.6 * nz.nan_to_num()), rtol=1e-6, atol=1e-6)
+    out.sum().backward()
+    np.testing.assert_allclose(N(x0.grad), 0.8, rtol=1e-6)
+
+
+def test_pretrain_model_dispatch(cuda):
+    """cal_loss sums the enabled terms in the reference's order and gates colla on i>0, normal on i>normal_start."""
+    from mvip_nerf_amd.nerf.utils import Pretrain_Model
+
+    class FakeSD(torch.nn.Module):
+        calls = []
+
+        def train_step_sd(self, i, *a, **k):
+            self.calls.append('rgb'); return torch.tensor([1.0])
+
+        def train_step_colla_sds(self, i, *a, **k):
+            self.calls.append('colla'); return torch.tensor([10.0])
+
+        def train_step_sd_normal(self, i, *a, **k):
+            self.calls.append('normal'); return torch.tensor([100.0])
+
+    opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=True, is_normal_guidance=True, text='t',
+                                text_normal='n', rgb_guidance_scale=7.5, colla_guidance_scale=7.5,
+                                normal_guidance_scale=1.5, normal_start=500, lambda_guidance=1)
+    pm = Pretrain_Model(opt, cuda, {'SD': FakeSD()})
+    assert float(pm.cal_loss(0, None, None, None, None, None, None, None)) == 1.0
+    assert float(pm.cal_loss(10, None, None, None, None, None, None, None)) == 11.0
+    assert float(pm.cal_loss(501, None, None, None, None, None, None, None)) == 111.0
+    assert FakeSD.calls == ['rgb', 'rgb', 'colla', 'rgb', 'colla', 'normal'] and pm.global_step == 3
