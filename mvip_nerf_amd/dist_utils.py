@@ -1,0 +1,71 @@
+"""Host logic of the multi-GPU path (one process per GPU, torch.distributed; backend "nccl" is RCCL
+on ROCm, "gloo" in the CPU tests).  No device code here, so it is exercised on CPU with gloo.
+
+The hot path shards by RAY: every per-step ray set is split rank r -> indices r::world, each rank
+renders and back-propagates its shard, and the only data-path collectives per step are
+  * one all_gather of the rendered masked colours (<= 139 KB at 378x504) so every rank can run the
+    image-space SDS term on the assembled frame, and
+  * one all_reduce(sum) of the flat 1,191,688-float gradient bucket of both MLPs (4.77 MB).
+"""
+import torch
+
+
+def shard(idx, rank, world):
+    """Strided shard: rank r owns positions r, r+world, ...  (equal sizes up to 1)."""
+    return idx if world == 1 else idx[rank::world]
+
+
+def shard_sizes(n, world):
+    return [len(range(r, n, world)) for r in range(world)]
+
+
+def unshard_order(n, world):
+    """Permutation p with cat([x[r::world] for r])[p] == x."""
+    order = torch.cat([torch.arange(r, n, world) for r in range(world)])
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(n)
+    return inv
+
+
+def all_gather_ragged(local, n_total, rank, world, dist):
+    """Gather strided shards of a [n_r, C] tensor into [n_total, C] in ORIGINAL order.  The local
+    shard keeps its autograd history (the gathered copies of other ranks are constants), which is
+    exactly what is needed: d loss / d local shard is formed on every rank."""
+    if world == 1:
+        return local
+    sizes = shard_sizes(n_total, world)
+    mx = max(sizes)
+    pad = local.detach()
+    if pad.shape[0] < mx:
+        pad = torch.cat([pad, pad.new_zeros((mx - pad.shape[0],) + tuple(pad.shape[1:]))], 0)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous())
+    parts = [p[:s] for p, s in zip(parts, sizes)]
+    parts[rank] = local
+    return torch.cat(parts, 0)[unshard_order(n_total, world).to(local.device)]
+
+
+class FlatGradBucket:
+    """One contiguous fp32 bucket for all parameters: grads are copied in, all-reduced once, and
+    handed back as views (so the optimizer reads the reduced values without another copy)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def all_reduce(self, dist, world):
+        if world == 1:
+            return
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        dist.all_reduce(self.flat)
+        for p, v in zip(self.params, self.views):
+            p.grad = v

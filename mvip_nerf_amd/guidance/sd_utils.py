@@ -105,8 +105,10 @@ class StableDiffusion(nn.Module):
         self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
 
     # -- hooks (tests replay recorded draws through _randn) --------------------------------------
+    generator = None      # optional torch.Generator: multi-GPU runs seed it identically on every rank
+
     def _randn(self, shape, dtype=torch.float32):
-        return torch.randn(tuple(shape), device=self.device, dtype=dtype)
+        return torch.randn(tuple(shape), device=self.device, dtype=dtype, generator=self.generator)
 
     def _encode_vae_image(self, image):
         """pipeline _encode_vae_image: scaling_factor * posterior.sample()."""

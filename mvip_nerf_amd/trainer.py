@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import ops, run
+from .dist_utils import shard, all_gather_ragged, FlatGradBucket
 from .run_nerf_helpers import img2mse
 
 
@@ -68,14 +69,14 @@ class SecondStageTrainer:
         self.guidance = guidance                       # Pretrain_Model-like object with cal_loss(), or None
         self.rng = np.random.RandomState(1234)         # same draw on every rank (view choice must agree)
         self.N_rand = args.N_rand
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.grad_vars), device=device)
+        self.bucket = FlatGradBucket(self.grad_vars)
         if world > 1:                                  # identical initial weights on every rank
             for p in self.grad_vars:
                 dist.broadcast(p.data, src=0)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _shard(self, idx):
-        return idx if self.world == 1 else idx[self.rank::self.world]
+        return shard(idx, self.rank, self.world)
 
     def _render_pixels(self, pose, sel, **kw):
         sc = self.scene
@@ -85,19 +86,7 @@ class SecondStageTrainer:
         return ret
 
     def _allreduce_grads(self):
-        if self.world == 1:
-            return
-        o = 0
-        for p in self.grad_vars:
-            n = p.numel()
-            self.flat_grad[o:o + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
-            o += n
-        self.dist.all_reduce(self.flat_grad)           # ONE 4.77 MB bucket over RCCL/xGMI
-        o = 0
-        for p in self.grad_vars:
-            n = p.numel()
-            p.grad = self.flat_grad[o:o + n].view_as(p).clone()
-            o += n
+        self.bucket.all_reduce(self.dist, self.world)      # ONE 4.77 MB bucket over RCCL/xGMI
 
     # -- one iteration -----------------------------------------------------------------------------
     def step(self, i):
@@ -112,18 +101,15 @@ class SecondStageTrainer:
 
         loss_sds = None
         if self.guidance is not None:
-            rgb_all, sel_all = rgb_masked, sel
-            if self.world > 1:                         # assemble the image on every rank
-                parts = [torch.empty_like(rgb_masked) for _ in range(self.world)]
-                # all ranks hold equal shard sizes up to 1; pad-free path for equal sizes only
-                self.dist.all_gather(parts, rgb_masked.detach())
-                parts[self.rank] = rgb_masked          # keep autograd on the local shard
-                rgb_all = torch.cat(parts, 0)
-                sel_all = torch.cat([sc.masked_idx[r::self.world] for r in range(self.world)], 0)
+            # assemble the frame on every rank (local shard keeps its autograd history)
+            rgb_all = all_gather_ragged(rgb_masked, sc.masked_idx.numel(), self.rank, self.world, self.dist)
             combin = sc.images[img_i].detach().clone().reshape(-1, 3)
-            combin = combin.index_put((sel_all,), rgb_all).reshape(sc.H, sc.W, 3)
+            combin = combin.index_put((sc.masked_idx,), rgb_all).reshape(sc.H, sc.W, 3)
             combin_rgb = combin.permute(2, 0, 1).unsqueeze(0)
             mask = sc.masks[img_i].float().reshape(1, 1, sc.H, sc.W)
+            if self.world > 1:                         # replicated SDS term: identical noise on every rank
+                for sd in self.guidance.guidance.values():
+                    sd.generator = torch.Generator(device=self.device).manual_seed(777 + i)
             loss_sds = self.guidance.cal_loss(i, None, None, None, combin_rgb, None, mask, None, 1)
 
         # 3. supervision batches: unmasked colour rays and inpainted-depth rays
