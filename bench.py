@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--train-steps', type=int, default=3, help='second-stage iterations timed after the render leg')
+    ap.add_argument('--sds-steps', type=int, default=3, help='SDS / full-iteration steps timed in the third leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -176,6 +177,53 @@ def main():
                            'what': 'second-stage iteration without the diffusion prior: masked-set render '
                                    '(11,544 rays) + 1024 colour rays + 1024 depth rays, losses, backward through '
                                    'both MLPs, gradient all-reduce, Adam'}
+    # ---- third leg: the diffusion prior (BASELINE configs[1]: RGB SDS only) ----
+    if args.sds_steps > 0:
+        import types
+        from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+        from mvip_nerf_amd.nerf.utils import Pretrain_Model
+        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+        sd = StableDiffusion(device, False, False)                  # SD-1.5-inpaint shapes, random weights, fp32
+        g2 = torch.Generator(device=device).manual_seed(2)
+        pred = torch.rand(1, 3, H, W, device=device, generator=g2).requires_grad_(True)
+        mask = torch.zeros(1, 1, H, W, device=device)
+        mask[:, :, (H - 104) // 2:(H - 104) // 2 + 104, (W - 111) // 2:(W - 111) // 2 + 111] = 1
+
+        def sds_step(i):
+            pred.grad = None
+            (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
+        sds_step(1000)
+        barrier()
+        t2 = time.perf_counter()
+        for k in range(args.sds_steps):
+            sds_step(1000 + k)
+        barrier()
+        dt_sds = time.perf_counter() - t2
+        opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
+                                    text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
+                                    colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
+                                    lambda_guidance=1)
+        scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+        full = SecondStageTrainer(make_args(), scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}),
+                                  world=world, rank=rank, dist=dist)
+        full.step(1000)
+        barrier()
+        t3 = time.perf_counter()
+        for k in range(args.sds_steps):
+            full.step(1001 + k)
+        barrier()
+        dt_full = time.perf_counter() - t3
+        if dist is not None:
+            t = torch.tensor([dt_sds, dt_full], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_sds, dt_full = float(t[0]), float(t[1])
+        result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': dt_sds / args.sds_steps * 1e3,
+                         'dtype': 'f32', 'what': 'train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
+                         '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
+        result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
+                                    'iterations_per_sec': args.sds_steps / dt_full,
+                                    'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
+                                            '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}
     if rank == 0:
         result['roofline'] = kernel_roofline(run, te, device)
         if world == 1 and not args.no_cpu_baseline:
