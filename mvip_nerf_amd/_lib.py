@@ -35,6 +35,10 @@ _SIGNATURES = {
                                       _int, _c_f]),
     'mvip_mlp_backward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, ctypes.POINTER(ctypes.c_void_p), _c_f, _i64, _int,
                                         _c_f]),
+    'mvip_mlp_stash_floats': (_i64, [_i64]),
+    'mvip_mlp_forward_rays_stash': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _int, _c_f]),
+    'mvip_mlp_forward_points_stash': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_mlp_backward_stash': (_int, [_c_f, _c_f, _i64, _c_f, ctypes.POINTER(ctypes.c_void_p), _c_f, _i64, _int, _c_f]),
     'mvip_mlp_unpack_grads': (_int, [_c_f, ctypes.POINTER(ctypes.c_void_p), _int, _c_f]),
     'mvip_composite_forward': (_int, [_c_f, _c_f, _c_f, _int, _c_f, _i64, _int, _int, _c_f, _c_f, _c_f, _c_f,
                                       _c_f, _c_f, _c_f]),

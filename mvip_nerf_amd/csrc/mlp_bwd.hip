@@ -75,12 +75,13 @@ __global__ void mlp_pack_transposed_kernel(const float *__restrict__ packed, flo
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void mlp_delta_kernel(
     const float *__restrict__ packed_t, const float *__restrict__ secb, const float *__restrict__ d_raw,
-    int64_t p_begin, int64_t p_count, const float *__restrict__ act, float *__restrict__ gst, int64_t n_pt) {
+    int64_t p_begin, int64_t p_count, const float *__restrict__ act, int64_t act_n_pt, int64_t act_pt0,
+    float *__restrict__ gst, int64_t n_pt) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hh = lane >> 5;
-    const int64_t pt = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t pt = (int64_t)blockIdx.x * 4 + wave;       // point tile inside this backward tile
     const int64_t pl = pt * 32 + j;
     const bool live = pl < p_count;
 
@@ -96,7 +97,9 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_kernel(
         if (hh == 0) { dt[0] = d.x; dt[1] = d.y; dt[2] = d.z; dt[3] = d.w; }
         store_tile(stash_block(gst, GT_D, n_pt, pt), dt, j, hh);
     }
-    auto act_tile = [&](int row_tile) { return load_tile(stash_block(const_cast<float *>(act), row_tile, n_pt, pt), j, hh); };
+    auto act_tile = [&](int row_tile) {
+        return load_tile(stash_block(const_cast<float *>(act), row_tile, act_n_pt, act_pt0 + pt), j, hh);
+    };
     auto put = [&](int row_tile, const f32x16 &t) { store_tile(stash_block(gst, row_tile, n_pt, pt), t, j, hh); };
 
     f32x16 vt[4];
@@ -200,9 +203,9 @@ __device__ __forceinline__ f32x4 read_piece(const float *tile, int row, int cw) 
 }
 
 template <int NTW, int KT>
-__device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act,
-                                           const float *__restrict__ gst, int64_t n_pt, int64_t pt0, int64_t pt1,
-                                           float *lds, int wave, int lane) {
+__device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act, int64_t act_n_pt,
+                                           int64_t act_pt0, const float *__restrict__ gst, int64_t n_pt,
+                                           int64_t pt0, int64_t pt1, float *lds, int wave, int lane) {
     constexpr int NT = 4 * NTW;
     const int i = lane & 31, hh = lane >> 5;
     const int extra = G.extra;
@@ -216,12 +219,14 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     auto issue_stage = [&](int64_t pt, float *dst) {
         for (int b = 0; b < nblk; ++b) {
             int tile;
-            const float *base = act;
-            if (b < NT) { tile = g_tile0 + b; base = gst; }
+            bool from_g = false;
+            if (b < NT) { tile = g_tile0 + b; from_g = true; }
             else if (b < NT + KT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
             else if (extra == 2 && b < NT + KT + 4) tile = AT_V + (b - NT - KT);
-            else { tile = GT_D; base = gst; }
-            glds16(base + ((int64_t)tile * n_pt + pt) * TILE_FLOATS + lane_off, dst + b * TILE_FLOATS + wave * 256);
+            else { tile = GT_D; from_g = true; }
+            const float *src = from_g ? gst + ((int64_t)tile * n_pt + pt) * TILE_FLOATS
+                                      : act + ((int64_t)tile * act_n_pt + act_pt0 + pt) * TILE_FLOATS;
+            glds16(src + lane_off, dst + b * TILE_FLOATS + wave * 256);
         }
     };
 
@@ -355,9 +360,9 @@ __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
 
 // blockIdx.y: 0..7 the eight 256x256 products, 8..9 the two 256x64 products, 10 the view branch
 __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
-                                                          const float *__restrict__ act,
-                                                          const float *__restrict__ gst, int64_t n_pt,
-                                                          int stages_per_slab) {
+                                                          const float *__restrict__ act, int64_t act_n_pt,
+                                                          int64_t act_pt0, const float *__restrict__ gst,
+                                                          int64_t n_pt, int stages_per_slab) {
     __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -367,9 +372,9 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restric
     if (pt1 > n_pt) pt1 = n_pt;
     if (pt0 >= pt1) return;
     const Gemm G = tab[id];
-    if (id < 8) wgrad_body<2, 8>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else if (id < 10) wgrad_body<2, 2>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else wgrad_body<1, 9>(G, act, gst, n_pt, pt0, pt1, lds, wave, lane);
+    if (id < 8) wgrad_body<2, 8>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else if (id < 10) wgrad_body<2, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else wgrad_body<1, 9>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,33 +420,42 @@ static GemmTable make_table(float *const *g) {
     return t;
 }
 
+// kept_act != nullptr: activations of ALL P points were stashed by the training forward
+// (mvip_mlp_forward_*_stash); otherwise they are recomputed tile by tile from (a, b).
 static int backward_impl(const float *packed, const float *a, const float *b, int64_t P, int S,
                          const float *d_raw, float *const *grads_host, void *workspace, int64_t tile_points,
-                         bool from_rays, void *stream) {
+                         bool from_rays, const float *kept_act, void *stream) {
     if (tile_points < 128) return MVIP_EINVAL;
+    tile_points = (tile_points / 128) * 128;
     hipStream_t s = as_stream(stream);
     float *ws = reinterpret_cast<float *>(workspace);
     float *packed_t = ws;
     const int64_t n_pt_max = n_point_tiles(tile_points);
     Gemm *tab_dev = reinterpret_cast<Gemm *>(ws + T_FLOATS);
-    float *act = ws + T_FLOATS + TABLE_FLOATS;
-    float *gst = act + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
+    float *act_ws = ws + T_FLOATS + TABLE_FLOATS;
+    float *gst = act_ws + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
     hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
     const GemmTable tab = make_table(grads_host);
     hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
+    const int64_t n_pt_all = n_point_tiles(P);
     for (int64_t p0 = 0; p0 < P; p0 += tile_points) {
         const int64_t pc = (P - p0 < tile_points) ? (P - p0) : tile_points;
         const int64_t n_pt = n_point_tiles(pc);
-        int rc = mlp_forward_launch(packed, a, b, p0, pc, S, nullptr, act, n_pt, from_rays, stream);
-        if (rc != MVIP_OK) return rc;
+        const float *act = act_ws;
+        int64_t act_n_pt = n_pt, act_pt0 = 0;
+        if (kept_act) { act = kept_act; act_n_pt = n_pt_all; act_pt0 = p0 / 32; }
+        else {
+            int rc = mlp_forward_launch(packed, a, b, p0, pc, S, nullptr, act_ws, n_pt, from_rays, stream);
+            if (rc != MVIP_OK) return rc;
+        }
         const dim3 grid1((unsigned)(n_pt / 4)), block(256);
         hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
-                           gst, n_pt);
+                           act_n_pt, act_pt0, gst, n_pt);
         int sps = (int)((n_pt + 63) / 64);
         if (sps < 1) sps = 1;
         if (sps > 32) sps = 32;
         const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), 11);
-        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab_dev, act, gst, n_pt, sps);
+        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps);
     }
     return check_launch();
 }
@@ -464,7 +478,7 @@ extern "C" int mvip_mlp_backward_rays(const float *packed, const float *rows, co
     if (B == 0) return MVIP_OK;
     if (!packed || !rows || !z || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
     for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
-    return backward_impl(packed, rows, z, B * S, S, d_raw, grads_host, workspace, tile_points, true, stream);
+    return backward_impl(packed, rows, z, B * S, S, d_raw, grads_host, workspace, tile_points, true, nullptr, stream);
 }
 
 extern "C" int mvip_mlp_backward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
@@ -475,5 +489,38 @@ extern "C" int mvip_mlp_backward_points(const float *packed, const float *pts, c
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
     for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
-    return backward_impl(packed, pts, dirs, P, 1, d_raw, grads_host, workspace, tile_points, false, stream);
+    return backward_impl(packed, pts, dirs, P, 1, d_raw, grads_host, workspace, tile_points, false, nullptr, stream);
+}
+
+extern "C" int64_t mvip_mlp_stash_floats(int64_t P) {
+    return P <= 0 ? 0 : (int64_t)AT_TILES * n_point_tiles(P) * TILE_FLOATS;
+}
+
+extern "C" int mvip_mlp_forward_rays_stash(const float *packed, const float *rows, const float *z, int64_t B, int S,
+                                           float *raw, float *stash, int precision, void *stream) {
+    if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (precision != 0) return MVIP_EUNSUP;
+    if (B == 0) return MVIP_OK;
+    if (!packed || !rows || !z || !raw || !stash) return MVIP_EINVAL;
+    return mlp_forward_launch(packed, rows, z, 0, B * S, S, raw, stash, n_point_tiles(B * S), true, stream);
+}
+
+extern "C" int mvip_mlp_forward_points_stash(const float *packed, const float *pts, const float *dirs, int64_t P,
+                                             float *raw, float *stash, int precision, void *stream) {
+    if (P < 0) return MVIP_EINVAL;
+    if (precision != 0) return MVIP_EUNSUP;
+    if (P == 0) return MVIP_OK;
+    if (!packed || !pts || !dirs || !raw || !stash) return MVIP_EINVAL;
+    return mlp_forward_launch(packed, pts, dirs, 0, P, 1, raw, stash, n_point_tiles(P), false, stream);
+}
+
+extern "C" int mvip_mlp_backward_stash(const float *packed, const float *stash, int64_t P, const float *d_raw,
+                                       float *const *grads_host, void *workspace, int64_t tile_points, int precision,
+                                       void *stream) {
+    if (P < 0) return MVIP_EINVAL;
+    if (precision != 0) return MVIP_EUNSUP;
+    if (P == 0) return MVIP_OK;
+    if (!packed || !stash || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
+    for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
+    return backward_impl(packed, nullptr, nullptr, P, 1, d_raw, grads_host, workspace, tile_points, false, stash, stream);
 }

@@ -4,6 +4,7 @@ Every function here launches HIP kernels from libmvipnerf.so on the current torc
 Nothing falls back to torch ops or the CPU: inputs must be dense fp32 tensors on the GPU.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -151,6 +152,26 @@ def _workspace(device, tile_points):
     return _WORKSPACE[key]
 
 
+# Keep the activations of a training forward for its backward when the live stashes stay under
+# this many bytes (9.9 KB per point); beyond it the backward recomputes them tile by tile.
+STASH_BUDGET_BYTES = 96 << 30
+_stash_live = [0]
+
+
+def _take_stash(P, device):
+    n = int(_lib.load().mvip_mlp_stash_floats(P))
+    if _stash_live[0] + 4 * n > STASH_BUDGET_BYTES:
+        return None
+    _stash_live[0] += 4 * n
+    t = torch.empty(n, device=device, dtype=_F32)
+    weakref.finalize(t, _stash_freed, 4 * n)        # also covers graphs that are dropped without backward
+    return t
+
+
+def _stash_freed(nbytes):
+    _stash_live[0] -= nbytes
+
+
 class _MLPRays(torch.autograd.Function):
     """raw[B,S,4] = MLP(enc(o + d z), enc(viewdir)); gradients flow to the 24 parameters only."""
 
@@ -158,8 +179,14 @@ class _MLPRays(torch.autograd.Function):
     def forward(ctx, rows, z, packed, *params):
         B, S = z.shape
         raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
-        call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
+        stash = _take_stash(B * S, z.device)
+        if stash is None:
+            call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
+        else:
+            call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), 0,
+                 stream())
         ctx.save_for_backward(rows, z, packed)
+        ctx.stash = stash
         return raw
 
     @staticmethod
@@ -168,8 +195,14 @@ class _MLPRays(torch.autograd.Function):
         B, S = z.shape
         grads = _zero_grads(z.device)
         ws = _workspace(z.device, BWD_TILE_POINTS)
-        call('mvip_mlp_backward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(_f32c(d_raw)),
-             _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+        stash, ctx.stash = ctx.stash, None
+        if stash is None:
+            call('mvip_mlp_backward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(_f32c(d_raw)),
+                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+        else:
+            call('mvip_mlp_backward_stash', ptr(packed), ptr(stash), B * S, ptr(_f32c(d_raw)),
+                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+            del stash
         return (None, None, None, *grads)
 
 

@@ -274,15 +274,18 @@ def test_mlp_backward_tiled_equals_untiled(cuda):
     z = ops.stratified_z(rows, 64, True)
     gout = torch.randn(40, 64, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
     outs = []
-    for tile in (65536, 512):
+    for tile, budget in ((65536, 96 << 30), (512, 96 << 30), (1024, 0)):   # kept stash, tiled stash, recompute
         ops.BWD_TILE_POINTS = tile
+        ops.STASH_BUDGET_BYTES = budget
         ps = [p.requires_grad_(True) for p in params_dev(32, cuda)]
         raw = ops.mlp_rays(rows, z, ops.mlp_pack(ps), ps)
         (raw * gout).sum().backward()
         outs.append([N(p.grad) for p in ps])
-    ops.BWD_TILE_POINTS = 65536
-    for a, b, k in zip(outs[0], outs[1], ops.PARAM_ORDER):
-        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * (np.abs(a).max() + 1e-12), err_msg=k)
+    ops.BWD_TILE_POINTS, ops.STASH_BUDGET_BYTES = 65536, 96 << 30
+    assert ops._stash_live[0] == 0                       # every stash was released
+    for other in outs[1:]:
+        for a, b, k in zip(outs[0], other, ops.PARAM_ORDER):
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * (np.abs(a).max() + 1e-12), err_msg=k)
 
 
 # ---------------------------------------------------------------------------------------------- normals
