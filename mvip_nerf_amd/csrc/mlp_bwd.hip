@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_kernel(
 // B2: weight gradients
 // ------------------------------------------------------------------------------------------------
 struct Gemm {
-    int g_tile0;            // first row tile of the G operand (gradient stash)
+    int g_tile0;            // first row tile of the G operand (gradient stash) this workgroup owns
+    int n_off;              // output-row offset of that tile inside dW / db
     int a_tile0[2];         // activation stash row tiles: segment 0, segment 1
     int a_count0;           // k tiles in segment 0 (the rest of KT belong to segment 1)
     float *dW;              // natural [out][in] gradient tensor
@@ -187,9 +188,10 @@ struct Gemm {
     int extra;              // 0 none, 1 sigma row (alpha_linear), 2 rgb rows (rgb_linear)
     float *dWx, *dbx;       // gradients of the extra rows
 };
-struct GemmTable { Gemm g[11]; };
+constexpr int N_PRODUCTS = 20;
+struct GemmTable { Gemm g[N_PRODUCTS]; };
 
-constexpr int W_STAGE_BLOCKS = 18;                         // max blocks per stage (views: 4+9+4+1)
+constexpr int W_STAGE_BLOCKS = 14;                         // max blocks per stage (views-A: 4 G + 5 act + 4 V + d^T)
 constexpr int W_STAGE_FLOATS = W_STAGE_BLOCKS * TILE_FLOATS;
 
 // one 4 KB [32 units][32 points] block -> LDS, 16-B pieces XOR-swizzled by ((row>>1)&7) on the
@@ -245,18 +247,22 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     for (int q = 0; q < 12; ++q) xw[q] = 0.f;
     xb[0] = xb[1] = xb[2] = 0.f;
 
+    auto load_ops = [&](const float *stg, int pg, f32x4 (&A)[NTW], f32x4 (&Bv)[KT]) {
+        const int cw = 2 * pg + hh;
+#pragma unroll
+        for (int a = 0; a < NTW; ++a) A[a] = read_piece(stg + (wave * NTW + a) * TILE_FLOATS, i, cw);
+#pragma unroll
+        for (int b = 0; b < KT; ++b) Bv[b] = read_piece(stg + (NT + b) * TILE_FLOATS, i, cw);
+    };
     auto compute_stage = [&](const float *stg) {
+        f32x4 A[NTW], Bv[KT], An[NTW], Bn[KT];
+        load_ops(stg, 0, A, Bv);
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg) {
             const int cw = 2 * pg + hh;
-            f32x4 A[NTW], Bv[KT];
+            if (pg < 3) load_ops(stg, pg + 1, An, Bn);      // operands of the next point group, one MFMA block early
 #pragma unroll
-            for (int a = 0; a < NTW; ++a) {
-                A[a] = read_piece(stg + (wave * NTW + a) * TILE_FLOATS, i, cw);
-                bsum[a] += (A[a][0] + A[a][1]) + (A[a][2] + A[a][3]);
-            }
-#pragma unroll
-            for (int b = 0; b < KT; ++b) Bv[b] = read_piece(stg + (NT + b) * TILE_FLOATS, i, cw);
+            for (int a = 0; a < NTW; ++a) bsum[a] += (A[a][0] + A[a][1]) + (A[a][2] + A[a][3]);
 #pragma unroll
             for (int a = 0; a < NTW; ++a)
 #pragma unroll
@@ -287,6 +293,12 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                     xb[cc] += (dc[0] + dc[1]) + (dc[2] + dc[3]);
                 }
             }
+            if (pg < 3) {
+#pragma unroll
+                for (int a = 0; a < NTW; ++a) A[a] = An[a];
+#pragma unroll
+                for (int b = 0; b < KT; ++b) Bv[b] = Bn[b];
+            }
         }
     };
 
@@ -308,7 +320,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
 #pragma unroll
     for (int a = 0; a < NTW; ++a) {
-        const int n0 = 32 * (wave * NTW + a);
+        const int n0 = G.n_off + 32 * (wave * NTW + a);
 #pragma unroll
         for (int b = 0; b < KT; ++b) {
             const int seg = b < ac0 ? 0 : 1;
@@ -354,11 +366,13 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 11; ++k) out[k] = tab.g[k];
+        for (int k = 0; k < N_PRODUCTS; ++k) out[k] = tab.g[k];
     }
 }
 
-// blockIdx.y: 0..7 the eight 256x256 products, 8..9 the two 256x64 products, 10 the view branch
+// blockIdx.y: 0..15 the eight 256x256 products as two 128-row halves each, 16..17 the two 256x64
+// products with the encoding, 18..19 the view branch in two column groups.  No wave holds more than
+// 128 accumulator registers: with 256 hipcc shuttles tiles between AGPRs and VGPRs every stage.
 __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
                                                           const float *__restrict__ act, int64_t act_n_pt,
                                                           int64_t act_pt0, const float *__restrict__ gst,
@@ -372,50 +386,58 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restric
     if (pt1 > n_pt) pt1 = n_pt;
     if (pt0 >= pt1) return;
     const Gemm G = tab[id];
-    if (id < 8) wgrad_body<2, 8>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else if (id < 10) wgrad_body<2, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else wgrad_body<1, 9>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    if (id < 16) wgrad_body<1, 8>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else if (id < 18) wgrad_body<2, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else if (id == 18) wgrad_body<1, 5>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    else wgrad_body<1, 4>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
 }
+
+static_assert(sizeof(Gemm) * N_PRODUCTS <= 1024 * 4, "table room");
 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
 static int64_t n_point_tiles(int64_t tile_points) { return ((tile_points + 127) / 128) * 4; }
 constexpr int TABLE_FLOATS = 1024;                      // room for the 11-entry product table
-static_assert(sizeof(Gemm) * 11 <= TABLE_FLOATS * 4, "table room");
+
 
 static GemmTable make_table(float *const *g) {
     GemmTable t{};
-    auto hidden = [&](int slot, int l, int act_tile0, int col0, int ldw, bool bias) {
-        Gemm &G = t.g[slot];
-        G.g_tile0 = GT_G + 8 * l; G.a_tile0[0] = act_tile0; G.a_tile0[1] = 0; G.a_count0 = 8;
-        G.dW = g[2 * l]; G.ldw = ldw; G.col0[0] = col0; G.col0[1] = 0; G.valid[0] = 256; G.valid[1] = 0;
-        G.db = bias ? g[2 * l + 1] : nullptr; G.extra = 0; G.dWx = G.dbx = nullptr;
+    auto hidden = [&](int slot, int g_tile, int act_tile0, float *dW, int col0, int ldw, float *db) {
+        for (int half = 0; half < 2; ++half) {          // rows 0..127 and 128..255 of the product
+            Gemm &G = t.g[2 * slot + half];
+            G.g_tile0 = g_tile + 4 * half; G.n_off = 128 * half;
+            G.a_tile0[0] = act_tile0; G.a_tile0[1] = 0; G.a_count0 = 8;
+            G.dW = dW; G.ldw = ldw; G.col0[0] = col0; G.col0[1] = 0; G.valid[0] = 256; G.valid[1] = 0;
+            G.db = db; G.extra = 0; G.dWx = G.dbx = nullptr;
+        }
     };
-    hidden(0, 1, AT_H + 0, 0, 256, true);
-    hidden(1, 2, AT_H + 8, 0, 256, true);
-    hidden(2, 3, AT_H + 16, 0, 256, true);
-    hidden(3, 4, AT_H + 24, 0, 256, true);
-    hidden(4, 5, AT_H + 32, 63, 319, true);              // layer 5, h4 columns
-    hidden(5, 6, AT_H + 40, 0, 256, true);
-    hidden(6, 7, AT_H + 48, 0, 256, true);
-    {   // feature_linear (+ the sigma row of alpha_linear)
-        Gemm &G = t.g[7];
-        G.g_tile0 = GT_F; G.a_tile0[0] = AT_H + 56; G.a_count0 = 8; G.dW = g[P_WF]; G.ldw = 256;
-        G.col0[0] = 0; G.valid[0] = 256; G.db = g[P_BF]; G.extra = 1; G.dWx = g[P_WA]; G.dbx = g[P_BA];
-    }
-    auto encoded = [&](int slot, int l, int ldw, bool bias) {   // products with the 63-channel encoding
-        Gemm &G = t.g[slot];
-        G.g_tile0 = GT_G + 8 * l; G.a_tile0[0] = AT_EMB; G.a_count0 = 2; G.dW = g[2 * l]; G.ldw = ldw;
+    hidden(0, GT_G + 8, AT_H + 0, g[2], 0, 256, g[3]);
+    hidden(1, GT_G + 16, AT_H + 8, g[4], 0, 256, g[5]);
+    hidden(2, GT_G + 24, AT_H + 16, g[6], 0, 256, g[7]);
+    hidden(3, GT_G + 32, AT_H + 24, g[8], 0, 256, g[9]);
+    hidden(4, GT_G + 40, AT_H + 32, g[10], 63, 319, g[11]);       // layer 5, h4 columns
+    hidden(5, GT_G + 48, AT_H + 40, g[12], 0, 256, g[13]);
+    hidden(6, GT_G + 56, AT_H + 48, g[14], 0, 256, g[15]);
+    hidden(7, GT_F, AT_H + 56, g[P_WF], 0, 256, g[P_BF]);         // feature_linear ...
+    t.g[14].extra = 1; t.g[14].dWx = g[P_WA]; t.g[14].dbx = g[P_BA];   // ... + the sigma row, once
+    auto encoded = [&](int id, int l, int ldw, bool bias) {      // products with the 63-channel encoding
+        Gemm &G = t.g[id];
+        G.g_tile0 = GT_G + 8 * l; G.n_off = 0; G.a_tile0[0] = AT_EMB; G.a_count0 = 2; G.dW = g[2 * l]; G.ldw = ldw;
         G.col0[0] = 0; G.valid[0] = 63; G.db = bias ? g[2 * l + 1] : nullptr; G.extra = 0;
     };
-    encoded(8, 0, 63, true);
-    encoded(9, 5, 319, false);
-    {   // view branch (+ the three rows of rgb_linear)
-        Gemm &G = t.g[10];
-        G.g_tile0 = GT_V; G.a_tile0[0] = AT_FEAT; G.a_tile0[1] = AT_EDIR; G.a_count0 = 8; G.dW = g[P_WV];
-        G.ldw = 283; G.col0[0] = 0; G.col0[1] = 256; G.valid[0] = 256; G.valid[1] = 27; G.db = g[P_BV];
+    encoded(16, 0, 63, true);
+    encoded(17, 5, 319, false);
+    {   // view branch, columns 0..127 of the feature + the 27 direction channels (+ rgb_linear rows, bias)
+        Gemm &G = t.g[18];
+        G.g_tile0 = GT_V; G.n_off = 0; G.a_tile0[0] = AT_FEAT; G.a_tile0[1] = AT_EDIR; G.a_count0 = 4; G.dW = g[P_WV];
+        G.ldw = 283; G.col0[0] = 0; G.col0[1] = 256; G.valid[0] = 128; G.valid[1] = 27; G.db = g[P_BV];
         G.extra = 2; G.dWx = g[P_WR]; G.dbx = g[P_BR];
+    }
+    {   // view branch, feature columns 128..255
+        Gemm &G = t.g[19];
+        G.g_tile0 = GT_V; G.n_off = 0; G.a_tile0[0] = AT_FEAT + 4; G.a_count0 = 4; G.dW = g[P_WV]; G.ldw = 283;
+        G.col0[0] = 128; G.valid[0] = 128; G.db = nullptr; G.extra = 0;
     }
     return t;
 }
@@ -454,7 +476,7 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         int sps = (int)((n_pt + 63) / 64);
         if (sps < 1) sps = 1;
         if (sps > 32) sps = 32;
-        const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), 11);
+        const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), N_PRODUCTS);
         hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps);
     }
     return check_launch();
