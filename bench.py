@@ -85,10 +85,16 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     ms = e0.elapsed_time(e1) / reps
     points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
     tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_mlp_forward.json')     # separate --pmc passes of this launch
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        src = 'profiles/r1_pmc_mlp_forward.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
     return {'bound': 'mfma', 'kernel': 'mlp_forward_kernel<rays>', 'achieved': round(tflops, 2),
             'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / PEAK_F32_TFLOPS, 4),
-            'traffic': None, 'launch_ms': round(ms, 3), 'points_per_launch': points,
-            'flop_per_point': FLOP_PER_POINT}
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+            'algorithmic_hbm_bytes': points * 20 + rows.shape[0] * 44, 'launch_ms': round(ms, 3),
+            'points_per_launch': points, 'flop_per_point': FLOP_PER_POINT}
 
 
 def main():
