@@ -186,6 +186,97 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     return ret
 
 
+def _write_png(path, rgb8):
+    """Minimal 8-bit RGB PNG writer (the reference uses imageio, which is not a dependency here)."""
+    import struct
+    import zlib
+    h, w, _ = rgb8.shape
+    raw = b''.join(b'\x00' + rgb8[y].tobytes() for y in range(h))
+    def chunk(tag, data):
+        c = struct.pack('>I', len(data)) + tag + data
+        return c + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0))
+                + chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def render_path(render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0,
+                disp_require_grad=False, need_alpha=False, rgb_require_grad=False, detach_weights=False,
+                patch_len=None, masks=None):
+    """DS_NeRF/run.py:1222-1362: render a list of poses; returns (rgbs, disps, (Xs, Ys)) -- numpy
+    stacks unless *_require_grad, in which case torch stacks with autograd history.  With `savedir`
+    the reference's on-disk layout is produced (rgb/*.png, depth|disp|weight|z|alpha/*.npy,
+    pose/*.txt, intrinsics.txt, images/*.png for gt)."""
+    import random
+    from .run_nerf_helpers import to8b
+    H, W, focal = hwf
+    if render_factor != 0:
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+    K = np.array([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]])
+    if savedir is not None:
+        os.makedirs(savedir, exist_ok=True)
+        np.savetxt(os.path.join(savedir, 'intrinsics.txt'), K)
+    rgbs, disps, Xs, Ys = [], [], [], []
+    for i, c2w in enumerate(render_poses):
+        if disp_require_grad or rgb_require_grad:
+            patch = None
+            if patch_len is not None:
+                masked = np.where(masks[i] != 0)
+                masked = (masked[0] // render_factor, masked[1] // render_factor)
+                Xs.append(random.randint(masked[0].min(), max(masked[0].max() - patch_len[0], masked[0].min())))
+                Ys.append(random.randint(masked[1].min(), max(masked[1].max() - patch_len[1], masked[1].min())))
+                patch = (Xs[-1], Ys[-1], patch_len[0], patch_len[1])
+            rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], retraw=True,
+                                                   need_alpha=need_alpha, detach_weights=detach_weights,
+                                                   patch=patch, **render_kwargs)
+        else:
+            with torch.no_grad():
+                rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], retraw=True,
+                                                       need_alpha=need_alpha, **render_kwargs)
+        disps.append(disp if disp_require_grad else disp.detach().cpu().numpy())
+        rgbs.append(rgb if rgb_require_grad else rgb.detach().cpu().numpy())
+        if savedir is not None:
+            dirs = {k: os.path.join(savedir, k) for k in ('rgb', 'depth', 'disp', 'weight', 'z', 'pose', 'images')}
+            if need_alpha:
+                dirs['alpha'] = os.path.join(savedir, 'alpha')
+            for d in dirs.values():
+                os.makedirs(d, exist_ok=True)
+            last = rgbs[-1] if not rgb_require_grad else rgbs[-1].detach().cpu().numpy()
+            _write_png(os.path.join(dirs['rgb'], '{:06d}.png'.format(i)), to8b(np.nan_to_num(last)))
+            if gt_imgs is not None:
+                gt = gt_imgs[i]
+                gt = gt.detach().cpu().numpy() if torch.is_tensor(gt) else np.asarray(gt)
+                _write_png(os.path.join(dirs['images'], '{:06d}.png'.format(i)), to8b(gt))
+            np.save(os.path.join(dirs['depth'], '{:06d}.npy'.format(i)), depth.detach().cpu().numpy())
+            np.save(os.path.join(dirs['disp'], '{:06d}.npy'.format(i)), disp.detach().cpu().numpy())
+            np.save(os.path.join(dirs['weight'], '{:06d}.npy'.format(i)), extras['weights'].detach().cpu().numpy())
+            np.save(os.path.join(dirs['z'], '{:06d}.npy'.format(i)), extras['z_vals'].detach().cpu().numpy())
+            if need_alpha:
+                np.save(os.path.join(dirs['alpha'], '{:06d}.npy'.format(i)), extras['alpha'].detach().cpu().numpy())
+            pose = torch.as_tensor(render_poses[i])[:3, :4].detach().cpu().numpy()
+            np.savetxt(os.path.join(dirs['pose'], '{:06d}.txt'.format(i)),
+                       np.concatenate([pose, np.array([[0, 0, 0, 1]])], axis=0))
+    disps = torch.stack(disps, 0) if disp_require_grad else np.stack(disps, 0)
+    rgbs = torch.stack(rgbs, 0) if rgb_require_grad else np.stack(rgbs, 0)
+    return rgbs, disps, (Xs, Ys)
+
+
+def save_checkpoint(path, global_step, render_kwargs_train, optimizer, module_prefix=True):
+    """The reference's checkpoint format (DS_NeRF/run.py:1043-1053).  Its state dicts carry the
+    `module.` prefix of nn.DataParallel; written the same way by default so either side can load
+    the other's files."""
+    def sd(net):
+        if net is None:
+            return None
+        d = net.state_dict()
+        return {('module.' + k if module_prefix else k): v for k, v in d.items()}
+    torch.save({'global_step': global_step, 'network_fn_state_dict': sd(render_kwargs_train['network_fn']),
+                'network_fine_state_dict': sd(render_kwargs_train['network_fine']),
+                'optimizer_state_dict': optimizer.state_dict()}, path)
+
+
 def render_path_4view(iter, all_masks, render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None,
                       render_factor=0, disp_require_grad=False, need_alpha=False, rgb_require_grad=False,
                       detach_weights=False, patch_len=None, masks=None):

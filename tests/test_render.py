@@ -171,3 +171,71 @@ def test_render_rays_train_backward_golden(golden, cuda):
             want = g[f'gval/{prefix}{k}']
             tol = (2e-3 if prefix == 'coarse.' else 2e-2) * np.abs(want).max()
             np.testing.assert_allclose(gr[g[f'gidx/{prefix}{k}']], want, rtol=5e-3, atol=tol, err_msg=prefix + k)
+
+
+def test_render_path_and_4view(cuda, tmp_path):
+    from mvip_nerf_amd import run
+    tr, te, _, _ = build(41, 42, cuda)
+    poses = O.bench_poses(12).to(cuda)
+    hwf = (24, 32, 383.65 * 32 / 504)
+    kw = dict(te, near=1.2, far=7.74)
+    rgbs, disps, (xs, ys) = run.render_path(poses[:2], hwf, 1 << 15, kw, gt_imgs=np.zeros((2, 24, 32, 3), np.float32),
+                                            savedir=str(tmp_path))
+    assert isinstance(rgbs, np.ndarray) and rgbs.shape == (2, 24, 32, 3) and disps.shape == (2, 24, 32) and xs == []
+    for sub in ('rgb/000001.png', 'depth/000000.npy', 'disp/000001.npy', 'weight/000000.npy', 'z/000001.npy',
+                'pose/000000.txt', 'images/000001.png', 'intrinsics.txt'):
+        assert (tmp_path / sub).exists(), sub
+    np.testing.assert_array_equal(np.load(tmp_path / 'disp/000001.npy'), disps[1])
+    # render_factor halves the frame; *_require_grad keeps torch tensors with history
+    rg, dg, _ = run.render_path(poses[:1], hwf, 1 << 15, dict(tr, near=1.2, far=7.74), render_factor=2,
+                                rgb_require_grad=True, disp_require_grad=True)
+    assert torch.is_tensor(rg) and rg.shape == (1, 12, 16, 3) and rg.requires_grad and dg.requires_grad
+    # render_path_4view: views [max(0,it-4) : it+5 : 2] of it = iter % 60, at 1/render_factor resolution
+    masks = np.arange(12)[:, None, None] * np.ones((12, 24, 32))
+    r4, d4, m4 = run.render_path_4view(65, masks, poses, hwf, 1 << 15, kw, render_factor=2, need_alpha=True)
+    assert r4.shape == (5, 12, 16, 3) and d4.shape == (5, 12, 16) and [int(m[0, 0]) for m in m4] == [1, 3, 5, 7, 9]
+    single = run.render(12, 16, hwf[2] / 2, chunk=1 << 15, c2w=poses[3][:3, :4], **kw)
+    np.testing.assert_array_equal(N(r4[1]), N(single[0]))
+    r4b, _, m4b = run.render_path_4view(2, masks, poses, hwf, 1 << 15, kw, render_factor=2, need_alpha=True)
+    assert r4b.shape[0] == 4 and [int(m[0, 0]) for m in m4b] == [0, 2, 4, 6]
+
+
+def test_trainer_step_matches_oracle_autograd(cuda):
+    """One second-stage iteration (no diffusion prior) on a tiny scene in deterministic mode:
+    the loss and the parameter gradients equal autograd through the CPU oracle."""
+    import types as _t
+    from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+    args = make_args(perturb=0., raw_noise_std=0., N_rand=24)
+    args.chunk, args.lrate_decay, args.depth_lambda, args.sds_loss_weight, args.no_coarse = 1 << 15, 10, 0.1, 1e-4, False
+    scene = SyntheticScene(H=20, W=28, focal=383.65 * 28 / 504, mask_hw=(6, 7), n_views=8, device=cuda)
+    tr = SecondStageTrainer(args, scene, cuda)
+    for net, seed in ((tr.kw_train['network_fn'], 51), (tr.kw_train['network_fine'], 52)):
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
+    tr.optimizer.step = lambda: None                       # keep weights/grads for inspection
+    i = 3
+    rng_state = tr.rng.get_state()
+    loss, n_rays = tr.step(i)
+    assert n_rays == 42 + 24 + 24
+    # oracle: same view, same pixel sets, same loss composition (run.py:1000-1027 + stand-in masked term)
+    tr.rng.set_state(rng_state)
+    img_i = int(tr.rng.choice(scene.i_train))
+    g = torch.Generator(device=cuda).manual_seed(10007 * (i + 1))
+    pick = scene.unmasked_idx[torch.randint(0, scene.unmasked_idx.numel(), (24,), device=cuda, generator=g)].cpu()
+    pick_d = scene.masked_idx[torch.randint(0, scene.masked_idx.numel(), (24,), device=cuda, generator=g)].cpu()
+    pc = {k: torch.from_numpy(v).requires_grad_(True) for k, v in seeded_state_dict(51).items()}
+    pf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in seeded_state_dict(52).items()}
+    ro, rd = O.get_rays(scene.H, scene.W, scene.focal, scene.poses[img_i].cpu())
+    rows = O.assemble_ray_batch(ro, rd, scene.near, scene.far)
+    rr = lambda sel: O.render_rays(rows[sel], pc, pf, 64, 64, lindisp=True, white_bkgd=True)
+    img = scene.images[img_i].cpu().reshape(-1, 3)
+    r1, r2, r3 = rr(scene.masked_idx.cpu()), rr(pick), rr(pick_d)
+    ref = (O.img2mse(r2['rgb_map'], img[pick]) + 0.1 * O.img2mse(r3['disp_map'], scene.depths[img_i].cpu().reshape(-1)[pick_d])
+           + O.img2mse(r2['rgb0'], img[pick]) + 1e-4 * O.img2mse(r1['rgb_map'], img[scene.masked_idx.cpu()]))
+    np.testing.assert_allclose(float(loss), float(ref), rtol=2e-4)
+    ref.backward()
+    for prefix, net, p in (('c', tr.kw_train['network_fn'], pc), ('f', tr.kw_train['network_fine'], pf)):
+        for k, q in net.named_parameters():
+            want = p[k].grad.numpy()
+            tol = 5e-3 * np.abs(want).max() + 1e-12
+            np.testing.assert_allclose(N(q.grad), want, rtol=5e-3, atol=tol, err_msg=prefix + k)
+    assert abs(tr.optimizer.param_groups[0]['lr'] - 3e-3 * 0.1 ** (0 / 10000)) < 1e-12 and tr.global_step == 1
