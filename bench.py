@@ -112,13 +112,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    # debug hooks for 1-GPU boxes: all ranks on device 0 over gloo (never set by the driver)
+    if os.environ.get('MVIP_BENCH_SINGLE_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('MVIP_DIST_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from mvip_nerf_amd import run
     torch.manual_seed(0)

@@ -12,7 +12,7 @@ import torch
 
 def shard(idx, rank, world):
     """Strided shard: rank r owns positions r, r+world, ...  (equal sizes up to 1)."""
-    return idx if world == 1 else idx[rank::world]
+    return idx if world == 1 else idx[rank::world].contiguous()
 
 
 def shard_sizes(n, world):

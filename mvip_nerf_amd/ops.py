@@ -48,6 +48,8 @@ def ray_rows(rays_o, rays_d, near, far, viewdirs_src=None):
 def ray_rows_from_pose(c2w, H, W, focal, near, far, sel=None):
     """Rows for the pixels `sel` (int64 flat y*W+x indices; None = whole frame, raster order)."""
     c = _f32c(c2w[:3, :4])
+    if sel is not None:
+        sel = sel.to(torch.int64).contiguous()
     B = H * W if sel is None else sel.numel()
     rows = torch.empty((B, 11), device=c.device, dtype=_F32)
     call('mvip_ray_rows_from_pose', ptr(c), int(H), int(W), float(focal), float(near), float(far),

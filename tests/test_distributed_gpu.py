@@ -1,0 +1,78 @@
+"""Two-rank run of the real SecondStageTrainer on the GPU box (gloo transport, both ranks on GPU 0):
+the sharded iteration -- strided ray shards, all_gather of the masked colours for the image-space
+prior, one flat gradient all_reduce -- must reproduce the single-process gradients."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _args():
+    return types.SimpleNamespace(
+        multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=64, alpha_model_path=None,
+        netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=3e-3, basedir='/tmp/x',
+        expname='none', ft_path=None, no_reload=True, perturb=0., N_samples=64, white_bkgd=True, raw_noise_std=0.,
+        dataset_type='llff', no_ndc=True, lindisp=True, sigma_loss=False, N_rand=32, chunk=1 << 15, lrate_decay=10,
+        depth_lambda=0.1, sds_loss_weight=1e-2, no_coarse=False)
+
+
+class _ImagePrior:
+    """Stand-in for Pretrain_Model: a deterministic image-space loss on the ASSEMBLED frame, so a
+    wrong gather order or a missing shard gradient shows up."""
+    guidance = {}
+
+    def cal_loss(self, i, a, b, c, combin_rgb, d, mask, e, B=1):
+        H, W = combin_rgb.shape[-2:]
+        yy = torch.linspace(0, 1, H, device=combin_rgb.device)[:, None]
+        xx = torch.linspace(0, 1, W, device=combin_rgb.device)[None, :]
+        wgt = (1 + yy + 2 * xx)[None, None]
+        return ((combin_rgb * wgt) ** 2).sum() * 1e-2
+
+
+def _run(rank, world, port, out):
+    from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+    from oracle.weights import seeded_state_dict
+    dev = torch.device('cuda', 0)
+    d = None
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        d = dist
+    try:
+        scene = SyntheticScene(H=20, W=28, focal=383.65 * 28 / 504, mask_hw=(7, 9), n_views=8, device=dev)
+        tr = SecondStageTrainer(_args(), scene, dev, guidance=_ImagePrior(), world=world, rank=rank, dist=d)
+        for net, seed in ((tr.kw_train['network_fn'], 61), (tr.kw_train['network_fine'], 62)):
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
+        tr.optimizer.step = lambda: None
+        loss, n = tr.step(5)
+        torch.save({'grads': [p.grad.detach().cpu() for p in tr.grad_vars], 'rays': n}, os.path.join(out, f'w{world}r{rank}.pt'))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_rank_trainer_equals_single(tmp_path, cuda):
+    _run(0, 1, 0, str(tmp_path))
+    mp.spawn(_run, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = torch.load(os.path.join(str(tmp_path), 'w1r0.pt'))
+    a, b = (torch.load(os.path.join(str(tmp_path), f'w2r{r}.pt')) for r in (0, 1))
+    assert a['rays'] + b['rays'] == ref['rays'] == 63 + 32 + 32
+    for ga, gb, gr in zip(a['grads'], b['grads'], ref['grads']):
+        assert torch.equal(ga, gb)                                   # identical after the all-reduce
+        tol = 2e-3 * float(gr.abs().max()) + 1e-12
+        np.testing.assert_allclose(ga.numpy(), gr.numpy(), rtol=2e-3, atol=tol)
