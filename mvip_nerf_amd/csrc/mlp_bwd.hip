@@ -27,7 +27,8 @@ namespace mvip {
 using namespace mlp;
 
 int mlp_forward_launch(const float *packed, const float *a, const float *b, int64_t p_begin, int64_t p_count,
-                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream);
+                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream,
+                       unsigned long long *clock_dbg = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // transposed weight image for B1

@@ -77,13 +77,20 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 template <int NT, int KG, bool LAST, class BOp, class Pre, class Epi>
 __device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BOp bop, Pre pre, Epi epi,
                                           int total_chunks = TOTAL_CHUNKS) {
+    // Two accumulator tiles alternate and the epilogue of tile ti-1 is issued two blocks into tile
+    // ti: its accumulator is long complete by then, so no MFMA->read wait states are needed and its
+    // VALU work hides under the dependency-paced MFMA chain of the current tile.
+    using PV = decltype(pre(ic<0>{}));
+    f32x16 accs[2];
+    PV pvs[2];
     static_for<NT>([&](auto ti) {
-        auto pv = pre(ti);
-        f32x16 acc;
+        constexpr int T = decltype(ti)::value;
+        pvs[T & 1] = pre(ti);
+        f32x16 &acc = accs[T & 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         static_for<KG>([&](auto kg) {
-            constexpr int bi = decltype(ti)::value * KG + decltype(kg)::value;
+            constexpr int bi = T * KG + decltype(kg)::value;
             constexpr bool last_block = LAST && (bi == NT * KG - 1);
             if constexpr (bi % CHUNK_BLOCKS == 0)
                 st.issue_chunk(g0 + bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT, total_chunks);
@@ -95,9 +102,10 @@ __device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BO
             acc = mfma(a[3], bop(kg, ic<3>{}), acc);
             if constexpr (bi % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
             a = an;
+            if constexpr (decltype(kg)::value == 1 && T > 0) epi(ic<T - 1>{}, accs[(T - 1) & 1], pvs[(T - 1) & 1]);
         });
-        epi(ti, acc, pv);
     });
+    epi(ic<NT - 1>{}, accs[(NT - 1) & 1], pvs[(NT - 1) & 1]);
 }
 struct NoPre { template <class T> __device__ __forceinline__ int operator()(T) const { return 0; } };
 

@@ -26,8 +26,14 @@ using namespace mlp;
 template <bool FROM_RAYS, bool STASH>
 __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     const float *__restrict__ packed, const float *__restrict__ in_a, const float *__restrict__ in_b,
-    int64_t p_begin, int64_t p_count, int S, float *__restrict__ raw, float *__restrict__ stash, int64_t n_pt) {
+    int64_t p_begin, int64_t p_count, int S, float *__restrict__ raw, float *__restrict__ stash, int64_t n_pt,
+    unsigned long long *__restrict__ clock_dbg) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    // diagnostics only (clock_dbg == nullptr in every product call): shader-clock and 100 MHz
+    // real-time stamps around the whole workgroup -> sustained clock and cycles per workgroup
+    unsigned long long t0c = 0, t0r = 0, ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (clock_dbg) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+#define MVIP_STAMP(k) do { if (clock_dbg) ts[k] = __builtin_amdgcn_s_memtime() - t0c; } while (0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hh = lane >> 5;
@@ -55,9 +61,11 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     stash_tile(AT_EMB + 1, emb[1]);
     stash_tile(AT_EDIR, edir);
 
+    MVIP_STAMP(0);                                    // inputs loaded + encoded
     __syncthreads();                                  // chunks 0,1 and section B have landed
     const float *sb = lds + RING_FLOATS;
     f32x4 a = st.first_block();
+    MVIP_STAMP(1);                                    // weight ring primed
 
     f32x16 h[8], o[8];
 
@@ -71,9 +79,11 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
 
-    // ---- layers 1..4: 256 -> 256 ----
-#pragma unroll 1
-    for (int l = 1; l <= 4; ++l) {
+    MVIP_STAMP(2);                                    // layer 0 done (256 MFMAs)
+    // ---- layers 1..4: 256 -> 256 (unrolled: inside a runtime loop the 256 loop-carried h/o
+    //      registers cost ~5.5k cycles of shuffling per layer, measured with tools/clock_probe.py) ----
+    static_for<4>([&](auto li) {
+        constexpr int l = 1 + decltype(li)::value;
         run_layer<LH_NT, LH_KG, false>(st, OFF_L1 / CHUNK_BLOCKS + (l - 1) * (LH_BLOCKS / CHUNK_BLOCKS), a,
             [&](auto kg, auto s) { return h[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
             NoPre{}, [&](auto ti, const f32x16 &acc, int) {
@@ -82,8 +92,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             });
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[t] = o[t];
-    }
+    });
 
+    MVIP_STAMP(3);                                    // layers 1..4 done (4096 MFMAs)
     // ---- layer 5: cat[encoded point (64), h4 (256)] -> 256 ----
     run_layer<L5_NT, L5_KG, false>(st, OFF_L5 / CHUNK_BLOCKS, a,
         [&](auto kg, auto s) {
@@ -97,9 +108,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
 
+    MVIP_STAMP(4);                                    // layer 5 done (1280 MFMAs)
     // ---- layers 6, 7 ----
-#pragma unroll 1
-    for (int l = 6; l <= 7; ++l) {
+    static_for<2>([&](auto li) {
+        constexpr int l = 6 + decltype(li)::value;
         run_layer<LH_NT, LH_KG, false>(st, OFF_L6 / CHUNK_BLOCKS + (l - 6) * (LH_BLOCKS / CHUNK_BLOCKS), a,
             [&](auto kg, auto s) { return h[kg.value >> 2][4 * (kg.value & 3) + s.value]; },
             NoPre{}, [&](auto ti, const f32x16 &acc, int) {
@@ -108,8 +120,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             });
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[t] = o[t];
-    }
+    });
 
+    MVIP_STAMP(5);                                    // layers 6, 7 done (2048 MFMAs)
     // ---- sigma = alpha_linear(h7): a 256-long dot product per point, on the VALU ----
     float sigma = dot_tiles<8>(h, sb + SB_WALPHA, hh);
     sigma += __shfl_xor(sigma, 32, 64);
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             stash_tile(AT_FEAT + ti.value, o[ti.value]);
         });
 
+    MVIP_STAMP(6);                                    // sigma + feature layer done (1024 MFMAs)
     // ---- view branch: cat[feature (256), encoded dir (27+5)] -> 128, relu ----
     f32x16 v[4];
     run_layer<LV_NT, LV_KG, true>(st, OFF_VIEWS / CHUNK_BLOCKS, a,
@@ -135,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
             stash_tile(AT_V + ti.value, v[ti.value]);
         });
 
+    MVIP_STAMP(7);                                    // view branch done (576 MFMAs)
     // ---- rgb = rgb_linear(v): three 128-long dot products ----
     float r0 = dot_tiles<4>(v, sb + SB_WRGB, hh);
     float r1 = dot_tiles<4>(v, sb + SB_WRGB + 128, hh);
@@ -146,21 +161,29 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
         float4 out = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
         reinterpret_cast<float4 *>(raw)[p] = out;
     }
+    if (clock_dbg && threadIdx.x == 0) {
+        unsigned long long *o = clock_dbg + 10 * (int64_t)blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - t0c;
+        o[1] = __builtin_amdgcn_s_memrealtime() - t0r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[2 + k] = ts[k];
+    }
 }
 
 // p_begin/p_count select a sub-range of the P points (used by the tiled backward); `stash`
 // (n_pt = p_count/32 rounded up to a multiple of 4 point tiles) receives the activations.
 int mlp_forward_launch(const float *packed, const float *a, const float *b, int64_t p_begin, int64_t p_count,
-                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream) {
+                       int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream,
+                       unsigned long long *clock_dbg = nullptr) {
     if (p_count == 0) return MVIP_OK;
     const dim3 grid((unsigned)((p_count + 127) / 128)), block(256);
     hipStream_t s = as_stream(stream);
     if (from_rays) {
-        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<true, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
-        else hipLaunchKernelGGL((mlp_forward_kernel<true, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
+        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<true, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt, clock_dbg);
+        else hipLaunchKernelGGL((mlp_forward_kernel<true, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt, clock_dbg);
     } else {
-        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
-        else hipLaunchKernelGGL((mlp_forward_kernel<false, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt);
+        if (stash) hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt, clock_dbg);
+        else hipLaunchKernelGGL((mlp_forward_kernel<false, false>), grid, block, 0, s, packed, a, b, p_begin, p_count, S, raw, stash, n_pt, clock_dbg);
     }
     return check_launch();
 }
@@ -185,4 +208,11 @@ extern "C" int mvip_mlp_forward_points(const float *packed, const float *pts, co
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !raw) return MVIP_EINVAL;
     return mlp_forward_launch(packed, pts, dirs, 0, P, 1, raw, nullptr, 0, false, stream);
+}
+
+/* diagnostics: as mvip_mlp_forward_rays, additionally writing per-workgroup (shader cycles, 100 MHz ticks) */
+extern "C" int mvip_debug_forward_clock(const float *packed, const float *rows, const float *z, int64_t B, int S,
+                                        float *raw, unsigned long long *clock_out, void *stream) {
+    if (B <= 0 || S <= 0 || !packed || !rows || !z || !raw || !clock_out) return MVIP_EINVAL;
+    return mlp_forward_launch(packed, rows, z, 0, B * S, S, raw, nullptr, 0, true, stream, clock_out);
 }
