@@ -184,6 +184,15 @@ int mvip_sds_grad(const float *eps_uncond, const float *eps_cond, const float *n
                   float guidance_scale, float w, int64_t n, int accumulate, float *grad,
                   void *stream);
 
+/* The same two kernels with the timestep-dependent scalars read from device memory
+ * (scal = {sqrt(abar), sqrt(1-abar), 1-abar}), so that ONE captured hipGraph of the SDS step
+ * serves every timestep. */
+int mvip_sds_add_noise_dev(const float *x0, const float *noise, const float *scal, int64_t n,
+                           float *latents, void *stream);
+int mvip_sds_grad_dev(const float *eps_uncond, const float *eps_cond, const float *noise,
+                      float guidance_scale, const float *scal, int64_t n, int accumulate, float *grad,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'mvip_normal_fit_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f]),
     'mvip_sds_add_noise': (_int, [_c_f, _c_f, _flt, _flt, _i64, _c_f, _c_f]),
     'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
+    'mvip_sds_add_noise_dev': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
+    'mvip_sds_grad_dev': (_int, [_c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _c_f, _c_f]),
 }
 
 # every symbol include/mvip_nerf.h declares; tests check the built library exports all of them

@@ -74,6 +74,96 @@ def sds_grad(eps_uncond, eps_cond, noise, guidance_scale, w, accumulate_into=Non
     return out
 
 
+class _AddNoiseDev(torch.autograd.Function):
+    """add_noise with {sqrt(abar), sqrt(1-abar)} read from a device tensor (graph-replayable)."""
+
+    @staticmethod
+    def forward(ctx, x0, noise, scal):
+        x0c, nc = x0.contiguous().float(), noise.contiguous().float()
+        out = torch.empty_like(x0c)
+        call('mvip_sds_add_noise_dev', ptr(x0c), ptr(nc), ptr(scal), x0c.numel(), ptr(out), stream())
+        ctx.save_for_backward(scal)
+        return out.to(x0.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scal,) = ctx.saved_tensors
+        return g * scal[0], None, None
+
+
+def sds_grad_dev(eps_uncond, eps_cond, noise, guidance_scale, scal):
+    eu = eps_uncond.contiguous().float()
+    ec = None if eps_cond is None else eps_cond.contiguous().float()
+    nz = noise.contiguous().float()
+    out = torch.empty_like(eu)
+    call('mvip_sds_grad_dev', ptr(eu), ptr(ec), ptr(nz), float(guidance_scale), ptr(scal), eu.numel(), 0, ptr(out),
+         stream())
+    return out
+
+
+class _InjectGrad(torch.autograd.Function):
+    """ones([1]) forward; backward hands `d_pred * upstream` to the image (the graph already holds
+    J^T (grad . mask), i.e. SpecifyGradient's backward chained through the VAE encoder and resize)."""
+
+    @staticmethod
+    def forward(ctx, pred, d_pred):
+        ctx.save_for_backward(d_pred)
+        return torch.ones([1], device=pred.device, dtype=pred.dtype)
+
+    @staticmethod
+    def backward(ctx, upstream):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * upstream, None
+
+
+class _GraphedStep:
+    """The whole single-view SDS step -- resize, masking, two VAE encodes, add_noise, UNet (CFG batch),
+    SDS gradient, and the backward through the VAE encoder to the image -- captured once as a hipGraph.
+    ~1400 kernel launches per step otherwise leave the GPU idle a third of the time (profiles/)."""
+
+    def __init__(self, sd, pred_shape, mask_shape, prompt, guidance_scale):
+        self.sd, self.prompt, self.gs = sd, prompt, guidance_scale
+        dev = sd.device
+        self.pred = torch.zeros(pred_shape, device=dev, requires_grad=True)
+        self.mask = torch.zeros(mask_shape, device=dev)
+        self.scal = torch.zeros(4, device=dev)                  # sqrt(abar), sqrt(1-abar), 1-abar, t
+        sd.networks.encode_prompt(prompt, guidance_scale > 1.0)    # cached constant, outside the capture
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                           # warm-up (library autotuning) before capture
+            for _ in range(2):
+                self._body()
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.d_pred = self._body()
+
+    def _body(self):
+        sd = self.sd
+        init_image, mask64, masked_latents, emb, cfg = sd._prepare(self.pred, self.mask, self.prompt, self.gs)
+        image_latents = sd._encode_vae_image(init_image)
+        noise = sd._randn(image_latents.shape, image_latents.dtype)
+        latents = _AddNoiseDev.apply(image_latents, noise, self.scal)
+        with torch.no_grad():
+            x = torch.cat([latents] * 2) if cfg else latents
+            x = torch.cat([x, mask64, masked_latents], dim=1)
+            eps = sd.unet(x.to(sd.precision_t), self.scal[3:4], encoder_hidden_states=emb,
+                          cross_attention_kwargs=None, return_dict=False)[0]
+            e_u, e_c = eps.chunk(2) if cfg else (eps, None)
+            grad = sds_grad_dev(e_u, e_c, noise, self.gs, self.scal)
+        (d_pred,) = torch.autograd.grad(latents, self.pred, grad_outputs=grad * mask64[0, :, :, :])
+        return d_pred
+
+    def run(self, pred, mask, t):
+        abar = self.sd._alphas_host[t]
+        self.scal.copy_(torch.tensor([abar ** 0.5, (1.0 - abar) ** 0.5, 1.0 - abar, float(t)]), non_blocking=True)
+        self.pred.data.copy_(pred.detach())
+        self.mask.copy_(mask)
+        self.graph.replay()
+        return self.d_pred.clone()
+
+
 def seed_everything(seed):
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
@@ -81,7 +171,7 @@ def seed_everything(seed):
 
 class StableDiffusion(nn.Module):
     def __init__(self, device, fp16, vram_O, sd_version='2.1', hf_key=None, t_range=[0.02, 0.98], networks=None,
-                 reference_rng=True):
+                 reference_rng=True, use_graphs=False):
         """Signature of DS_NeRF/guidance/sd_utils.py:46 plus two keyword extensions: `networks`
         (an object with .vae, .unet, .encode_prompt(prompt, cfg), .alphas_cumprod; default = the
         SD-1.5-inpaint-shaped modules of sd_nets with random weights, since no checkpoint exists
@@ -102,6 +192,8 @@ class StableDiffusion(nn.Module):
         self._alphas_host = [float(a) for a in networks.alphas_cumprod.cpu()]   # no device sync per step
         self.strength = 0.75
         self.reference_rng = reference_rng
+        self.use_graphs = use_graphs       # capture the single-view steps as hipGraphs (same arithmetic)
+        self._graphs = {}
         self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
 
     # -- hooks (tests replay recorded draws through _randn) --------------------------------------
@@ -154,10 +246,19 @@ class StableDiffusion(nn.Module):
             grad = sds_grad(e_u, e_c, noise, guidance_scale, 1.0 - abar, accumulate_into)
         return latents, grad
 
+    def _graphed(self, t, mask, prompt, pred, guidance_scale):
+        key = (tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale))
+        if key not in self._graphs:
+            self._graphs[key] = _GraphedStep(self, pred.shape, mask.shape, prompt, guidance_scale)
+        d_pred = self._graphs[key].run(pred, mask, t)
+        return _InjectGrad.apply(pred, d_pred)
+
     # -- the three step methods ---------------------------------------------------------------------
     def train_step_sd(self, i, mask, prompt, pred_rgb, guidance_scale=100, as_latent=False, grad_scale=1,
                       save_guidance_path: Path = None):
         """DS_NeRF/guidance/sd_utils.py:275-429."""
+        if self.use_graphs:
+            return self._graphed(self._timestep(np.sqrt(i / 20000)), mask, prompt, pred_rgb, guidance_scale)
         prep = self._prepare(pred_rgb, mask, prompt, guidance_scale)
         t = self._timestep(np.sqrt(i / 20000))
         latents, grad = self._noise_and_predict(*prep, t, guidance_scale)
@@ -166,6 +267,9 @@ class StableDiffusion(nn.Module):
     def train_step_sd_normal(self, i, mask, prompt, pred_normal_map, guidance_scale=100, normal_start=0,
                              as_latent=False, grad_scale=1, save_guidance_path: Path = None):
         """DS_NeRF/guidance/sd_utils.py:120-272."""
+        if self.use_graphs:
+            return self._graphed(self._timestep(np.sqrt((i - normal_start) / 20000)), mask, prompt, pred_normal_map,
+                                 guidance_scale)
         prep = self._prepare(pred_normal_map, mask, prompt, guidance_scale)
         t = self._timestep(np.sqrt((i - normal_start) / 20000))
         latents, grad = self._noise_and_predict(*prep, t, guidance_scale)

@@ -22,8 +22,13 @@ def N(t):
 
 def make_sd(dev, seed, n_draws):
     from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
-    nets = types.SimpleNamespace(vae=TinyVAE().to(dev), unet=TinyUNet().to(dev),
-                                 encode_prompt=lambda p, cfg: prompt_embedding(p, cfg).to(dev),
+    cache = {}
+
+    def encode_prompt(p, cfg):               # cached on the device (a graph capture cannot contain H2D copies)
+        if (p, cfg) not in cache:
+            cache[(p, cfg)] = prompt_embedding(p, cfg).to(dev)
+        return cache[(p, cfg)]
+    nets = types.SimpleNamespace(vae=TinyVAE().to(dev), unet=TinyUNet().to(dev), encode_prompt=encode_prompt,
                                  alphas_cumprod=TinyScheduler().alphas_cumprod)
     sd = StableDiffusion(dev, False, False, networks=nets)
     torch.manual_seed(int(seed))
@@ -134,3 +139,30 @@ def test_pretrain_model_dispatch(cuda):
     assert float(pm.cal_loss(10, None, None, None, None, None, None, None)) == 11.0
     assert float(pm.cal_loss(501, None, None, None, None, None, None, None)) == 111.0
     assert FakeSD.calls == ['rgb', 'rgb', 'colla', 'rgb', 'colla', 'normal'] and pm.global_step == 3
+
+
+def test_graphed_step_equals_eager(golden, cuda):
+    """use_graphs=True replays a captured hipGraph of the whole step (incl. the VAE-encoder backward);
+    with the same noise it must give the eager gradient, for several timesteps through ONE graph."""
+    import itertools
+    g = golden('sds_rgb_i100')
+    torch.manual_seed(3)
+    fixed = [torch.randn(1, 4, 64, 64, device=cuda) for _ in range(4)]
+    outs = {}
+    for mode in (False, True):
+        sd = make_sd(cuda, 0, 0)
+        sd.use_graphs = mode
+        cyc = itertools.cycle(fixed)
+        sd._randn = lambda shape, dtype=torch.float32: next(cyc)
+        res = []
+        for i in (100, 5000, 19000):
+            pred = T(g['pred'], cuda).requires_grad_(True)
+            loss = sd.train_step_sd(i, T(g['mask'], cuda), 'a stone bench in a park', pred, guidance_scale=7.5)
+            (1e-4 * loss).sum().backward()
+            res.append(N(pred.grad))
+        outs[mode] = res
+        if mode:
+            assert len(sd._graphs) == 1
+    for a, b in zip(outs[False], outs[True]):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * np.abs(a).max())
+    assert not np.allclose(outs[True][0], outs[True][2])       # the timestep really changed between replays

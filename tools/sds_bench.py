@@ -4,9 +4,16 @@ import torch
 sys.path.insert(0, '.')
 from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
 
+GRAPHS = False
+CHANNELS_LAST = False
+
+
 def run(fp16, steps=5):
     dev = torch.device('cuda', 0)
-    sd = StableDiffusion(dev, fp16, False)
+    sd = StableDiffusion(dev, fp16, False, use_graphs=GRAPHS)
+    if CHANNELS_LAST:
+        sd.vae.to(memory_format=torch.channels_last)
+        sd.unet.to(memory_format=torch.channels_last)
     g = torch.Generator(device=dev).manual_seed(2)
     pred = torch.rand(1, 3, 378, 504, device=dev, generator=g).requires_grad_(True)
     mask = torch.zeros(1, 1, 378, 504, device=dev); mask[:, :, 137:241, 196:307] = 1
@@ -23,9 +30,10 @@ def run(fp16, steps=5):
             'mem_GB': torch.cuda.max_memory_allocated() / 1e9}
 
 if __name__ == '__main__':
-    for fp16 in (False, True):
+    for graphs, cl in ((False, False), (False, True), (True, True)):
+        GRAPHS, CHANNELS_LAST = graphs, cl
         try:
-            print(json.dumps(run(fp16)), flush=True)
+            print('graphs', graphs, 'channels_last', cl, json.dumps(run(False)), flush=True)
         except Exception as e:
             print('FAILED', fp16, repr(e)[:500], flush=True)
         torch.cuda.empty_cache()
