@@ -166,6 +166,32 @@ def main():
                    'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
                    'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
     }
+    # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on
+    #      hi/lo splits of both operands, fp32 accumulate).  Reported separately; `value` stays exact fp32. ----
+    with torch.no_grad():
+        ref_img = step(0)
+        for net in (te['network_fn'], te['network_fine']):
+            net.inference_precision = 1
+        fast_img = step(0)
+        barrier()
+        tf = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        barrier()
+        dt_fast = time.perf_counter() - tf
+        for net in (te['network_fn'], te['network_fine']):
+            net.inference_precision = 0
+    if dist is not None:
+        t = torch.tensor([dt_fast], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_fast = float(t.item())
+    mse_fast = float(((fast_img - ref_img) ** 2).mean())
+    result['render_f16x3'] = {
+        'rays_per_sec': rays_per_step * args.steps / dt_fast, 'ms_per_step': dt_fast / args.steps * 1e3,
+        'dtype': 'f16x3 (fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate)',
+        'psnr_vs_f32_render_dB': -10 * math.log10(max(mse_fast, 1e-30)),
+        'max_abs_pixel_diff': float((fast_img - ref_img).abs().max())}
+
     # ---- second leg: the training iteration (masked render + 2 supervision batches, fwd+bwd+Adam) ----
     if args.train_steps > 0:
         from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene

@@ -83,9 +83,21 @@ int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream);
  */
 int64_t mvip_mlp_packed_floats(void);
 int mvip_mlp_pack(const float *const *params_host, float *packed, void *stream);
+/* image for precision 1; packed_f32 = the image mvip_mlp_pack() wrote for the same parameters
+ * (its fp32 bias / head section is shared). */
+int mvip_mlp_pack_f16x3(const float *const *params_host, float *image, const float *packed_f32,
+                        void *stream);
+int mvip_mlp_forward_rays_f16x3(const float *image, const float *rows, const float *z, int64_t B, int S,
+                                float *raw, void *stream);
+int mvip_mlp_forward_points_f16x3(const float *image, const float *pts, const float *dirs, int64_t P,
+                                  float *raw, void *stream);
 
 /* Forward from geometry: rows [B,11], z [B,S] -> raw [B,S,4]; points are o + d*z, view dirs
- * are rows[:,8:11] (run.py:1783, :1787).  precision: 0 = exact fp32 MFMA. */
+ * are rows[:,8:11] (run.py:1783, :1787).
+ * precision 0: exact fp32 MFMA, `packed` from mvip_mlp_pack().
+ * precision 1: "f16x3" split precision -- fp16 MFMA on W = Wh+Wl, X = Xh+Xl with the three leading
+ *   products (Wh.Xh + Wh.Xl + Wl.Xh) accumulated in fp32; `packed` must be the image written by
+ *   mvip_mlp_pack_f16x3() (same size).  Forward only; ~1e-6 relative deviation from precision 0. */
 int mvip_mlp_forward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
                           float *raw, int precision, void *stream);
 

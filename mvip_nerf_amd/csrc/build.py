@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(PKG, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libmvipnerf.so')
 
-SOURCES = ['api.hip', 'rays.hip', 'composite.hip', 'sample_pdf.hip', 'mlp_pack.hip', 'mlp_fwd.hip',
+SOURCES = ['api.hip', 'rays.hip', 'composite.hip', 'sample_pdf.hip', 'mlp_pack.hip', 'mlp_fwd.hip', 'mlp_fwd_f16x3.hip',
            'mlp_bwd.hip', 'normal_fit.hip', 'sds_elem.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function']

@@ -192,9 +192,13 @@ int mlp_forward_launch(const float *packed, const float *a, const float *b, int6
 
 using namespace mvip;
 
+extern "C" int mvip_mlp_forward_rays_f16x3(const float *, const float *, const float *, int64_t, int, float *, void *);
+extern "C" int mvip_mlp_forward_points_f16x3(const float *, const float *, const float *, int64_t, float *, void *);
+
 extern "C" int mvip_mlp_forward_rays(const float *packed, const float *rows, const float *z, int64_t B, int S,
                                      float *raw, int precision, void *stream) {
     if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (precision == 1) return mvip_mlp_forward_rays_f16x3(packed, rows, z, B, S, raw, stream);
     if (precision != 0) return MVIP_EUNSUP;
     if (B == 0) return MVIP_OK;
     if (!packed || !rows || !z || !raw) return MVIP_EINVAL;
@@ -204,6 +208,7 @@ extern "C" int mvip_mlp_forward_rays(const float *packed, const float *rows, con
 extern "C" int mvip_mlp_forward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
                                        float *raw, int precision, void *stream) {
     if (P < 0) return MVIP_EINVAL;
+    if (precision == 1) return mvip_mlp_forward_points_f16x3(packed, pts, dirs, P, raw, stream);
     if (precision != 0) return MVIP_EUNSUP;
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !raw) return MVIP_EINVAL;

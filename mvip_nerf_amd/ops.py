@@ -118,6 +118,14 @@ def mlp_pack(params):
     return packed
 
 
+def mlp_pack_f16x3(params, packed_f32):
+    """Image for the split-precision forward (precision=1); same size as the fp32 image."""
+    ps = [_f32c(p.detach()) for p in params]
+    img = torch.empty(packed_floats(), device=ps[0].device, dtype=_F32)
+    call('mvip_mlp_pack_f16x3', _lib.ptr_array(ps), ptr(img), ptr(packed_f32), stream())
+    return img
+
+
 def mlp_unpack_grads(grad_packed, like):
     grads = [torch.empty(shp, device=grad_packed.device, dtype=_F32) for shp in PARAM_SHAPES]
     call('mvip_mlp_unpack_grads', ptr(grad_packed), _lib.ptr_array(grads), 0, stream())
@@ -227,24 +235,31 @@ class _MLPPoints(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
-    routes the gradient image back to them; with no grad needed the Function is skipped."""
+    routes the gradient image back to them; with no grad needed the Function is skipped.
+    `packed_f16x3` (inference only) selects the split-precision kernel (precision = 1)."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _MLPRays.apply(rows, z, packed, *params)
     B, S = z.shape
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
-    call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
+    if packed_f16x3 is not None:
+        call('mvip_mlp_forward_rays', ptr(packed_f16x3), ptr(rows), ptr(z), B, S, ptr(raw), 1, stream())
+    else:
+        call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
     return raw
 
 
-def mlp_points(pts, dirs, packed, params):
+def mlp_points(pts, dirs, packed, params, packed_f16x3=None):
     pts, dirs = _f32c(pts), _f32c(dirs)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _MLPPoints.apply(pts, dirs, packed, *params)
     raw = torch.empty((pts.shape[0], 4), device=pts.device, dtype=_F32)
-    call('mvip_mlp_forward_points', ptr(packed), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 0, stream())
+    if packed_f16x3 is not None:
+        call('mvip_mlp_forward_points', ptr(packed_f16x3), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 1, stream())
+    else:
+        call('mvip_mlp_forward_points', ptr(packed), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 0, stream())
     return raw
 
 

@@ -69,6 +69,11 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, output_ch)
         self._packed = None
         self._packed_key = None
+        self._packed16 = None
+        self._packed16_key = None
+        # 0: exact fp32 MFMA everywhere.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative) for
+        # forward passes that need no gradient (rendering); training always runs precision 0.
+        self.inference_precision = 0
 
     def _check_supported(self):
         if not (self.D == 8 and self.W == 256 and self.input_ch == 63 and self.input_ch_views == 27
@@ -101,11 +106,21 @@ class NeRF(nn.Module):
         out = ops.mlp_points(pts.reshape(-1, 3), dirs.reshape(-1, 3), self.packed(), self.param_list())
         return out.reshape(*x.shape[:-1], 4)
 
+    def packed_f16x3(self):
+        packed = self.packed()
+        if self._packed16 is None or self._packed16_key != self._packed_key:
+            self._packed16 = ops.mlp_pack_f16x3(self.param_list(), packed)
+            self._packed16_key = self._packed_key
+        return self._packed16
+
+    def _fast_image(self):
+        return self.packed_f16x3() if self.inference_precision == 1 else None
+
     def query_points(self, pts, dirs):
-        return ops.mlp_points(pts, dirs, self.packed(), self.param_list())
+        return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image())
 
     def query_rays(self, rows, z):
-        return ops.mlp_rays(rows, z, self.packed(), self.param_list())
+        return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

@@ -323,3 +323,42 @@ def test_normal_fit_shapes(cuda, H, W, k):
     n = ops.normal_fit(T(pts, cuda), k)
     ref = O.normal_fit_boxsum(torch.from_numpy(pts)[None], k)[0].numpy()
     np.testing.assert_allclose(N(n), ref, rtol=5e-4, atol=5e-5 * np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------------- split precision
+def test_mlp_forward_f16x3_accuracy(golden, cuda):
+    """precision=1 (fp16 MFMA on hi/lo splits of both operands, 3 products): error against the fp64
+    evaluation of the same network is within a small multiple of the exact-fp32 kernel's own error."""
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    ps = params_dev(g['seed'], cuda)
+    packed = ops.mlp_pack(ps)
+    p16 = ops.mlp_pack_f16x3(ps, packed)
+    pts, dirs = T(g['pts'], cuda), T(g['dirs'], cuda)
+    with torch.no_grad():
+        r32 = N(ops.mlp_points(pts, dirs, packed, ps))
+        r16 = N(ops.mlp_points(pts, dirs, packed, ps, packed_f16x3=p16))
+    sd64 = {k: torch.from_numpy(v).double() for k, v in params_np(g['seed']).items()}
+    emb64 = torch.from_numpy(g['emb']).double()
+    ref = O.mlp_forward(sd64, emb64).numpy()
+    e32, e16 = np.abs(r32 - ref).max(), np.abs(r16 - ref).max()
+    scale = np.abs(ref).max()
+    assert e32 < 3e-6 * scale
+    assert e16 < 8e-6 * scale, (e16, e32, scale)
+    np.testing.assert_allclose(r16, g['out'], rtol=5e-5, atol=5e-6)
+
+
+def test_render_f16x3_matches_fp32_render(cuda):
+    from mvip_nerf_amd import run
+    import types as _t
+    from tests.test_render import build
+    tr, te, _, _ = build(71, 72, cuda)
+    H, W, f = 24, 32, 383.65 * 32 / 504
+    c2w = O.bench_poses(3)[2].to(cuda)
+    with torch.no_grad():
+        a = run.render(H, W, f, chunk=1 << 15, c2w=c2w, near=1.2, far=7.74, **te)
+        for net in (te['network_fn'], te['network_fine']):
+            net.inference_precision = 1
+        b = run.render(H, W, f, chunk=1 << 15, c2w=c2w, near=1.2, far=7.74, **te)
+    mse = float(((N(a[0]) - N(b[0])) ** 2).mean())
+    assert mse < 1e-9, f'PSNR(f16x3 vs fp32) = {-10 * np.log10(max(mse, 1e-30)):.1f} dB'
