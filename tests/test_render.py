@@ -239,3 +239,60 @@ def test_trainer_step_matches_oracle_autograd(cuda):
             tol = 5e-3 * np.abs(want).max() + 1e-12
             np.testing.assert_allclose(N(q.grad), want, rtol=5e-3, atol=tol, err_msg=prefix + k)
     assert abs(tr.optimizer.param_groups[0]['lr'] - 3e-3 * 0.1 ** (0 / 10000)) < 1e-12 and tr.global_step == 1
+
+
+def test_render_general_branches_vs_oracle(cuda):
+    """The uncommon branches of render()/render_rays(): a generic (non-HIP) network_fn through
+    network_query_fn, per-ray depth column (12 columns), c2w_staticcam, and NeRF.forward on the
+    embedded [P,90] input that run_network would build."""
+    from mvip_nerf_amd import run, ops
+    from mvip_nerf_amd.run_nerf_helpers import get_embedder
+    tr, te, _, _ = build(81, 82, cuda)
+    H, W, f = 10, 14, 383.65 * 14 / 504
+    poses = O.bench_poses(6).to(cuda)
+    pc = {k: torch.from_numpy(v) for k, v in seeded_state_dict(81).items()}
+    pf = {k: torch.from_numpy(v) for k, v in seeded_state_dict(82).items()}
+    ro, rd = O.get_rays(H, W, f, poses[2].cpu())
+    rows_ref = O.assemble_ray_batch(ro, rd, 1.2, 7.74)
+    with torch.no_grad():
+        ref = O.render_rays(rows_ref, pc, pf, 64, 64, lindisp=True, white_bkgd=True)
+        base = run.render(H, W, f, chunk=64, c2w=poses[2], near=1.2, far=7.74, **te)
+        np.testing.assert_allclose(N(base[0]).reshape(-1, 3), ref['rgb_map'].numpy(), rtol=2e-4, atol=2e-5)
+        # (1) depth column -> 12-column rows, general assembly path
+        depths = torch.rand(H * W, device=cuda)
+        with_depth = run.render(H, W, f, chunk=64, c2w=poses[2], near=1.2, far=7.74, depths=depths, **te)
+        np.testing.assert_array_equal(N(with_depth[0]), N(base[0]))
+        # (2) a generic callable instead of the HIP module: the reference's embed/cat/chunk flow
+        embed_fn, _ = get_embedder(10, 0)
+        embeddirs_fn, _ = get_embedder(4, 0)
+        pcd = {k: v.to(cuda) for k, v in pc.items()}
+        pfd = {k: v.to(cuda) for k, v in pf.items()}
+        class Plain(torch.nn.Module):
+            def __init__(self, p):
+                super().__init__(); self.p = p
+            def forward(self, x):
+                return O.mlp_forward(self.p, x)
+        def query(inputs, viewdirs, fn):
+            return run.run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=200)
+        kw = dict(te, network_fn=Plain(pcd), network_fine=Plain(pfd), network_query_fn=query)
+        generic = run.render(H, W, f, chunk=64, c2w=poses[2], near=1.2, far=7.74, **kw)
+        np.testing.assert_allclose(N(generic[0]), N(base[0]), rtol=2e-4, atol=2e-5)
+        # (3) static camera: rays from poses[4], view directions from poses[2]
+        sc = run.render(H, W, f, chunk=64, c2w=poses[2], c2w_staticcam=poses[4], near=1.2, far=7.74, **te)
+        ro4, rd4 = O.get_rays(H, W, f, poses[4].cpu())
+        rows4 = O.assemble_ray_batch(ro4, rd4, 1.2, 7.74)
+        rows4[:, 8:11] = rows_ref[:, 8:11]
+        ref4 = O.render_rays(rows4, pc, pf, 64, 64, lindisp=True, white_bkgd=True)
+        np.testing.assert_allclose(N(sc[0]).reshape(-1, 3), ref4['rgb_map'].numpy(), rtol=2e-4, atol=2e-5)
+        # (4) NeRF.forward(embedded) == oracle MLP on the same embedded input
+        pts = torch.rand(70, 3, device=cuda) * 4 - 2
+        dirs = torch.nn.functional.normalize(torch.randn(70, 3, device=cuda), dim=-1)
+        emb = torch.cat([embed_fn(pts), embeddirs_fn(dirs)], -1)
+        assert emb.shape == (70, 90)
+        out = te['network_fn'](emb)
+        np.testing.assert_allclose(N(out), O.mlp_forward(pc, emb.cpu()).numpy(), rtol=2e-5, atol=2e-6)
+    # (5) ndc=True goes through ndc_rays (tensor algebra) and still renders
+    with torch.no_grad():
+        kw = {k: v for k, v in te.items() if k not in ('ndc', 'lindisp')}      # NDC scenes sample linearly in depth
+        nd = run.render(H, W, f, chunk=64, c2w=poses[2], ndc=True, near=0., far=1., lindisp=False, **kw)
+    assert nd[0].shape == (H, W, 3) and torch.isfinite(nd[0]).all()
