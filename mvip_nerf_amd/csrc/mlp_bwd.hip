@@ -29,6 +29,13 @@ using namespace mlp;
 int mlp_forward_launch(const float *packed, const float *a, const float *b, int64_t p_begin, int64_t p_count,
                        int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream,
                        unsigned long long *clock_dbg = nullptr);
+// split-precision (precision = 1) counterparts, mlp_fwd_f16x3.hip / mlp_bwd_f16x3.hip
+int mlp_forward_f16x3_launch(const float *img, const float *a, const float *b, int64_t p_begin, int64_t p_count,
+                             int S, float *raw, float *stash, int64_t n_pt, bool from_rays, void *stream);
+int mlp_delta_f16x3_prepare(const float *image16, float *image_t16, void *stream);
+int mlp_delta_f16x3_launch(const float *image_t16, const float *secb, const float *d_raw, int64_t p0, int64_t pc,
+                           const float *act, int64_t act_n_pt, int64_t act_pt0, float *gst, int64_t n_pt,
+                           void *stream);
 
 // ------------------------------------------------------------------------------------------------
 // transposed weight image for B1
@@ -447,7 +454,7 @@ static GemmTable make_table(float *const *g) {
 // (mvip_mlp_forward_*_stash); otherwise they are recomputed tile by tile from (a, b).
 static int backward_impl(const float *packed, const float *a, const float *b, int64_t P, int S,
                          const float *d_raw, float *const *grads_host, void *workspace, int64_t tile_points,
-                         bool from_rays, const float *kept_act, void *stream) {
+                         bool from_rays, const float *kept_act, int precision, void *stream) {
     if (tile_points < 128) return MVIP_EINVAL;
     tile_points = (tile_points / 128) * 128;
     hipStream_t s = as_stream(stream);
@@ -457,7 +464,9 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
     Gemm *tab_dev = reinterpret_cast<Gemm *>(ws + T_FLOATS);
     float *act_ws = ws + T_FLOATS + TABLE_FLOATS;
     float *gst = act_ws + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
-    hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
+    // precision 1: `packed` is the f16x3 image; the transposed image is rebuilt from it (hi+lo is exact)
+    if (precision == 1) { int rc = mlp_delta_f16x3_prepare(packed, packed_t, stream); if (rc != MVIP_OK) return rc; }
+    else hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
     const GemmTable tab = make_table(grads_host);
     hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
     const int64_t n_pt_all = n_point_tiles(P);
@@ -468,12 +477,19 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         int64_t act_n_pt = n_pt, act_pt0 = 0;
         if (kept_act) { act = kept_act; act_n_pt = n_pt_all; act_pt0 = p0 / 32; }
         else {
-            int rc = mlp_forward_launch(packed, a, b, p0, pc, S, nullptr, act_ws, n_pt, from_rays, stream);
+            int rc = precision == 1
+                         ? mlp_forward_f16x3_launch(packed, a, b, p0, pc, S, nullptr, act_ws, n_pt, from_rays, stream)
+                         : mlp_forward_launch(packed, a, b, p0, pc, S, nullptr, act_ws, n_pt, from_rays, stream);
             if (rc != MVIP_OK) return rc;
         }
         const dim3 grid1((unsigned)(n_pt / 4)), block(256);
-        hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
-                           act_n_pt, act_pt0, gst, n_pt);
+        if (precision == 1) {
+            int rc = mlp_delta_f16x3_launch(packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act, act_n_pt, act_pt0, gst,
+                                            n_pt, stream);
+            if (rc != MVIP_OK) return rc;
+        } else
+            hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
+                               act_n_pt, act_pt0, gst, n_pt);
         int sps = (int)((n_pt + 63) / 64);
         if (sps < 1) sps = 1;
         if (sps > 32) sps = 32;
@@ -497,22 +513,24 @@ extern "C" int mvip_mlp_backward_rays(const float *packed, const float *rows, co
                                       const float *d_raw, float *const *grads_host, void *workspace,
                                       int64_t tile_points, int precision, void *stream) {
     if (B < 0 || S <= 0) return MVIP_EINVAL;
-    if (precision != 0) return MVIP_EUNSUP;
+    if (precision != 0 && precision != 1) return MVIP_EUNSUP;
     if (B == 0) return MVIP_OK;
     if (!packed || !rows || !z || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
     for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
-    return backward_impl(packed, rows, z, B * S, S, d_raw, grads_host, workspace, tile_points, true, nullptr, stream);
+    return backward_impl(packed, rows, z, B * S, S, d_raw, grads_host, workspace, tile_points, true, nullptr, precision,
+                         stream);
 }
 
 extern "C" int mvip_mlp_backward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
                                         const float *d_raw, float *const *grads_host, void *workspace,
                                         int64_t tile_points, int precision, void *stream) {
     if (P < 0) return MVIP_EINVAL;
-    if (precision != 0) return MVIP_EUNSUP;
+    if (precision != 0 && precision != 1) return MVIP_EUNSUP;
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
     for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
-    return backward_impl(packed, pts, dirs, P, 1, d_raw, grads_host, workspace, tile_points, false, nullptr, stream);
+    return backward_impl(packed, pts, dirs, P, 1, d_raw, grads_host, workspace, tile_points, false, nullptr, precision,
+                         stream);
 }
 
 extern "C" int64_t mvip_mlp_stash_floats(int64_t P) {
@@ -522,18 +540,22 @@ extern "C" int64_t mvip_mlp_stash_floats(int64_t P) {
 extern "C" int mvip_mlp_forward_rays_stash(const float *packed, const float *rows, const float *z, int64_t B, int S,
                                            float *raw, float *stash, int precision, void *stream) {
     if (B < 0 || S <= 0) return MVIP_EINVAL;
-    if (precision != 0) return MVIP_EUNSUP;
+    if (precision != 0 && precision != 1) return MVIP_EUNSUP;
     if (B == 0) return MVIP_OK;
     if (!packed || !rows || !z || !raw || !stash) return MVIP_EINVAL;
+    if (precision == 1)
+        return mlp_forward_f16x3_launch(packed, rows, z, 0, B * S, S, raw, stash, n_point_tiles(B * S), true, stream);
     return mlp_forward_launch(packed, rows, z, 0, B * S, S, raw, stash, n_point_tiles(B * S), true, stream);
 }
 
 extern "C" int mvip_mlp_forward_points_stash(const float *packed, const float *pts, const float *dirs, int64_t P,
                                              float *raw, float *stash, int precision, void *stream) {
     if (P < 0) return MVIP_EINVAL;
-    if (precision != 0) return MVIP_EUNSUP;
+    if (precision != 0 && precision != 1) return MVIP_EUNSUP;
     if (P == 0) return MVIP_OK;
     if (!packed || !pts || !dirs || !raw || !stash) return MVIP_EINVAL;
+    if (precision == 1)
+        return mlp_forward_f16x3_launch(packed, pts, dirs, 0, P, 1, raw, stash, n_point_tiles(P), false, stream);
     return mlp_forward_launch(packed, pts, dirs, 0, P, 1, raw, stash, n_point_tiles(P), false, stream);
 }
 
@@ -541,9 +563,10 @@ extern "C" int mvip_mlp_backward_stash(const float *packed, const float *stash, 
                                        float *const *grads_host, void *workspace, int64_t tile_points, int precision,
                                        void *stream) {
     if (P < 0) return MVIP_EINVAL;
-    if (precision != 0) return MVIP_EUNSUP;
+    if (precision != 0 && precision != 1) return MVIP_EUNSUP;
     if (P == 0) return MVIP_OK;
     if (!packed || !stash || !d_raw || !grads_host || !workspace) return MVIP_EINVAL;
     for (int i = 0; i < P_COUNT; ++i) if (!grads_host[i]) return MVIP_EINVAL;
-    return backward_impl(packed, nullptr, nullptr, P, 1, d_raw, grads_host, workspace, tile_points, false, stash, stream);
+    return backward_impl(packed, nullptr, nullptr, P, 1, d_raw, grads_host, workspace, tile_points, false, stash,
+                         precision, stream);
 }

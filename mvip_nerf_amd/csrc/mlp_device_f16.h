@@ -1,0 +1,128 @@
+// Device-side building blocks of the split-precision ("f16x3") kernels; see mlp_fwd_f16x3.hip.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+#include "mlp_device.h"
+
+namespace mvip {
+using namespace mlp;
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int F_GROUP_BLOCKS = 64;                         // blocks (1 KB) per barrier group
+constexpr int F_RING_FLOATS = 2 * F_GROUP_BLOCKS * BLOCK_FLOATS;   // 128 KB
+constexpr int F_LDS_FLOATS = F_RING_FLOATS + SEC_B_FLOATS;
+constexpr int F_TOTAL_GROUPS = (TOTAL_BLOCKS + F_GROUP_BLOCKS - 1) / F_GROUP_BLOCKS;
+static_assert(OFF_L1 % F_GROUP_BLOCKS == 0 && OFF_L5 % F_GROUP_BLOCKS == 0 && OFF_L6 % F_GROUP_BLOCKS == 0 &&
+              OFF_FEAT % F_GROUP_BLOCKS == 0 && OFF_VIEWS % F_GROUP_BLOCKS == 0 && LH_BLOCKS % F_GROUP_BLOCKS == 0,
+              "layers must start on barrier-group boundaries");
+
+struct StreamF {
+    const float *img;       // f16x3 image viewed as floats (same byte layout granularity: 256 floats = 1 KB)
+    float *lds;
+    int wave, lane;
+    int total_blocks = TOTAL_BLOCKS;
+    // issue the 64 blocks of barrier group g into ring half (g & 1): 16 blocks per wave
+    __device__ __forceinline__ void issue_group(int g) const {
+        if (g * F_GROUP_BLOCKS < total_blocks) {
+            const int nblk = (total_blocks - g * F_GROUP_BLOCKS) < F_GROUP_BLOCKS ? (total_blocks - g * F_GROUP_BLOCKS)
+                                                                                 : F_GROUP_BLOCKS;
+            const float *src = img + (int64_t)g * F_GROUP_BLOCKS * BLOCK_FLOATS + lane * 4;
+            float *dst = lds + (g & 1) * (F_GROUP_BLOCKS * BLOCK_FLOATS);
+            for (int b = wave; b < nblk; b += 4) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+        }
+    }
+    template <int BLK>      // BLK = absolute block index in the stream (compile time)
+    __device__ __forceinline__ h16x8 read_block() const {
+        constexpr int off = (BLK % (2 * F_GROUP_BLOCKS)) * BLOCK_FLOATS;
+        return *reinterpret_cast<const h16x8 *>(lds + off + lane * 4);
+    }
+};
+
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+struct Frag { h16x8 hi[2], lo[2]; };            // one 32-unit activation tile as B operands (k-steps 0,1)
+
+__device__ __forceinline__ Frag split_tile(const f32x16 &x) {
+    Frag f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = x[8 * s + j];
+            const _Float16 hv = (_Float16)v;
+            f.hi[s][j] = hv;
+            f.lo[s][j] = (_Float16)(v - (float)hv);
+        }
+    return f;
+}
+
+// bias + (optional) ReLU for this mode: v_max_f32 instead of compare+select
+template <bool RELU>
+__device__ __forceinline__ f32x16 bias_act(const f32x16 &acc, const float *bias32, int hh) {
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * hh);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float x = acc[4 * q + s] + b[s];
+            r[4 * q + s] = RELU ? fmaxf(x, 0.f) : x;
+        }
+    }
+    return r;
+}
+
+struct APair { h16x8 h, l; };      // [Ah | Al] fragments of one k-step
+
+// One layer: NT output tiles, KS k-steps of 16; BASE = absolute block offset of the layer.
+// bfrag(ks) -> (hi, lo) B fragments of k-step ks.  A operands are read from LDS TWO k-steps ahead
+// (a k-step is only 96 MFMA cycles, less than the loaded LDS latency); `a0`/`a1` carry the fragments
+// of the current and the next k-step across tiles and layers.  Reads never cross a barrier-group
+// boundary early: the next group is only guaranteed to have landed after its barrier.
+template <int BASE, int NT, int KS, bool LAST, class BFrag, class Pre, class Epi>
+__device__ __forceinline__ void run_layer_f(const StreamF &st, APair &a0, APair &a1, BFrag bfrag, Pre pre, Epi epi) {
+    using PV = decltype(pre(ic<0>{}));
+    f32x16 accs[2];
+    PV pvs[2];
+    static_for<NT>([&](auto ti) {
+        constexpr int T = decltype(ti)::value;
+        pvs[T & 1] = pre(ti);
+        f32x16 &acc = accs[T & 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        static_for<KS>([&](auto ks) {
+            constexpr int K = decltype(ks)::value;
+            constexpr int blk = BASE + 2 * (T * KS + K);                     // Ah block of this k-step
+            constexpr int left = LAST ? (NT * KS - (T * KS + K) - 1) : 1000;  // k-steps after this one
+            constexpr bool group_end = (blk + 2) % F_GROUP_BLOCKS == 0;       // this is the last k-step of its group
+            constexpr bool next_is_group_end = (blk + 4) % F_GROUP_BLOCKS == 0;
+            if constexpr (blk % F_GROUP_BLOCKS == 0) st.issue_group(blk / F_GROUP_BLOCKS + 1);
+            APair a2 = a1;
+            // fragments of k-step +2 live in the same group iff neither this nor the next step ends it
+            if constexpr (left >= 2 && !group_end && !next_is_group_end)
+                a2 = APair{st.template read_block<blk + 4>(), st.template read_block<blk + 5>()};
+            const auto b = bfrag(ks);
+            acc = mfma16(a0.h, b.first, acc);
+            acc = mfma16(a0.h, b.second, acc);
+            acc = mfma16(a0.l, b.first, acc);
+            if constexpr (group_end) {
+                __syncthreads();                                             // next group landed, this half is free
+                if constexpr (left >= 1) a1 = APair{st.template read_block<blk + 2>(), st.template read_block<blk + 3>()};
+                if constexpr (left >= 2) a2 = APair{st.template read_block<blk + 4>(), st.template read_block<blk + 5>()};
+            } else if constexpr (next_is_group_end) {
+                a2 = a1;                                                      // refilled after the next barrier
+            }
+            a0 = a1; a1 = a2;
+            if constexpr (K == 1 && T > 0) epi(ic<T - 1>{}, accs[(T - 1) & 1], pvs[(T - 1) & 1]);
+        });
+    });
+    epi(ic<NT - 1>{}, accs[(NT - 1) & 1], pvs[(NT - 1) & 1]);
+}
+
+struct FragPair { h16x8 first, second; };
+
+
+}  // namespace mvip

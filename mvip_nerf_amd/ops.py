@@ -186,17 +186,18 @@ class _MLPRays(torch.autograd.Function):
     """raw[B,S,4] = MLP(enc(o + d z), enc(viewdir)); gradients flow to the 24 parameters only."""
 
     @staticmethod
-    def forward(ctx, rows, z, packed, *params):
+    def forward(ctx, rows, z, packed, precision, *params):
+        """`packed` is the weight image of `precision` (0: fp32 image, 1: f16x3 image)."""
         B, S = z.shape
         raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
         stash = _take_stash(B * S, z.device)
         if stash is None:
-            call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
+            call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), precision, stream())
         else:
-            call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), 0,
+            call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), precision,
                  stream())
         ctx.save_for_backward(rows, z, packed)
-        ctx.stash = stash
+        ctx.stash, ctx.precision = stash, precision
         return raw
 
     @staticmethod
@@ -208,21 +209,22 @@ class _MLPRays(torch.autograd.Function):
         stash, ctx.stash = ctx.stash, None
         if stash is None:
             call('mvip_mlp_backward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(_f32c(d_raw)),
-                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, ctx.precision, stream())
         else:
             call('mvip_mlp_backward_stash', ptr(packed), ptr(stash), B * S, ptr(_f32c(d_raw)),
-                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
+                 _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, ctx.precision, stream())
             del stash
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class _MLPPoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pts, dirs, packed, *params):
+    def forward(ctx, pts, dirs, packed, precision, *params):
         P = pts.shape[0]
         raw = torch.empty((P, 4), device=pts.device, dtype=_F32)
-        call('mvip_mlp_forward_points', ptr(packed), ptr(pts), ptr(dirs), P, ptr(raw), 0, stream())
+        call('mvip_mlp_forward_points', ptr(packed), ptr(pts), ptr(dirs), P, ptr(raw), precision, stream())
         ctx.save_for_backward(pts, dirs, packed)
+        ctx.precision = precision
         return raw
 
     @staticmethod
@@ -231,17 +233,20 @@ class _MLPPoints(torch.autograd.Function):
         grads = _zero_grads(pts.device)
         ws = _workspace(pts.device, BWD_TILE_POINTS)
         call('mvip_mlp_backward_points', ptr(packed), ptr(pts), ptr(dirs), pts.shape[0], ptr(_f32c(d_raw)),
-             _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, 0, stream())
-        return (None, None, None, *grads)
+             _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, ctx.precision, stream())
+        return (None, None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params, packed_f16x3=None):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
-    routes the gradient image back to them; with no grad needed the Function is skipped.
-    `packed_f16x3` (inference only) selects the split-precision kernel (precision = 1)."""
+    routes the gradients back to them; with no grad needed the Function is skipped.
+    `packed_f16x3` selects the split-precision kernel (precision = 1) for no-grad calls,
+    `train_f16x3` (the same kind of image) for calls that will be back-propagated."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return _MLPRays.apply(rows, z, packed, *params)
+        if train_f16x3 is not None:
+            return _MLPRays.apply(rows, z, train_f16x3, 1, *params)
+        return _MLPRays.apply(rows, z, packed, 0, *params)
     B, S = z.shape
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
     if packed_f16x3 is not None:
@@ -251,10 +256,12 @@ def mlp_rays(rows, z, packed, params, packed_f16x3=None):
     return raw
 
 
-def mlp_points(pts, dirs, packed, params, packed_f16x3=None):
+def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None):
     pts, dirs = _f32c(pts), _f32c(dirs)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return _MLPPoints.apply(pts, dirs, packed, *params)
+        if train_f16x3 is not None:
+            return _MLPPoints.apply(pts, dirs, train_f16x3, 1, *params)
+        return _MLPPoints.apply(pts, dirs, packed, 0, *params)
     raw = torch.empty((pts.shape[0], 4), device=pts.device, dtype=_F32)
     if packed_f16x3 is not None:
         call('mvip_mlp_forward_points', ptr(packed_f16x3), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 1, stream())

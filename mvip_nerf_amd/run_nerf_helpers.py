@@ -74,6 +74,7 @@ class NeRF(nn.Module):
         # 0: exact fp32 MFMA everywhere.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative) for
         # forward passes that need no gradient (rendering); training always runs precision 0.
         self.inference_precision = 0
+        self.train_precision = 0      # 1: f16x3 forward + delta kernels in training too (weight gradients stay fp32 MFMA)
 
     def _check_supported(self):
         if not (self.D == 8 and self.W == 256 and self.input_ch == 63 and self.input_ch_views == 27
@@ -116,11 +117,14 @@ class NeRF(nn.Module):
     def _fast_image(self):
         return self.packed_f16x3() if self.inference_precision == 1 else None
 
+    def _train_image(self):
+        return self.packed_f16x3() if self.train_precision == 1 else None
+
     def query_points(self, pts, dirs):
-        return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image())
+        return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image(), self._train_image())
 
     def query_rays(self, rows, z):
-        return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image())
+        return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

@@ -362,3 +362,18 @@ def test_render_f16x3_matches_fp32_render(cuda):
         b = run.render(H, W, f, chunk=1 << 15, c2w=c2w, near=1.2, far=7.74, **te)
     mse = float(((N(a[0]) - N(b[0])) ** 2).mean())
     assert mse < 1e-9, f'PSNR(f16x3 vs fp32) = {-10 * np.log10(max(mse, 1e-30)):.1f} dB'
+
+
+def test_mlp_backward_f16x3_golden(golden, cuda):
+    """train_precision=1: split-precision stash-forward + delta kernels; gradients vs the reference autograd."""
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    for budget in (96 << 30, 0):                       # kept-stash path and recompute path
+        ops.STASH_BUDGET_BYTES = budget
+        ps = [p.requires_grad_(True) for p in params_dev(g['seed'], cuda)]
+        packed = ops.mlp_pack(ps)
+        raw = ops.mlp_points(T(g['pts'], cuda), T(g['dirs'], cuda), packed, ps, train_f16x3=ops.mlp_pack_f16x3(ps, packed))
+        np.testing.assert_allclose(N(raw), g['out'], rtol=5e-5, atol=5e-6)
+        (raw * T(g['gout'], cuda)).sum().backward()
+        _check_grads(g, '', {k: p.grad for k, p in zip(ops.PARAM_ORDER, ps)}, 2e-5, 2e-4)
+    ops.STASH_BUDGET_BYTES = 96 << 30
