@@ -211,6 +211,25 @@ def main():
             t = torch.tensor([dt_tr], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_tr = float(t.item())
+        # the same iteration with the split-precision kernels (train_precision = 1: f16x3 forward, delta and
+        # weight-gradient kernels; same stash, same atomics, fp32 accumulation everywhere)
+        for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
+            n.train_precision = 1
+        trainer.step(100)
+        barrier()
+        t1b = time.perf_counter()
+        for k in range(args.train_steps):
+            trainer.step(101 + k)
+        barrier()
+        dt_tr16 = time.perf_counter() - t1b
+        for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
+            n.train_precision = 0
+        if dist is not None:
+            t = torch.tensor([dt_tr16], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_tr16 = float(t.item())
+        result['train_f16x3'] = {'rays_per_sec': n_rays * world / dt_tr16, 'ms_per_step': dt_tr16 / args.train_steps * 1e3,
+                                 'what': 'the same iteration with train_precision=1 (split-precision MFMA kernels)'}
         result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
                            'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
                            'what': 'second-stage iteration without the diffusion prior: masked-set render '

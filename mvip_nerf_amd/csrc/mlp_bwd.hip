@@ -22,6 +22,7 @@
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_device.h"
+#include "mlp_device_f16.h"
 
 namespace mvip {
 using namespace mlp;
@@ -212,15 +213,38 @@ __device__ __forceinline__ f32x4 read_piece(const float *tile, int row, int cw) 
     return *reinterpret_cast<const f32x4 *>(tile + row * 32 + ((cw ^ ((row >> 1) & 7)) << 2));
 }
 
-template <int NTW, int KT>
+// |d_raw| maximum of a backward call (bits of a non-negative float order like unsigned integers)
+__global__ void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// PREC = 1: the point-contraction runs on v_mfma_f32_32x32x16_f16 with both operands split hi+lo in
+// registers from the fp32 stash blocks (three products, fp32 accumulate).  Gradients are scaled by a
+// per-call power of two (from max|d_raw|) before splitting and the result is un-scaled before the
+// atomics, so the fp16 lo terms stay out of the subnormal range for any loss scale.
+// BSPLIT (used by the f16 path of the 128x256 products): instead of each wave owning NTW gradient
+// tiles x ALL act tiles, each wave owns ALL NTW(=4) gradient tiles x KT(=2) act tiles -- the same
+// 8 accumulator tiles and 24 MFMAs per k-step, but 6 instead of 9 operand conversions.
+template <int NTW, int KT, int PREC = 0, bool BSPLIT = false>
 __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act, int64_t act_n_pt,
                                            int64_t act_pt0, const float *__restrict__ gst, int64_t n_pt,
-                                           int64_t pt0, int64_t pt1, float *lds, int wave, int lane) {
-    constexpr int NT = 4 * NTW;
+                                           int64_t pt0, int64_t pt1, float *lds, int wave, int lane,
+                                           float gscale = 1.f, float inv_gscale = 1.f) {
+    constexpr int NT = BSPLIT ? NTW : 4 * NTW;           // gradient tiles in a stage
+    constexpr int KTT = BSPLIT ? 4 * KT : KT;            // act tiles in a stage
+    const int a_first = BSPLIT ? 0 : wave * NTW;         // this wave's first gradient tile
+    const int b_first = BSPLIT ? wave * KT : 0;          // this wave's first act tile
     const int i = lane & 31, hh = lane >> 5;
     const int extra = G.extra;
     const int nextra = extra == 2 ? 5 : (extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
-    const int nblk = NT + KT + nextra;
+    const int nblk = NT + KTT + nextra;
     const int g_tile0 = G.g_tile0, a0 = G.a_tile0[0], a1 = G.a_tile0[1], ac0 = G.a_count0;
 
     // wave w stages rows 8w..8w+7 of every block of the stage (one LDS-DMA per block and wave)
@@ -231,8 +255,8 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
             int tile;
             bool from_g = false;
             if (b < NT) { tile = g_tile0 + b; from_g = true; }
-            else if (b < NT + KT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
-            else if (extra == 2 && b < NT + KT + 4) tile = AT_V + (b - NT - KT);
+            else if (b < NT + KTT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
+            else if (extra == 2 && b < NT + KTT + 4) tile = AT_V + (b - NT - KTT);
             else { tile = GT_D; from_g = true; }
             const float *src = from_g ? gst + ((int64_t)tile * n_pt + pt) * TILE_FLOATS
                                       : act + ((int64_t)tile * act_n_pt + act_pt0 + pt) * TILE_FLOATS;
@@ -278,7 +302,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[a][b] = mfma(A[a][s], Bv[b][s], acc[a][b]);
             if (extra == 1 && wave == 0) {             // d(alpha_linear.weight)[k] = sum_p d_sigma[p] h7[k][p]
-                const f32x4 ds = read_piece(stg + (NT + KT) * TILE_FLOATS, 3, cw);
+                const f32x4 ds = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw);
                 if constexpr (KT == 8) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b)
@@ -288,7 +312,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                 xb[0] += (ds[0] + ds[1]) + (ds[2] + ds[3]);
             }
             if (extra == 2 && wave == 0) {             // d(rgb_linear.weight)[c][k] = sum_p d_rgb[c][p] v[k][p]
-                const float *xt = stg + (NT + KT) * TILE_FLOATS;
+                const float *xt = stg + (NT + KTT) * TILE_FLOATS;
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
                     const f32x4 dc = read_piece(xt + 4 * TILE_FLOATS, cc, cw);
@@ -310,6 +334,75 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         }
     };
 
+    auto compute_stage_f16 = [&](const float *stg) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                 // 16 points per k-step; lane (i,hh) takes points 16ks+8hh..+7
+            const int cw = 4 * ks + 2 * hh;
+            h16x8 Ah[NTW], Al[NTW], Bh[KT], Bl[KT];
+            auto split8 = [&](const f32x4 &p0, const f32x4 &p1, float sc, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = (q < 4 ? p0[q & 3] : p1[q & 3]) * sc;
+                    const _Float16 hv = (_Float16)v;
+                    hi[q] = hv;
+                    lo[q] = (_Float16)(v - (float)hv);
+                }
+            };
+#pragma unroll
+            for (int a = 0; a < NTW; ++a) {
+                const float *t = stg + (a_first + a) * TILE_FLOATS;
+                const f32x4 p0 = read_piece(t, i, cw), p1 = read_piece(t, i, cw + 1);
+                bsum[a] += ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+                split8(p0, p1, gscale, Ah[a], Al[a]);
+            }
+            f32x4 ds0, ds1;
+            const bool do_alpha = extra == 1 && (BSPLIT || wave == 0);     // sigma-row dots over this wave's act tiles
+            if (do_alpha) {
+                ds0 = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw);
+                ds1 = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw + 1);
+                xb[0] += ((ds0[0] + ds0[1]) + (ds0[2] + ds0[3])) + ((ds1[0] + ds1[1]) + (ds1[2] + ds1[3]));
+            }
+#pragma unroll
+            for (int b = 0; b < KT; ++b) {
+                const float *t = stg + (NT + b_first + b) * TILE_FLOATS;
+                const f32x4 p0 = read_piece(t, i, cw), p1 = read_piece(t, i, cw + 1);
+                split8(p0, p1, 1.f, Bh[b], Bl[b]);
+                if (do_alpha) {
+                    if constexpr (KT <= 8) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xw[b] = fmaf(ds1[q], p1[q], fmaf(ds0[q], p0[q], xw[b]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < NTW; ++a)
+#pragma unroll
+                for (int b = 0; b < KT; ++b) {
+                    acc[a][b] = mfma16(Ah[a], Bh[b], acc[a][b]);
+                    acc[a][b] = mfma16(Ah[a], Bl[b], acc[a][b]);
+                    acc[a][b] = mfma16(Al[a], Bh[b], acc[a][b]);
+                }
+            if (extra == 2 && wave == 0) {             // rgb rows: fp32 VALU dots on the same 8 points
+                const float *xt = stg + (NT + KTT) * TILE_FLOATS;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const f32x4 d0 = read_piece(xt + 4 * TILE_FLOATS, cc, cw), d1 = read_piece(xt + 4 * TILE_FLOATS, cc, cw + 1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 v0 = read_piece(xt + t * TILE_FLOATS, i, cw), v1 = read_piece(xt + t * TILE_FLOATS, i, cw + 1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xw[cc * 4 + t] = fmaf(d1[q], v1[q], fmaf(d0[q], v0[q], xw[cc * 4 + t]));
+                    }
+                    xb[cc] += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
+                }
+            }
+        }
+    };
+    auto compute = [&](const float *stg) {
+        if constexpr (PREC == 1) compute_stage_f16(stg);
+        else compute_stage(stg);
+    };
+
     // double-buffered stages with COMPILE-TIME buffer addresses (so LDS-DMA writes into one buffer
     // provably do not alias the ds_reads of the other and no wait is inserted between them)
     float *buf0 = lds, *buf1 = lds + W_STAGE_FLOATS;
@@ -317,42 +410,43 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     __syncthreads();
     for (int64_t pt = pt0; pt < pt1; pt += 2) {
         if (pt + 1 < pt1) issue_stage(pt + 1, buf1);
-        compute_stage(buf0);
+        compute(buf0);
         __syncthreads();          // stage pt+1 landed (vmcnt(0)) and everyone is done with buf0
         if (pt + 1 >= pt1) break;
         if (pt + 2 < pt1) issue_stage(pt + 2, buf0);
-        compute_stage(buf1);
+        compute(buf1);
         __syncthreads();
     }
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
 #pragma unroll
     for (int a = 0; a < NTW; ++a) {
-        const int n0 = G.n_off + 32 * (wave * NTW + a);
+        const int n0 = G.n_off + 32 * (a_first + a);
 #pragma unroll
         for (int b = 0; b < KT; ++b) {
-            const int seg = b < ac0 ? 0 : 1;
-            const int kcol = 32 * (seg ? b - ac0 : b) + i;
+            const int bg = b_first + b;                       // act tile index inside the product
+            const int seg = bg < ac0 ? 0 : 1;
+            const int kcol = 32 * (seg ? bg - ac0 : bg) + i;
             if (kcol < G.valid[seg]) {
                 float *dst = G.dW + (int64_t)(n0 + 4 * hh) * G.ldw + G.col0[seg] + kcol;
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    atomicAdd(dst + (int64_t)(8 * (q >> 2) + (q & 3)) * G.ldw, acc[a][b][q]);
+                    atomicAdd(dst + (int64_t)(8 * (q >> 2) + (q & 3)) * G.ldw, acc[a][b][q] * inv_gscale);
             }
         }
-        if (G.db) {
+        if (G.db && (!BSPLIT || a == wave)) {                 // BSPLIT: every wave holds all four sums, each flushes one
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
             if (hh == 0) atomicAdd(G.db + n0 + i, tot);
         }
     }
-    if (extra == 1 && wave == 0) {
+    if (extra == 1 && (BSPLIT || wave == 0)) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < (KT < 8 ? KT : 8); ++b) {
             const float tot = xw[b] + __shfl_xor(xw[b], 32, 64);
-            if (hh == 0) atomicAdd(G.dWx + 32 * b + i, tot);
+            if (hh == 0) atomicAdd(G.dWx + 32 * (b_first + b) + i, tot);
         }
         const float tb = xb[0] + __shfl_xor(xb[0], 32, 64);
-        if (lane == 0) atomicAdd(G.dbx, tb);
+        if (lane == 0 && wave == 0) atomicAdd(G.dbx, tb);
     }
     if (extra == 2 && wave == 0) {
 #pragma unroll
@@ -381,10 +475,12 @@ __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
 // blockIdx.y: 0..15 the eight 256x256 products as two 128-row halves each, 16..17 the two 256x64
 // products with the encoding, 18..19 the view branch in two column groups.  No wave holds more than
 // 128 accumulator registers: with 256 hipcc shuttles tiles between AGPRs and VGPRs every stage.
+template <int PREC>
 __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
                                                           const float *__restrict__ act, int64_t act_n_pt,
                                                           int64_t act_pt0, const float *__restrict__ gst,
-                                                          int64_t n_pt, int stages_per_slab) {
+                                                          int64_t n_pt, int stages_per_slab,
+                                                          const unsigned *__restrict__ absmax_bits) {
     __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -394,13 +490,25 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restric
     if (pt1 > n_pt) pt1 = n_pt;
     if (pt0 >= pt1) return;
     const Gemm G = tab[id];
-    if (id < 16) wgrad_body<1, 8>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else if (id < 18) wgrad_body<2, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else if (id == 18) wgrad_body<1, 5>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
-    else wgrad_body<1, 4>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane);
+    float gs = 1.f, igs = 1.f;
+    if constexpr (PREC == 1) {                     // scale max|d_raw| to [64, 128)
+        const float mx = __uint_as_float(*absmax_bits);
+        int e = ((__float_as_int(mx) >> 23) & 255) - 127;
+        if (!(mx > 0.f) || e > 120) e = 6;
+        if (e < -110) e = -110;
+        gs = __int_as_float((127 + 6 - e) << 23);
+        igs = __int_as_float((127 + e - 6) << 23);
+    }
+    if (id < 16) {
+        if constexpr (PREC == 1) wgrad_body<4, 2, 1, true>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        else wgrad_body<1, 8, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    }
+    else if (id < 18) wgrad_body<2, 2, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else if (id == 18) wgrad_body<1, 5, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else wgrad_body<1, 4, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
 }
 
-static_assert(sizeof(Gemm) * N_PRODUCTS <= 1024 * 4, "table room");
+static_assert(sizeof(Gemm) * N_PRODUCTS <= 1024 * 4 - 16, "table room (+ the absmax word)");
 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
@@ -469,6 +577,11 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
     else hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
     const GemmTable tab = make_table(grads_host);
     hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
+    unsigned *absmax = reinterpret_cast<unsigned *>(ws + T_FLOATS + TABLE_FLOATS - 4);   // tail of the table block
+    if (precision == 1) {
+        hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, d_raw, P * 4, absmax);
+    }
     const int64_t n_pt_all = n_point_tiles(P);
     for (int64_t p0 = 0; p0 < P; p0 += tile_points) {
         const int64_t pc = (P - p0 < tile_points) ? (P - p0) : tile_points;
@@ -494,7 +607,10 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         if (sps < 1) sps = 1;
         if (sps > 32) sps = 32;
         const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), N_PRODUCTS);
-        hipLaunchKernelGGL(mlp_wgrad_kernel, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps);
+        if (precision == 1)
+            hipLaunchKernelGGL(mlp_wgrad_kernel<1>, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+        else
+            hipLaunchKernelGGL(mlp_wgrad_kernel<0>, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
     }
     return check_launch();
 }

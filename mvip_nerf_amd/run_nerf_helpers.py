@@ -71,10 +71,9 @@ class NeRF(nn.Module):
         self._packed_key = None
         self._packed16 = None
         self._packed16_key = None
-        # 0: exact fp32 MFMA everywhere.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative) for
-        # forward passes that need no gradient (rendering); training always runs precision 0.
-        self.inference_precision = 0
-        self.train_precision = 0      # 1: f16x3 forward + delta kernels in training too (weight gradients stay fp32 MFMA)
+        # 0: exact fp32 MFMA.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative, fp32 accumulate).
+        self.inference_precision = 0  # forward passes that need no gradient (rendering)
+        self.train_precision = 0      # stash-writing forward, delta and weight-gradient kernels
 
     def _check_supported(self):
         if not (self.D == 8 and self.W == 256 and self.input_ch == 63 and self.input_ch_views == 27

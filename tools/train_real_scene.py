@@ -11,6 +11,7 @@ from mvip_nerf_amd.run_nerf_helpers import img2mse, mse2psnr
 ap = argparse.ArgumentParser()
 ap.add_argument('--iters', type=int, default=3000)
 ap.add_argument('--rays', type=int, default=4096)
+ap.add_argument('--train-precision', type=int, default=0)
 ap.add_argument('--oracle-view', type=int, default=1, help='render this many held-out views with the CPU oracle')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -30,6 +31,8 @@ args = types.SimpleNamespace(multires=10, i_embed=0, use_viewdirs=True, multires
 torch.manual_seed(0)
 tr, te, _, grad_vars, opt = run.create_nerf(args, device=dev)
 kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
+for _n in (tr['network_fn'], tr['network_fine']):
+    _n.train_precision = a.train_precision
 g = torch.Generator(device=dev).manual_seed(0)
 t0 = time.perf_counter()
 log = []
@@ -50,7 +53,7 @@ for it in range(a.iters):
         print(it, float(loss), flush=True)
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0
-res = {'iters': a.iters, 'rays_per_iter': a.rays, 'train_seconds': train_s, 'ms_per_iter': train_s / a.iters * 1e3,
+res = {'train_precision': a.train_precision, 'iters': a.iters, 'rays_per_iter': a.rays, 'train_seconds': train_s, 'ms_per_iter': train_s / a.iters * 1e3,
        'train_rays_per_sec': a.iters * a.rays / train_s, 'H': H, 'W': W, 'views_train': len(i_train), 'loss_log': log}
 kw_te = dict(te, near=near, far=far)
 psnr_hip, renders = [], []
@@ -83,4 +86,4 @@ for k in range(a.oracle_view):
 res['hip_vs_oracle_same_weights'] = cmp
 print(json.dumps(res))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'real_scene_r1.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'real_scene_r1_prec{a.train_precision}.json'), 'w'), indent=1)
