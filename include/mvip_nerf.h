@@ -205,6 +205,56 @@ int mvip_sds_grad_dev(const float *eps_uncond, const float *eps_cond, const floa
                       float guidance_scale, const float *scal, int64_t n, int accumulate, float *grad,
                       void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a14-a16  GroupNorm (+ fused SiLU) of the SDS networks: the `norm -> silu -> conv` prologue of every
+ * ResNet block inside vae.encode / unet (call sites DS_NeRF/guidance/sd_utils.py:148, :162, :189,
+ * :212; the blocks themselves live in `diffusers`, absent from the reference tree -- published
+ * SD-1.5 architecture, parity checked against torch.nn.functional.group_norm in fp32).
+ * x, y, dy, dx: [N, C, HW] contiguous (NCHW); gamma, beta: [C] or NULL; dtype 0 = fp32, 1 = fp16
+ * (storage type of x/y/dy/dx/gamma/beta; arithmetic fp32, statistics fp64).
+ *   forward : y = act((x - mean_g) * rstd_g * gamma[c] + beta[c]),  act = SiLU if `silu` else identity;
+ *             mean, rstd [N, G] fp32 are written for the backward.
+ *   backward: dx only (the SDS networks are frozen; gradients flow to the rendered image).
+ * workspace: mvip_groupnorm_workspace_bytes(N, C, HW) bytes, 16-byte aligned. */
+int64_t mvip_groupnorm_workspace_bytes(int64_t N, int64_t C, int64_t HW);
+int mvip_groupnorm_forward(const void *x, const void *gamma, const void *beta, int64_t N, int64_t C,
+                           int64_t HW, int G, float eps, int silu, int dtype, void *y, float *mean,
+                           float *rstd, void *workspace, void *stream);
+int mvip_groupnorm_backward(const void *x, const void *dy, const void *gamma, const void *beta,
+                            const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
+                            int silu, int dtype, void *dx, void *workspace, void *stream);
+/* statistics only (mean, rstd [N, G]); the normalised tensor is then produced by another kernel */
+int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G, float eps, int dtype,
+                         float *mean, float *rstd, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a14-a16  3x3 / stride 1 / pad 1 convolution of the SDS networks (the ResNet-block convolutions inside
+ * vae.encode / unet: DS_NeRF/guidance/sd_utils.py:148, :162, :189, :212; layers from the published SD-1.5
+ * architecture) as an implicit GEMM on the fp16 matrix cores in split precision: both operands are
+ * split into fp16 hi + lo terms and Wh.Xh + Wh.Xl + Wl.Xh is accumulated in fp32 (~1e-6 relative).
+ *
+ * Activations travel in "split planes": xs[N][Cin/16][2][2][H][W][8] fp16 (N*Cin*H*W*4 bytes), written
+ * by mvip_groupnorm_split_planes (GroupNorm + optional SiLU fused) or mvip_split_planes (x * scale2[0]).
+ * Weights are packed once per layer by mvip_conv3x3_pack into mvip_conv3x3_packed_bytes(Cout, Cin)
+ * bytes; transpose = 1 packs the data-gradient operator (then the conv maps dY [N,Cout,H,W] -> dX
+ * [N,Cin,H,W]: call mvip_conv3x3_f16x3 with Cin and Cout swapped).
+ * scale2 = {s, 1/s, scratch, scratch} (device, 16 bytes): power-of-two scale from the absolute maximum.
+ *   y[n,co,h,w] = conv(x, W)[n,co,h,w] / (s_w s_x) + bias[co] + chan_add[n,co] + residual[n,co,h,w]
+ * (bias, chan_add, residual, x_scale2 may be NULL).  Supported: Cout % 32 == 0, Cin % 16 == 0,
+ * H % 8 == 0, W % 32 == 0 (mvip_conv3x3_supported); anything else returns MVIP_EINVAL. */
+int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W);
+int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
+int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
+int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *stream);
+int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
+                      void *stream);
+int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
+                                const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
+                                void *stream);
+int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                       const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                       int64_t H, int64_t W, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

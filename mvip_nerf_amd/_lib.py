@@ -58,6 +58,19 @@ _SIGNATURES = {
     'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
     'mvip_sds_add_noise_dev': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_sds_grad_dev': (_int, [_c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_groupnorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'mvip_groupnorm_forward': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _flt, _int, _int, _c_f, _c_f, _c_f, _c_f,
+                                      _c_f]),
+    'mvip_groupnorm_stats': (_int, [_c_f, _i64, _i64, _i64, _int, _flt, _int, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_conv3x3_supported': (_int, [_i64, _i64, _i64, _i64]),
+    'mvip_conv3x3_packed_bytes': (_i64, [_i64, _i64]),
+    'mvip_conv3x3_pack': (_int, [_c_f, _i64, _i64, _int, _c_f, _c_f]),
+    'mvip_absmax_scale': (_int, [_c_f, _i64, _c_f, _c_f]),
+    'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
+    'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _c_f]),
+    'mvip_conv3x3_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_groupnorm_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _int, _c_f, _c_f,
+                                       _c_f]),
 }
 
 # every symbol include/mvip_nerf.h declares; tests check the built library exports all of them

@@ -1,0 +1,390 @@
+// 3x3 / stride 1 / pad 1 convolution of the SDS networks as an implicit GEMM on the fp16 matrix cores in
+// split precision ("f16x3": both operands split into fp16 hi + lo, the three leading products
+// Wh.Xh + Wh.Xl + Wl.Xh accumulated in fp32 -- ~1e-6 relative, i.e. fp32-grade results at ~2.7x the
+// exact-fp32 MFMA rate).  These are the ResNet-block convolutions inside vae.encode / unet
+// (call sites DS_NeRF/guidance/sd_utils.py:148, :162, :189, :212; block structure from the published
+// SD-1.5 architecture) -- 1.0 TFLOP per VAE encode, the largest single item of the SDS step.
+//
+// GEMM view: M = output channels, N = pixels, K = (tap, input channel).
+//   * activations arrive in "split planes": xs[n][Cin/16][kg 2][hl 2][H][W][8 halves] -- for 16-channel
+//     chunk ck, plane (kg, hl) holds channels ck*16 + kg*8 + 0..7 of every pixel as the hi (hl=0) or lo
+//     (hl=1) fp16 term.  16 B per (pixel, plane) = one MFMA B-operand fragment, so a haloed pixel tile goes
+//     HBM -> LDS by DMA (global_load_lds) with no register staging, and the shifted windows of the nine
+//     taps are plain offset reads of the same LDS tile.  The producers write this layout directly
+//     (GroupNorm+SiLU apply, or the plain converter for gradients).
+//   * weights are packed once per layer in MFMA A-fragment order, pre-scaled by a power of two so that
+//     the lo terms stay in fp16's normal range:
+//     wp[Cout/32][Cin/16][ky][kx][hl][lane 64][8 halves]; the tail holds {scale, 1/scale}.
+//   * one workgroup = MT*32 output channels x (8 x 32) pixels, 4 waves, each wave MT x 2 accumulator tiles;
+//     MT = 4, 2 or 1 is chosen per launch so that the grid covers the 256 CUs.
+//     K loop: 16 input channels x one kernel row per stage (3 taps, 72 MFMAs per wave at MT=4), weights
+//     and the input tile double-buffered in LDS, one barrier per stage.
+//   * epilogue: x 1/scale, + bias, + per-(sample, channel) addend (time embedding), + residual, NCHW fp32.
+#include "common.h"
+
+namespace mvip {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CV_TH = 8, CV_TW = 32;
+constexpr int CV_HW = CV_TW + 2;                    // haloed tile width
+constexpr int CV_PIX = (CV_TH + 2) * CV_HW;         // 340 haloed pixels
+constexpr int CV_IN_ROUNDS = 6;                     // 4 planes x 340 = 1360 slots, padded to 6 x 256
+constexpr int CV_IN_BYTES = CV_IN_ROUNDS * 256 * 16;
+
+__device__ __forceinline__ void glds16b(const void *src_lane, void *dst_wave) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                     (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h2 a, b;
+        a.x = (_Float16)v[2 * i]; a.y = (_Float16)v[2 * i + 1];
+        b.x = (_Float16)(v[2 * i] - (float)a.x); b.y = (_Float16)(v[2 * i + 1] - (float)a.y);
+        h[i] = __builtin_bit_cast(unsigned, a); l[i] = __builtin_bit_cast(unsigned, b);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ---- power-of-two scale from the absolute maximum ----------------------------------------------------
+__global__ void cv_absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// scale2 = {s, 1/s} with s a power of two such that absmax*s lies in [2^9, 2^10)
+__global__ void cv_scale_kernel(const unsigned *__restrict__ bits, float *__restrict__ scale2) {
+    const float m = __uint_as_float(*bits);
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e;
+        frexpf(m, &e);
+        int k = 10 - e;
+        if (k > 60) k = 60;
+        if (k < -60) k = -60;
+        s = ldexpf(1.f, k);
+    }
+    scale2[0] = s;
+    scale2[1] = 1.f / s;
+}
+
+// ---- weight packing ----------------------------------------------------------------------------------
+// one thread per 16-byte fragment piece.  transpose = 1 packs the data-gradient operator:
+// W'[co'][ci'][ky][kx] = W[ci'][co'][2-ky][2-kx]  (Cout' = Cin, Cin' = Cout of the forward layer).
+__global__ void cv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int transpose,
+                               const float *__restrict__ scale2, uint4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CK = Cin / 16;
+    const int64_t total = (int64_t)(Cout / 32) * CK * 9 * 2 * 64;
+    if (idx >= total) return;
+    int64_t r = idx;
+    const int lane = (int)(r % 64); r /= 64;
+    const int hl = (int)(r % 2); r /= 2;
+    const int kx = (int)(r % 3); r /= 3;
+    const int ky = (int)(r % 3); r /= 3;
+    const int ck = (int)(r % CK); r /= CK;
+    const int co = (int)r * 32 + (lane & 31);
+    const int kg = lane >> 5;
+    const float s = scale2[0];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ck * 16 + kg * 8 + j;
+        const int64_t src = transpose ? (((int64_t)ci * Cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)
+                                      : (((int64_t)co * Cin + ci) * 3 + ky) * 3 + kx;
+        v[j] = w[src] * s;
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    out[idx] = hl ? lo : hi;
+}
+
+// ---- activation producers ------------------------------------------------------------------------------
+// grid (ceil(HW/256), N*C/16): thread = pixel, 16 channel rows read coalesced, 4 plane pieces written.
+// GN: z = act((x - mean)*rstd*gamma + beta) with per-group statistics; otherwise z = x * scale2[0].
+template <bool GN, bool SILU>
+__global__ void __launch_bounds__(256)
+cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                   const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ scale2,
+                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs) {
+    __shared__ float pa[16], pb[16], pm[16];
+    const int CK = C / 16;
+    const int ck = (int)(blockIdx.y % CK);
+    const int64_t n = blockIdx.y / CK;
+    if (GN) {
+        if (threadIdx.x < 16) {
+            const int c = ck * 16 + threadIdx.x;
+            const int G = C / cpg;
+            const int g = c / cpg;
+            pm[threadIdx.x] = mean[n * G + g];
+            pa[threadIdx.x] = rstd[n * G + g] * (gamma ? gamma[c] : 1.f);
+            pb[threadIdx.x] = beta ? beta[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float s = (!GN && scale2) ? scale2[0] : 1.f;
+    const float *xr = x + (n * C + ck * 16) * HW + p;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = xr[c * HW];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (GN) {
+            const float z = (v[c] - pm[c]) * pa[c] + pb[c];
+            v[c] = SILU ? z / (1.0f + expf(-z)) : z;
+        } else {
+            v[c] *= s;
+        }
+    }
+    uint4 *dst = xs + ((n * CK + ck) * 4) * HW + p;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[kg * 8 + j];
+        uint4 hi, lo;
+        split8(t, hi, lo);
+        dst[(kg * 2 + 0) * HW] = hi;
+        dst[(kg * 2 + 1) * HW] = lo;
+    }
+}
+
+// ---- the convolution -------------------------------------------------------------------------------------
+struct ConvArgs {
+    const char *xs, *wp, *zero16;
+    const float *bias, *chan_add, *residual, *x_scale2, *w_scale2;
+    float *y;
+    int N, CK, Cout, H, W, tilesX, tilesY, MB;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
+    constexpr int WB = 3 * MT * 2 * 1024;              // weights of one stage (kernel row, 16 channels)
+    __shared__ __attribute__((aligned(16))) char lds[2 * WB + 2 * CV_IN_BYTES];
+    char *lds_w = lds, *lds_in = lds + 2 * WB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, kg = lane >> 5;
+
+    // XCD-aware order: each of the 8 XCDs walks a contiguous range of (tile, channel-block) pairs, the
+    // channel blocks of one pixel tile adjacent in time, so the tile's planes are served by that XCD's L2.
+    int id = blockIdx.x;
+    const int total = gridDim.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int mb = id % a.MB;
+    int tile = id / a.MB;
+    const int tx = tile % a.tilesX; tile /= a.tilesX;
+    const int ty = tile % a.tilesY;
+    const int n = tile / a.tilesY;
+    const int y0 = ty * CV_TH, x0 = tx * CV_TW;
+    const int H = a.H, W = a.W;
+    const int64_t plane = (int64_t)H * W * 16;
+
+    int in_off[CV_IN_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < CV_IN_ROUNDS; ++r) {
+        const int s = r * 256 + tid;
+        in_off[r] = -1;
+        if (s < 4 * CV_PIX) {
+            const int piece = s / CV_PIX, p = s - piece * CV_PIX;
+            const int row = p / CV_HW, col = p - row * CV_HW;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[r] = (int)(piece * plane) + (gy * W + gx) * 16;
+        }
+    }
+    const char *xs_n = a.xs + (int64_t)n * a.CK * 4 * plane;
+    constexpr int WROW = 3 * 2 * 1024;                 // one stage of one 32-channel row block
+    const char *wp_b = a.wp + (int64_t)mb * MT * a.CK * 3 * WROW;
+
+    auto issue_input = [&](int ck, int buf) {
+        const char *base = xs_n + (int64_t)ck * 4 * plane;
+        char *dst = lds_in + buf * CV_IN_BYTES + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < CV_IN_ROUNDS; ++r)
+            glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * 4096);
+    };
+    auto issue_weights = [&](int t, int buf) {
+        const char *src = wp_b + (int64_t)t * WROW + lane * 16;
+        char *dst = lds_w + buf * WB;
+#pragma unroll
+        for (int b0 = 0; b0 < 6 * MT; b0 += 4) {        // LDS block b = m*6 + kx*2 + hl
+            const int b = b0 + wave;
+            if (b < 6 * MT) glds16b(src + (int64_t)(b / 6) * a.CK * 3 * WROW + (b % 6) * 1024, dst + b * 1024);
+        }
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    const int nstage = a.CK * 3;
+    issue_input(0, 0);
+    issue_weights(0, 0);
+    const int jrow0 = 2 * wave;
+    for (int t = 0; t < nstage; ++t) {
+        const int ck = t / 3, ky = t - ck * 3;
+        __syncthreads();                       // stage t landed (vmcnt(0)); every wave is done with stage t-1
+        if (t + 1 < nstage) issue_weights(t + 1, (t + 1) & 1);
+        if (ky == 0 && ck + 1 < a.CK) issue_input(ck + 1, (ck + 1) & 1);
+        const char *inb = lds_in + (ck & 1) * CV_IN_BYTES + (kg * 2) * (CV_PIX * 16);
+        const char *wb = lds_w + (t & 1) * WB + lane * 16;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            h16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = (jrow0 + j + ky) * CV_HW + l32 + kx;
+                bh[j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
+                bl[j] = *reinterpret_cast<const h16x8 *>(inb + CV_PIX * 16 + p * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const h16x8 ah = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
+                const h16x8 al = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[m][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+    const int gx = x0 + l32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gy = y0 + jrow0 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                float v = acc[m][j][r] * inv;
+                if (a.bias) v += a.bias[co];
+                if (a.chan_add) v += a.chan_add[(int64_t)n * a.Cout + co];
+                const int64_t o = (((int64_t)n * a.Cout + co) * H + gy) * W + gx;
+                if (a.residual) v += a.residual[o];
+                a.y[o] = v;
+            }
+        }
+}
+
+// largest MT in {4, 2, 1} dividing Cout/32 whose grid still has >= 256 workgroups (else the smallest)
+static inline int cv_mt(int64_t Cout, int64_t tiles) {
+    if (Cout % 32 != 0) return 0;
+    const int64_t rows = Cout / 32;
+    for (int mt = 4; mt > 1; mt >>= 1)
+        if (rows % mt == 0 && tiles * (rows / mt) >= 256) return mt;
+    return 1;
+}
+
+}  // namespace mvip
+
+using namespace mvip;
+
+extern "C" int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W) {
+    return Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 16 == 0 && H > 0 && W > 0 && H % CV_TH == 0 && W % CV_TW == 0 &&
+           H * W <= (1 << 24);
+}
+
+extern "C" int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return Cout * Cin * 9 * 4 + 256;       // tail: {scale, 1/scale, absmax bits}, then a 16-byte zero page
+}
+
+// tail layout (byte offsets from Cout*Cin*36): 0 scale, 4 1/scale, 8 absmax bits, 128..143 zeros
+extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed,
+                                 void *stream) {
+    const int64_t co = transpose ? Cin : Cout, ci = transpose ? Cout : Cin;      // operator dims
+    if (!weight || !packed || co <= 0 || co % 32 != 0 || ci <= 0 || ci % 16 != 0) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    char *tail = (char *)packed + co * ci * 36;
+    if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
+    hipLaunchKernelGGL(cv_absmax_kernel, dim3(256), dim3(256), 0, st, weight, Cout * Cin * 9, (unsigned *)(tail + 8));
+    hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
+    const int64_t total = (co / 32) * (ci / 16) * 9 * 2 * 64;
+    hipLaunchKernelGGL(cv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, (int)co, (int)ci,
+                       transpose, (const float *)tail, (uint4 *)packed);
+    return check_launch();
+}
+
+extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *stream) {
+    if (n < 0 || !scale2 || (n > 0 && !x)) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(scale2, 0, 16, st) != hipSuccess) return check_launch();
+    if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(512), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
+    hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(scale2 + 2), scale2);
+    return check_launch();
+}
+
+extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
+                                 void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0) return MVIP_EINVAL;
+    if (N == 0 || HW == 0) return MVIP_OK;
+    if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
+    hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
+                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs);
+    return check_launch();
+}
+
+extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
+                                           const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu,
+                                           void *xs, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0) return MVIP_EINVAL;
+    if (N == 0 || HW == 0) return MVIP_OK;
+    if (!x || !xs || !mean || !rstd || N * (C / 16) > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
+    if (silu)
+        hipLaunchKernelGGL((cv_to_split_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs);
+    else
+        hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs);
+    return check_launch();
+}
+
+extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                  const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                                  int64_t H, int64_t W, float *y, void *stream) {
+    if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!xs || !packed || !y) return MVIP_EINVAL;
+    const int MT = cv_mt(Cout, N * (W / CV_TW) * (H / CV_TH));
+    ConvArgs a;
+    a.xs = (const char *)xs; a.wp = (const char *)packed;
+    const char *tail = (const char *)packed + Cout * Cin * 36;
+    a.w_scale2 = (const float *)tail; a.zero16 = tail + 128;
+    a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
+    a.N = (int)N; a.CK = (int)(Cin / 16); a.Cout = (int)Cout; a.H = (int)H; a.W = (int)W;
+    a.tilesX = (int)(W / CV_TW); a.tilesY = (int)(H / CV_TH); a.MB = (int)(Cout / (32 * MT));
+    const int64_t blocks = N * a.tilesX * a.tilesY * a.MB;
+    if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+    if (MT == 4)
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else if (MT == 2)
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    return check_launch();
+}

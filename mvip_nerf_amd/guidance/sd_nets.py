@@ -17,22 +17,49 @@ import torch.nn.functional as F
 
 
 # ---------------------------------------------------------------------------------------------- blocks
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm (same parameters and state-dict keys) whose device path is the HIP kernel pair of
+    csrc/group_norm.hip, optionally fused with the SiLU that follows it in every ResNet block.
+    Host tensors (only the CPU shape/name checks build these modules on the host) take torch's op."""
+
+    def forward(self, x, silu=False):
+        if x.is_cuda:
+            from .. import ops
+            return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+        y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.silu(y) if silu else y
+
+
+def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
+    """conv(silu(norm(x))) [+ chan_add[:, :, None, None]] [+ residual].  Device fp32 tensors whose shape the
+    split-precision MFMA convolution covers (csrc/conv3x3.hip: 3x3/s1/p1, Cout % 32 == 0, Cin % 16 == 0,
+    H % 8 == 0, W % 32 == 0) run statistics -> normalise+SiLU -> convolution (+ the additions) in four HIP
+    launches; every other shape takes the GroupNorm kernel pair followed by the library convolution."""
+    if x.is_cuda:
+        from .. import ops
+        if ops.conv3x3_supported(conv, x):
+            return ops.norm_act_conv3x3(x, norm, conv, True, chan_add, residual)
+    h = conv(norm(x, silu=True))
+    if chan_add is not None:
+        h = h + chan_add[:, :, None, None]
+    return h if residual is None else residual + h
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb=None, groups=32, eps=1e-5):
         super().__init__()
-        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.norm1 = GroupNorm(groups, cin, eps=eps)
         self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
         self.time_emb_proj = nn.Linear(temb, cout) if temb else None
-        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.norm2 = GroupNorm(groups, cout, eps=eps)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(F.silu(self.norm1(x)))
-        if self.time_emb_proj is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
-        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+        t = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+        h = norm_act_conv(self.norm1, self.conv1, x, chan_add=t)
+        return norm_act_conv(self.norm2, self.conv2, h,
+                             residual=x if self.conv_shortcut is None else self.conv_shortcut(x))
 
 
 class Attention(nn.Module):
@@ -89,7 +116,7 @@ class BasicTransformerBlock(nn.Module):
 class Transformer2DModel(nn.Module):
     def __init__(self, ch, heads, ctx_dim):
         super().__init__()
-        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.norm = GroupNorm(32, ch, eps=1e-6)
         self.proj_in = nn.Conv2d(ch, ch, 1)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, ctx_dim)])
         self.proj_out = nn.Conv2d(ch, ch, 1)
@@ -211,7 +238,7 @@ class UNet2DConditionModel(nn.Module):
             skips = [skip_ch.pop() for _ in range(3)]
             self.up_blocks.append(UpBlock(c, co, skips, temb, heads, ctx_dim, attn=i > 0, up=i < len(rev) - 1))
             c = co
-        self.conv_norm_out = nn.GroupNorm(32, block_out[0])
+        self.conv_norm_out = GroupNorm(32, block_out[0])
         self.conv_out = nn.Conv2d(block_out[0], out_channels, 3, padding=1)
         self._t_dim = block_out[0]
 
@@ -226,14 +253,14 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, encoder_hidden_states)
         for blk in self.up_blocks:
             x = blk(x, skips, temb, encoder_hidden_states)
-        return (self.conv_out(F.silu(self.conv_norm_out(x))),)
+        return (self.conv_out(self.conv_norm_out(x, silu=True)),)
 
 
 # ---------------------------------------------------------------------------------------------- VAE
 class VAEAttention(nn.Module):
     def __init__(self, ch):
         super().__init__()
-        self.group_norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.group_norm = GroupNorm(32, ch, eps=1e-6)
         self.to_q, self.to_k, self.to_v = nn.Linear(ch, ch), nn.Linear(ch, ch), nn.Linear(ch, ch)
         self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
 
@@ -267,7 +294,7 @@ class Encoder(nn.Module):
             self.down_blocks.append(blk)
             c = co
         self.mid_block = VAEMid(c)
-        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_norm_out = GroupNorm(32, c, eps=1e-6)
         self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
 
     def forward(self, x):
@@ -277,7 +304,7 @@ class Encoder(nn.Module):
                 x = r(x)
             if blk.downsamplers is not None:
                 x = blk.downsamplers[0](x)
-        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+        return self.conv_out(self.conv_norm_out(self.mid_block(x), silu=True))
 
 
 class Decoder(nn.Module):
@@ -294,7 +321,7 @@ class Decoder(nn.Module):
             blk.upsamplers = nn.ModuleList([Upsample2D(co)]) if i < len(rev) - 1 else None
             self.up_blocks.append(blk)
             c = co
-        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_norm_out = GroupNorm(32, c, eps=1e-6)
         self.conv_out = nn.Conv2d(c, 3, 3, padding=1)
 
     def forward(self, z):
@@ -304,7 +331,7 @@ class Decoder(nn.Module):
                 x = r(x)
             if blk.upsamplers is not None:
                 x = blk.upsamplers[0](x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(self.conv_norm_out(x, silu=True))
 
 
 class LatentDist:

@@ -415,3 +415,170 @@ class _NormalFit(torch.autograd.Function):
 def normal_fit(points, k=31):
     """points [3,H,W] planar -> least-squares plane normals [3,H,W] (DS_NeRF/run.py:1924-1940)."""
     return _NormalFit.apply(_f32c(points), int(k))
+
+
+# GroupNorm (+ SiLU) of the SDS networks -------------------------------------------------------------
+
+_GN_DTYPES = {torch.float32: 0, torch.float16: 1}
+
+
+def _gn_workspace(N, C, HW, device):
+    nbytes = int(_lib.load().mvip_groupnorm_workspace_bytes(N, C, HW))
+    return torch.empty(max(nbytes // 8, 1), device=device, dtype=torch.float64)
+
+
+class _GroupNorm(torch.autograd.Function):
+    """y = act(group_norm(x)) in two HIP launches (csrc/group_norm.hip); dx only: the SDS networks are
+    frozen, so a weight or bias that requires grad is an error, not a silent zero."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        if x.dtype not in _GN_DTYPES:
+            raise _lib.MvipError(f'group_norm: unsupported dtype {x.dtype}')
+        if (weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad):
+            raise NotImplementedError('group_norm: parameter gradients are not implemented (frozen networks only)')
+        dt = x.dtype
+        xc = x.contiguous()
+        N, C = xc.shape[0], xc.shape[1]
+        HW = xc.numel() // max(N * C, 1)
+        w = None if weight is None else weight.detach().to(dt).contiguous()
+        b = None if bias is None else bias.detach().to(dt).contiguous()
+        y = torch.empty_like(xc)
+        mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = _gn_workspace(N, C, HW, x.device)
+        call('mvip_groupnorm_forward', ptr(xc, dt), ptr(w, dt), ptr(b, dt), N, C, HW, int(groups), float(eps),
+             int(bool(silu)), _GN_DTYPES[dt], ptr(y, dt), ptr(mean), ptr(rstd), ptr(ws, torch.float64), stream())
+        ctx.save_for_backward(xc, w, b, mean, rstd)
+        ctx.cfg = (int(groups), int(bool(silu)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, b, mean, rstd = ctx.saved_tensors
+        groups, silu = ctx.cfg
+        dt = xc.dtype
+        dyc = dy.contiguous().to(dt)
+        N, C = xc.shape[0], xc.shape[1]
+        HW = xc.numel() // max(N * C, 1)
+        dx = torch.empty_like(xc)
+        ws = _gn_workspace(N, C, HW, xc.device)
+        call('mvip_groupnorm_backward', ptr(xc, dt), ptr(dyc, dt), ptr(w, dt), ptr(b, dt), ptr(mean), ptr(rstd), N, C,
+             HW, groups, silu, _GN_DTYPES[dt], ptr(dx, dt), ptr(ws, torch.float64), stream())
+        return dx, None, None, None, None, None
+
+
+def group_norm(x, weight, bias, groups, eps=1e-5, silu=False):
+    """act(F.group_norm(x, groups, weight, bias, eps)) for x [N, C, *]; act = SiLU when `silu`."""
+    return _GroupNorm.apply(x, weight, bias, groups, eps, silu)
+
+
+# 3x3 convolution of the SDS networks (split-precision implicit GEMM, csrc/conv3x3.hip) ---------------------
+
+def conv3x3_supported(conv, x):
+    """True when `conv` (an nn.Conv2d) applied to x [N, Cin, H, W] fp32 can run on the HIP kernel."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32):
+        return False
+    lib = _lib.load()
+    ok = bool(lib.mvip_conv3x3_supported(conv.out_channels, conv.in_channels, x.shape[2], x.shape[3]))
+    if ok and x.requires_grad and torch.is_grad_enabled():        # the data gradient runs the transposed operator
+        ok = bool(lib.mvip_conv3x3_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]))
+    return ok
+
+
+def conv3x3_pack(weight, transpose=False):
+    """Packed split-precision image of a [Cout, Cin, 3, 3] weight (transpose: the data-gradient operator)."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    nbytes = int(_lib.load().mvip_conv3x3_packed_bytes(Cout, Cin))
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    w = weight.detach().contiguous()
+    call('mvip_conv3x3_pack', ptr(w), Cout, Cin, int(bool(transpose)), ptr(packed, torch.uint8), stream())
+    return packed
+
+
+def _conv_packed(conv, transpose):
+    """Per-module cache of the packed images (the SDS networks are frozen; re-packed if the weight changes)."""
+    cache = conv.__dict__.setdefault('_mvip_packed', {})
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    if cache.get('key') != key:
+        cache.clear()
+        cache['key'] = key
+    if transpose not in cache:
+        cache[transpose] = conv3x3_pack(conv.weight, transpose)
+    return cache[transpose]
+
+
+def _split_buffer(N, C, HW, device):
+    return torch.empty(N * C * HW * 2, device=device, dtype=torch.float16)
+
+
+class _NormActConv3x3(torch.autograd.Function):
+    """conv3x3(act(group_norm(x))) + bias [+ chan_add[:, :, None, None]] [+ residual]: statistics, split-plane
+    writer (normalise + SiLU fused) and the MFMA convolution.  Backward: dY -> split planes (scaled by a power of
+    two from its absolute maximum) -> the same kernel with the transposed weight image -> GroupNorm backward.
+    Parameter gradients are not produced (frozen networks)."""
+
+    @staticmethod
+    def forward(ctx, x, chan_add, residual, norm, conv, silu):
+        for p in (norm.weight, norm.bias, conv.weight, conv.bias):
+            if p is not None and p.requires_grad:
+                raise NotImplementedError('conv3x3: parameter gradients are not implemented (frozen networks only)')
+        xc = x.contiguous()
+        N, C, H, W = xc.shape
+        HW, G, Cout = H * W, norm.num_groups, conv.out_channels
+        dev = xc.device
+        mean = torch.empty((N, G), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = _gn_workspace(N, C, HW, dev)
+        gw = None if norm.weight is None else norm.weight.detach().contiguous()
+        gb = None if norm.bias is None else norm.bias.detach().contiguous()
+        call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
+             ptr(ws, torch.float64), stream())
+        xs = _split_buffer(N, C, HW, dev)
+        call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
+             int(bool(silu)), ptr(xs, torch.float16), stream())
+        y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
+        bias = None if conv.bias is None else conv.bias.detach().contiguous()
+        ca = None if chan_add is None else chan_add.detach().contiguous()
+        rs = None if residual is None else residual.detach().contiguous()
+        call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(_conv_packed(conv, False), torch.uint8), ptr(bias),
+             ptr(ca), ptr(rs), ptr(None), N, C, Cout, H, W, ptr(y), stream())
+        ctx.save_for_backward(xc, gw, gb, mean, rstd)
+        ctx.mods = (norm, conv, bool(silu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gw, gb, mean, rstd = ctx.saved_tensors
+        norm, conv, silu = ctx.mods
+        N, C, H, W = xc.shape
+        HW, Cout, dev = H * W, conv.out_channels, xc.device
+        dyc = dy.contiguous().float()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not _lib.load().mvip_conv3x3_supported(C, Cout, H, W):
+                raise NotImplementedError(f'conv3x3 data gradient: unsupported shape Cin={C} Cout={Cout}')
+            scale2 = torch.empty(4, device=dev, dtype=torch.float32)
+            call('mvip_absmax_scale', ptr(dyc), dyc.numel(), ptr(scale2), stream())
+            dys = _split_buffer(N, Cout, HW, dev)
+            call('mvip_split_planes', ptr(dyc), N, Cout, HW, ptr(scale2), ptr(dys, torch.float16), stream())
+            dact = torch.empty_like(xc)
+            call('mvip_conv3x3_f16x3', ptr(dys, torch.float16), ptr(_conv_packed(conv, True), torch.uint8), ptr(None),
+                 ptr(None), ptr(None), ptr(scale2), N, Cout, C, H, W, ptr(dact), stream())
+            del dys
+            dx = torch.empty_like(xc)
+            ws = _gn_workspace(N, C, HW, dev)
+            call('mvip_groupnorm_backward', ptr(xc), ptr(dact), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW,
+                 norm.num_groups, int(silu), 0, ptr(dx), ptr(ws, torch.float64), stream())
+        d_ca = dyc.sum((2, 3)) if ctx.needs_input_grad[1] else None
+        d_rs = dyc if ctx.needs_input_grad[2] else None
+        return dx, d_ca, d_rs, None, None, None
+
+
+def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None):
+    """conv(act(norm(x))) [+ chan_add[:, :, None, None]] [+ residual] on the HIP kernels; the caller checks
+    conv3x3_supported first."""
+    return _NormActConv3x3.apply(x, chan_add, residual, norm, conv, silu)

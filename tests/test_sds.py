@@ -166,3 +166,116 @@ def test_graphed_step_equals_eager(golden, cuda):
     for a, b in zip(outs[False], outs[True]):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * np.abs(a).max())
     assert not np.allclose(outs[True][0], outs[True][2])       # the timestep really changed between replays
+
+
+# GroupNorm (+SiLU) of the SDS networks: HIP kernel pair vs the fp64 statement of the same op on the host.
+# Tolerance: fp32 5e-6 relative to the output scale (statistics are fp64 in the kernel); fp16 storage 2e-3.
+@pytest.mark.parametrize('shape,groups', [((2, 320, 64, 64), 32), ((1, 128, 96, 96), 32), ((2, 64, 7, 9), 32),
+                                           ((1, 64, 3, 5), 32), ((1, 128, 512, 512), 32), ((2, 2560, 8, 8), 32),
+                                           ((3, 12, 5), 4)])
+@pytest.mark.parametrize('silu', [False, True])
+def test_group_norm_forward_backward(cuda, shape, groups, silu):
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(sum(shape) + int(silu))
+    C = shape[1]
+    x = (torch.randn(shape, generator=gen) * 1.7 + 0.9)
+    w = torch.randn(C, generator=gen) * 0.5 + 1.0
+    b = torch.randn(C, generator=gen) * 0.3
+    dy = torch.randn(shape, generator=gen)
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr, groups, w.double(), b.double(), 1e-6)
+    if silu:
+        yr = torch.nn.functional.silu(yr)
+    yr.backward(dy.double())
+    xd = x.to(cuda).requires_grad_(True)
+    y = ops.group_norm(xd, w.to(cuda), b.to(cuda), groups, 1e-6, silu)
+    y.backward(dy.to(cuda))
+    ys, gs = float(yr.abs().max()), float(xr.grad.abs().max())
+    np.testing.assert_allclose(N(y), yr.detach().float().numpy(), rtol=0, atol=5e-6 * max(ys, 1.0))
+    np.testing.assert_allclose(N(xd.grad), xr.grad.float().numpy(), rtol=0, atol=5e-6 * max(gs, 1e-3))
+
+
+def test_group_norm_fp16_and_errors(cuda):
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 32, 32, generator=gen)
+    w, b = torch.randn(64, generator=gen), torch.randn(64, generator=gen)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(x.half().double(), 32, w.half().double(),
+                                                                  b.half().double(), 1e-5))
+    xh = x.half().to(cuda).requires_grad_(True)
+    y = ops.group_norm(xh, w.half().to(cuda), b.half().to(cuda), 32, 1e-5, True)
+    assert y.dtype == torch.float16
+    np.testing.assert_allclose(N(y.float()), ref.float().numpy(), rtol=2e-3, atol=2e-3)
+    y.float().sum().backward()
+    assert xh.grad.dtype == torch.float16 and torch.isfinite(xh.grad).all()
+    # same values as the modules of sd_nets produce through torch on the host
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm
+    m = GroupNorm(32, 64, eps=1e-5)
+    with torch.no_grad():
+        m.weight.copy_(w); m.bias.copy_(b)
+    m.requires_grad_(False)
+    host = m(x, silu=True)
+    dev = m.to(cuda)(x.to(cuda), silu=True)
+    np.testing.assert_allclose(N(dev), host.detach().numpy(), rtol=0, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        ops.group_norm(x.to(cuda), w.to(cuda).requires_grad_(True), b.to(cuda), 32, 1e-5, False)
+    with pytest.raises(Exception):
+        ops.group_norm(x.to(cuda), w.to(cuda), b.to(cuda), 7, 1e-5, False)       # C % G != 0
+
+
+# GroupNorm + SiLU + 3x3 convolution (+ channel addend + residual) on the split-precision MFMA kernel vs the
+# same expression in fp64 on the host.  Tolerance 1e-5 of the output / gradient scale (fp16 hi+lo operands,
+# three products, fp32 accumulation: ~1e-6 relative).
+@pytest.mark.parametrize('N_,cin,cout,H,W,grad', [(1, 32, 64, 8, 32, False), (2, 128, 128, 16, 64, True),
+                                                  (1, 64, 128, 24, 96, True), (1, 128, 256, 8, 32, True),
+                                                  (1, 16, 64, 8, 32, False)])
+def test_norm_act_conv3x3(cuda, N_, cin, cout, H, W, grad):
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm, norm_act_conv
+    gen = torch.Generator().manual_seed(cin + cout + H)
+    G = 8 if cin < 32 else 32
+    norm = GroupNorm(G, cin, eps=1e-6)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(cin, generator=gen) * 0.4 + 1.0)
+        norm.bias.copy_(torch.randn(cin, generator=gen) * 0.3)
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (9 * cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    for p in list(norm.parameters()) + list(conv.parameters()):
+        p.requires_grad_(False)
+    x = torch.randn(N_, cin, H, W, generator=gen) * 1.3 + 0.2
+    ca = torch.randn(N_, cout, generator=gen)
+    rs = torch.randn(N_, cout, H, W, generator=gen)
+    dy = torch.randn(N_, cout, H, W, generator=gen) * 1e-5          # gradients are tiny in the SDS step
+    # fp64 statement on the host
+    xr, car, rsr = (t.double().requires_grad_(grad) for t in (x, ca, rs))
+    h = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, G, norm.weight.double(), norm.bias.double(), 1e-6))
+    yr = torch.nn.functional.conv2d(h, conv.weight.double(), conv.bias.double(), padding=1) + car[:, :, None, None] + rsr
+    # device
+    norm_d, conv_d = norm.to(cuda), conv.to(cuda)
+    xd, cad, rsd = (t.to(cuda).requires_grad_(grad) for t in (x, ca, rs))
+    assert ops.conv3x3_supported(conv_d, xd)
+    y = norm_act_conv(norm_d, conv_d, xd, chan_add=cad, residual=rsd)
+    ys = float(yr.abs().max())
+    np.testing.assert_allclose(N(y), yr.detach().float().numpy(), rtol=0, atol=1e-5 * ys)
+    if grad:
+        yr.backward(dy.double())
+        y.backward(dy.to(cuda))
+        for got, ref in ((xd.grad, xr.grad), (cad.grad, car.grad), (rsd.grad, rsr.grad)):
+            np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_resnet_block_fused_equals_library_path(cuda):
+    """The SD ResNet block through the fused HIP path equals the same block through GroupNorm kernels + the
+    library convolution (shape the MFMA kernel does not cover is forced by making the width 48)."""
+    from mvip_nerf_amd.guidance.sd_nets import ResnetBlock2D
+    torch.manual_seed(3)
+    blk = ResnetBlock2D(128, 256, temb=64).to(cuda)
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(1, 128, 16, 64, device=cuda)
+    temb = torch.randn(1, 64, device=cuda)
+    fused = blk(x, temb)
+    x48 = torch.nn.functional.pad(x, (0, 0, 0, 0))          # same data; library path via the CPU module
+    ref = blk.to('cpu').double()(x48.cpu().double(), temb.cpu().double())
+    np.testing.assert_allclose(N(fused), ref.float().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))

@@ -1,4 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.sds_bench import run
 print(run(False, steps=3))
