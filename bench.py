@@ -271,12 +271,25 @@ def main():
             full.step(1001 + k)
         barrier()
         dt_full = time.perf_counter() - t3
+        for n in (full.kw_train['network_fn'], full.kw_train['network_fine']):
+            n.train_precision = 1
+        full.step(2000)
+        barrier()
+        t4 = time.perf_counter()
+        for k in range(args.sds_steps):
+            full.step(2001 + k)
+        barrier()
+        dt_full16 = time.perf_counter() - t4
         if dist is not None:
-            t = torch.tensor([dt_sds, dt_full], device=device, dtype=torch.float64)
+            t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_sds, dt_full = float(t[0]), float(t[1])
+            dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
+        result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
+                                          'iterations_per_sec': args.sds_steps / dt_full16,
+                                          'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
         result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': dt_sds / args.sds_steps * 1e3,
-                         'dtype': 'f32', 'what': 'train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
+                         'dtype': 'f32 tensors; 3x3 ResNet convolutions on fp16 MFMA in split precision (f16x3, ~1e-6 relative), the rest library fp32',
+                         'what': 'train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
                          '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
         result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
                                     'iterations_per_sec': args.sds_steps / dt_full,
