@@ -284,6 +284,33 @@ def main():
             t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
+        # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
+        # collaborative SDS over <=5 neighbour views); NeRF kernels at train_precision=1
+        for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
+            a2 = make_args()
+            a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
+            opt.is_normal_guidance, opt.is_colla_guidance, opt.normal_start = True, colla, 500
+            opt.text_normal = 'a normal map of a stone bench in a park'
+            tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
+                                     rank=rank, dist=dist)
+            for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
+                n.train_precision = 1
+            tr2.step(1000)
+            barrier()
+            t5 = time.perf_counter()
+            rays = 0
+            for k in range(nsteps):
+                rays += tr2.step(1001 + k)[1]
+            barrier()
+            dt5 = time.perf_counter() - t5
+            if dist is not None:
+                t = torch.tensor([dt5], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt5 = float(t.item())
+            result[name] = {'ms_per_step': dt5 / nsteps * 1e3, 'rays_with_grad_per_step_per_gpu': rays // nsteps,
+                            'sds_evaluations_per_step': 2 + (5 if colla else 0)}
+            del tr2
+        opt.is_normal_guidance = opt.is_colla_guidance = False
         result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
                                           'iterations_per_sec': args.sds_steps / dt_full16,
                                           'what': 'the same iteration with train_precision=1 for the NeRF kernels'}

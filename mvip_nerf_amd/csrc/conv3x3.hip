@@ -53,11 +53,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
 }
 
 // ---- power-of-two scale from the absolute maximum ----------------------------------------------------
-__global__ void cv_absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
+__global__ void __launch_bounds__(256) cv_absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(x[i]);
-        m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m;
+    auto take = [&](float v) { v = fabsf(v); m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m; };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) take(x[i]);
+    } else {
+        for (int64_t i = tid; i < n; i += stride) take(x[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -332,7 +339,7 @@ extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void 
     if (n < 0 || !scale2 || (n > 0 && !x)) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(scale2, 0, 16, st) != hipSuccess) return check_launch();
-    if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(512), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
+    if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(2048), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(scale2 + 2), scale2);
     return check_launch();
 }

@@ -78,12 +78,48 @@ class SecondStageTrainer:
     def _shard(self, idx):
         return shard(idx, self.rank, self.world)
 
-    def _render_pixels(self, pose, sel, **kw):
+    def _render_pixels(self, pose, sel, hwf=None, **kw):
         sc = self.scene
-        rows = ops.ray_rows_from_pose(pose, sc.H, sc.W, sc.focal, sc.near, sc.far, sel=sel)
+        H, W, focal = hwf if hwf is not None else (sc.H, sc.W, sc.focal)
+        rows = ops.ray_rows_from_pose(pose, H, W, focal, sc.near, sc.far, sel=sel)
         ret = run.batchify_rays(rows, self.args.chunk, **{k: v for k, v in kw.items()
                                                            if k not in ('ndc', 'use_viewdirs')})
         return ret
+
+    def _render_frame(self, pose, hwf, key, **kw):
+        """One full frame at (H, W, focal) = hwf, rays sharded over the ranks; returns the assembled
+        [H*W, ...] map `key` (the local shard keeps its autograd history) and the local ray count."""
+        H, W, _ = hwf
+        idx = torch.arange(H * W, device=self.device)
+        sel = self._shard(idx)
+        ret = self._render_pixels(pose, sel, hwf=hwf, **kw)
+        return all_gather_ragged(ret[key], H * W, self.rank, self.world, self.dist), sel.numel()
+
+    def _normal_map(self, pose):
+        """run.py:948-965: reduced-resolution depth (train kwargs, with grad) -> back-projection -> 31x31
+        plane-fit normals -> (n + 1) / 2, [1, 3, H_r, W_r]."""
+        sc, f = self.scene, self.args.normalmap_render_factor
+        H_r, W_r, focal_r = sc.H // f, sc.W // f, sc.focal / f
+        depth, n = self._render_frame(pose, (H_r, W_r, focal_r), 'depth_map', retraw=True, **self.kw_train)
+        K = torch.tensor([[focal_r, 0, W_r / 2], [0, focal_r, H_r / 2], [0, 0, 1]], dtype=torch.float32)
+        points = run.depth2xyz_torch(depth.reshape(H_r, W_r), K)
+        points = points.unsqueeze(0).transpose(2, 3).transpose(1, 2)
+        return (run.depth2normal_geo(points) + 1) / 2, n
+
+    def _colla_views(self, i):
+        """run.py:968-974 / render_path_4view (:1365-1401): the <=5 neighbour views [it-4 : it+5 : 2] of
+        it = i % 60 at the reduced resolution, TEST kwargs, with grad; masks stay at full resolution."""
+        sc, f = self.scene, self.args.normalmap_render_factor
+        hwf = (sc.H // f, sc.W // f, sc.focal / f)
+        it = i % 60
+        lo, hi = max(0, it - 4), min(len(sc.poses), it + 5)
+        rgbs, n = [], 0
+        for k in range(lo, hi, 2):
+            rgb, m = self._render_frame(sc.poses[k], hwf, 'rgb_map', retraw=True, need_alpha=True, **self.kw_test)
+            rgbs.append(rgb.reshape(hwf[0], hwf[1], 3))
+            n += m
+        masks = sc.masks[lo:min(len(sc.masks), it + 5):2]
+        return torch.stack(rgbs, 0).permute(0, 3, 1, 2), masks.float().unsqueeze(1), n
 
     def _allreduce_grads(self):
         self.bucket.all_reduce(self.dist, self.world)      # ONE 4.77 MB bucket over RCCL/xGMI
@@ -107,10 +143,17 @@ class SecondStageTrainer:
             combin = combin.index_put((sc.masked_idx,), rgb_all).reshape(sc.H, sc.W, 3)
             combin_rgb = combin.permute(2, 0, 1).unsqueeze(0)
             mask = sc.masks[img_i].float().reshape(1, 1, sc.H, sc.W)
+            normal_map = rgbs4 = mask4 = None
+            if getattr(args, 'is_normal_guidance', False):      # run.py:948 (colla without normal is a NameError
+                normal_map, n = self._normal_map(pose)          # in the reference, run.py:1003; here it passes None)
+                rays_rendered += n
+            if getattr(args, 'is_colla_guidance', False):
+                rgbs4, mask4, n = self._colla_views(i)
+                rays_rendered += n
             if self.world > 1:                         # replicated SDS term: identical noise on every rank
                 for sd in self.guidance.guidance.values():
                     sd.generator = torch.Generator(device=self.device).manual_seed(777 + i)
-            loss_sds = self.guidance.cal_loss(i, None, None, None, combin_rgb, None, mask, None, 1)
+            loss_sds = self.guidance.cal_loss(i, rgbs4, normal_map, None, combin_rgb, None, mask, mask4, 1)
 
         # 3. supervision batches: unmasked colour rays and inpainted-depth rays
         g = torch.Generator(device=self.device).manual_seed(10007 * (i + 1))

@@ -22,8 +22,9 @@ def _free_port():
     return p
 
 
-def _args():
+def _args(full=False):
     return types.SimpleNamespace(
+        is_normal_guidance=full, is_colla_guidance=full, normalmap_render_factor=2,
         multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=64, alpha_model_path=None,
         netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=3e-3, basedir='/tmp/x',
         expname='none', ft_path=None, no_reload=True, perturb=0., N_samples=64, white_bkgd=True, raw_noise_std=0.,
@@ -41,10 +42,17 @@ class _ImagePrior:
         yy = torch.linspace(0, 1, H, device=combin_rgb.device)[:, None]
         xx = torch.linspace(0, 1, W, device=combin_rgb.device)[None, :]
         wgt = (1 + yy + 2 * xx)[None, None]
-        return ((combin_rgb * wgt) ** 2).sum() * 1e-2
+        loss = ((combin_rgb * wgt) ** 2).sum() * 1e-2
+        if b is not None:                              # normal map [1,3,H_r,W_r] (configs[2])
+            loss = loss + (b * torch.flip(b, [2]).detach() * 3.0).sum() * 1e-2
+        if a is not None:                              # neighbour views [V,3,H_r,W_r] + masks [V,1,H,W] (configs[3])
+            assert e.shape == (a.shape[0], 1, H, W)
+            k = torch.arange(1, a.shape[0] + 1, device=a.device, dtype=a.dtype)[:, None, None, None]
+            loss = loss + ((a * k) ** 2).sum() * 1e-2
+        return loss
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, full=False):
     from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
     from oracle.weights import seeded_state_dict
     dev = torch.device('cuda', 0)
@@ -55,7 +63,7 @@ def _run(rank, world, port, out):
         d = dist
     try:
         scene = SyntheticScene(H=20, W=28, focal=383.65 * 28 / 504, mask_hw=(7, 9), n_views=8, device=dev)
-        tr = SecondStageTrainer(_args(), scene, dev, guidance=_ImagePrior(), world=world, rank=rank, dist=d)
+        tr = SecondStageTrainer(_args(full), scene, dev, guidance=_ImagePrior(), world=world, rank=rank, dist=d)
         for net, seed in ((tr.kw_train['network_fn'], 61), (tr.kw_train['network_fine'], 62)):
             net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
         tr.optimizer.step = lambda: None
@@ -74,5 +82,19 @@ def test_two_rank_trainer_equals_single(tmp_path, cuda):
     assert a['rays'] + b['rays'] == ref['rays'] == 63 + 32 + 32
     for ga, gb, gr in zip(a['grads'], b['grads'], ref['grads']):
         assert torch.equal(ga, gb)                                   # identical after the all-reduce
+        tol = 2e-3 * float(gr.abs().max()) + 1e-12
+        np.testing.assert_allclose(ga.numpy(), gr.numpy(), rtol=2e-3, atol=tol)
+
+
+def test_two_rank_trainer_full_guidance(tmp_path, cuda):
+    """configs[2]/[3] branches of the iteration: reduced-resolution depth -> normal map, and the <=5 neighbour
+    views, both ray-sharded and re-assembled by all_gather, must give the single-process gradients."""
+    _run(0, 1, 0, str(tmp_path), True)
+    mp.spawn(_run, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    ref = torch.load(os.path.join(str(tmp_path), 'w1r0.pt'))
+    a, b = (torch.load(os.path.join(str(tmp_path), f'w2r{r}.pt')) for r in (0, 1))
+    assert a['rays'] + b['rays'] == ref['rays'] == 63 + 32 + 32 + 140 + 4 * 140
+    for ga, gb, gr in zip(a['grads'], b['grads'], ref['grads']):
+        assert torch.equal(ga, gb)
         tol = 2e-3 * float(gr.abs().max()) + 1e-12
         np.testing.assert_allclose(ga.numpy(), gr.numpy(), rtol=2e-3, atol=tol)
