@@ -255,6 +255,20 @@ int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, co
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * encodings of the reference's second model NeRF_TCNN
+ * (DS_NeRF/run_nerf_helpers_tcnn.py:36-46 hash grid, :63-69 spherical harmonics, :91-101 forward), which
+ * the reference takes from tiny-cuda-nn (absent from the reference tree; published algorithm restated).
+ * x [P,3] raw coordinates, mapped to [0,1] by (x + bound)/(2 bound) when bound > 0; table [n_entries,2];
+ * levels [16][4] 32-bit words {scale (fp32 bits), resolution, offset, size} in DEVICE memory;
+ * features / d_features [32][P] level-major (row 2l+f = feature f of level l); d_table is accumulated
+ * into (zero it first).  mvip_sh4: dirs [P,3] in [-1,1] -> out [16][P]. */
+int mvip_hashgrid_forward(const float *x, const float *table, const void *levels, int64_t P, float bound,
+                          float *features, void *stream);
+int mvip_hashgrid_backward(const float *x, const float *d_features, const void *levels, int64_t P, float bound,
+                           float *d_table, void *stream);
+int mvip_sh4(const float *dirs, int64_t P, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -582,3 +582,45 @@ def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None):
     """conv(act(norm(x))) [+ chan_add[:, :, None, None]] [+ residual] on the HIP kernels; the caller checks
     conv3x3_supported first."""
     return _NormActConv3x3.apply(x, chan_add, residual, norm, conv, silu)
+
+
+# Hash-grid model (NeRF_TCNN) -----------------------------------------------------------------------------
+
+class _HashGrid(torch.autograd.Function):
+    """Multiresolution hash-grid features [32, P] (level-major) of points x [P, 3]; gradient w.r.t. the table
+    by fp32 atomics (positions never need a gradient on this path)."""
+
+    @staticmethod
+    def forward(ctx, x, table, levels, bound):
+        xc = _f32c(x.detach())
+        tc = table.detach().contiguous()
+        P = xc.shape[0]
+        out = torch.empty((32, P), device=xc.device, dtype=torch.float32)
+        call('mvip_hashgrid_forward', ptr(xc), ptr(tc), ptr(levels, torch.int32), P, float(bound), ptr(out), stream())
+        ctx.save_for_backward(xc, levels)
+        ctx.meta = (float(bound), tc.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, levels = ctx.saved_tensors
+        bound, n = ctx.meta
+        d = dout.contiguous().float()
+        dtable = torch.zeros(n, device=xc.device, dtype=torch.float32)
+        call('mvip_hashgrid_backward', ptr(xc), ptr(d), ptr(levels, torch.int32), xc.shape[0], bound, ptr(dtable),
+             stream())
+        return None, dtable, None, None
+
+
+def hashgrid_encode(x, table, levels, bound=0.0):
+    """x [P,3] (raw coordinates in [-bound, bound], or already in [0,1] when bound == 0), table flat
+    [n_entries*2], levels [16,4] int32 -> [32, P]."""
+    return _HashGrid.apply(x, table, levels, bound)
+
+
+def sh4(dirs):
+    """Degree-4 spherical harmonics [16, P] of unit directions [P, 3] (NeRF_TCNN's input convention)."""
+    dc = _f32c(dirs.detach())
+    out = torch.empty((16, dc.shape[0]), device=dc.device, dtype=torch.float32)
+    call('mvip_sh4', ptr(dc), dc.shape[0], ptr(out), stream())
+    return out

@@ -365,6 +365,58 @@ def create_nerf(args, device=None):
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
 
 
+def create_nerf_tcnn(args, device=None):
+    """DS_NeRF/run.py:1602-1700: the hash-grid model (`no_tcnn = False`, the shipped config's choice).
+    Identity embedders, one NeRF_TCNN per level of the hierarchy, Adam over all parameters; same return
+    tuple and checkpoint keys as create_nerf."""
+    from .run_nerf_helpers_tcnn import NeRF_TCNN
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    if getattr(args, 'alpha_model_path', None) is not None:
+        raise NotImplementedError('alpha_model_path is outside the hot-path scope')
+    embed_fn = lambda inp: inp
+    embeddirs_fn = (lambda inp: inp) if args.use_viewdirs else None
+    model = NeRF_TCNN(encoding="hashgrid", seed=0).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF_TCNN(encoding="hashgrid", seed=1).to(device)
+        grad_vars += list(model_fine.parameters())
+
+    def network_query_fn(inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           netchunk=args.netchunk)
+
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    if getattr(args, 'ft_path', None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f] if os.path.isdir(d) else []
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt = torch.load(ckpts[-1], map_location=device)
+        start = ckpt['global_step']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(_strip_module_prefix(ckpt['network_fn_state_dict']))
+        if model_fine is not None:
+            model_fine.load_state_dict(_strip_module_prefix(ckpt['network_fine_state_dict']))
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    else:
+        render_kwargs_train['ndc'] = True
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
 def depth2xyz_torch(depth_map, depth_cam_matrix, depth_scale=1.0):
     """DS_NeRF/run.py:1909-1922: tensor(h,w), 3x3 intrinsics -> tensor(h,w,3)."""
     K = depth_cam_matrix

@@ -114,10 +114,16 @@ class SecondStageTrainer:
         it = i % 60
         lo, hi = max(0, it - 4), min(len(sc.poses), it + 5)
         rgbs, n = [], 0
-        for k in range(lo, hi, 2):
-            rgb, m = self._render_frame(sc.poses[k], hwf, 'rgb_map', retraw=True, need_alpha=True, **self.kw_test)
+        views = list(range(lo, hi, 2))
+        for k in views:
+            # train_step_colla_sds overwrites its loss on every view (sd_utils.py:575-597): only the LAST view's
+            # graph ever receives a gradient, the earlier views enter as constants.  Rendering them without
+            # autograd changes no value and no gradient and skips their activation stash and backward.
+            with torch.set_grad_enabled(k == views[-1]):
+                rgb, m = self._render_frame(sc.poses[k], hwf, 'rgb_map', retraw=True, need_alpha=True,
+                                            **self.kw_test)
             rgbs.append(rgb.reshape(hwf[0], hwf[1], 3))
-            n += m
+            n += m if k == views[-1] else 0
         masks = sc.masks[lo:min(len(sc.masks), it + 5):2]
         return torch.stack(rgbs, 0).permute(0, 3, 1, 2), masks.float().unsqueeze(1), n
 

@@ -45,10 +45,11 @@ class _ImagePrior:
         loss = ((combin_rgb * wgt) ** 2).sum() * 1e-2
         if b is not None:                              # normal map [1,3,H_r,W_r] (configs[2])
             loss = loss + (b * torch.flip(b, [2]).detach() * 3.0).sum() * 1e-2
-        if a is not None:                              # neighbour views [V,3,H_r,W_r] + masks [V,1,H,W] (configs[3])
+        if a is not None:                              # neighbour views [V,3,H_r,W_r] + masks [V,1,H,W] (configs[3]); as in
+            # train_step_colla_sds only the last view carries gradient, the others enter as constants
             assert e.shape == (a.shape[0], 1, H, W)
             k = torch.arange(1, a.shape[0] + 1, device=a.device, dtype=a.dtype)[:, None, None, None]
-            loss = loss + ((a * k) ** 2).sum() * 1e-2
+            loss = loss + ((a[-1:] * k[-1:]) ** 2).sum() * 1e-2 + (a[:-1].detach() * a[-1:]).sum() * 1e-2
         return loss
 
 
@@ -93,7 +94,7 @@ def test_two_rank_trainer_full_guidance(tmp_path, cuda):
     mp.spawn(_run, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
     ref = torch.load(os.path.join(str(tmp_path), 'w1r0.pt'))
     a, b = (torch.load(os.path.join(str(tmp_path), f'w2r{r}.pt')) for r in (0, 1))
-    assert a['rays'] + b['rays'] == ref['rays'] == 63 + 32 + 32 + 140 + 4 * 140
+    assert a['rays'] + b['rays'] == ref['rays'] == 63 + 32 + 32 + 140 + 140        # rays rendered WITH grad
     for ga, gb, gr in zip(a['grads'], b['grads'], ref['grads']):
         assert torch.equal(ga, gb)
         tol = 2e-3 * float(gr.abs().max()) + 1e-12
