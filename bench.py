@@ -104,6 +104,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--train-steps', type=int, default=3, help='second-stage iterations timed after the render leg')
     ap.add_argument('--sds-steps', type=int, default=3, help='SDS / full-iteration steps timed in the third leg')
+    ap.add_argument('--no-hashgrid', dest='hashgrid', action='store_false')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -166,6 +167,44 @@ def main():
                    'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
                    'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
     }
+    # ---- extra leg: the reference's second model (hash grid + tiny MLPs, the shipped config's `no_tcnn = False`),
+    # same frames / same training iteration; SURVEY.md 8(f) row 4
+    if args.hashgrid:
+        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+        a_h = make_args()
+        a_h.no_tcnn, a_h.netchunk, a_h.lrate = False, 1 << 20, 1e-2
+        scene_h = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+        tr_h = SecondStageTrainer(a_h, scene_h, device, guidance=None, world=world, rank=rank, dist=dist)
+
+        def render_h(k):
+            with torch.no_grad():
+                return run.render(H, W, FOCAL, chunk=1 << 15, c2w=orbit_pose(rank * 7 + k, device), near=NEAR, far=FAR,
+                                  **tr_h.kw_test)
+        render_h(0)
+        barrier()
+        th = time.perf_counter()
+        for k in range(args.steps):
+            render_h(k + 1)
+        barrier()
+        dt_h = time.perf_counter() - th
+        tr_h.step(0)
+        barrier()
+        th = time.perf_counter()
+        for k in range(args.train_steps):
+            tr_h.step(1 + k)
+        barrier()
+        dt_ht = time.perf_counter() - th
+        if dist is not None:
+            t = torch.tensor([dt_h, dt_ht], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_h, dt_ht = float(t[0]), float(t[1])
+        result['hashgrid_model'] = {
+            'render_rays_per_sec': H * W * world * args.steps / dt_h, 'render_ms_per_frame': dt_h / args.steps * 1e3,
+            'train_ms_per_step': dt_ht / max(args.train_steps, 1) * 1e3,
+            'what': 'NeRF_TCNN (16-level hash grid + 64-wide MLPs, coarse+fine), same frames and same training '
+                    'iteration as the 8x256 legs; parity unpinned (tiny-cuda-nn absent)'}
+        del tr_h
+
     # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on
     #      hi/lo splits of both operands, fp32 accumulate).  Reported separately; `value` stays exact fp32. ----
     with torch.no_grad():

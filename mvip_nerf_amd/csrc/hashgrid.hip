@@ -13,7 +13,8 @@
 // distinct 64-byte sector per corner).  One thread per (point, level), blockIdx.y = level so a workgroup
 // stays inside one level's table (the three coarse levels are dense and L2-resident); features are written
 // level-major [32][P] so that both this kernel's stores and the following 32->64 GEMM read whole rows.
-// Backward = the same walk with fire-and-forget fp32 atomics into the table gradient.
+// Backward = the same walk; contributions to the same entry are first summed per workgroup tile in an LDS
+// hash map, then added with fire-and-forget fp32 atomics.
 #include "common.h"
 
 namespace mvip {
@@ -77,27 +78,67 @@ hg_forward_kernel(const float *__restrict__ x, const float2 *__restrict__ table,
     out[(int64_t)(2 * level + 1) * P + p] = f1;
 }
 
+// Table-gradient accumulation.  Scene coordinates occupy a small part of the [-bound, bound] box, so on the
+// coarse and middle levels thousands of samples hit the same few entries and plain global atomics serialise
+// (measured: 547 ms for 8.4 M points).  Each workgroup therefore walks a tile of HG_TILE points of ONE level and
+// first sums contributions per entry in an LDS hash map (open addressing, 4 probes, ds_add_f32); at the end of
+// the tile every occupied slot is flushed with one pair of global atomics.  Contributions that find no slot
+// (fine levels: nearly every entry distinct) go to global memory directly.
+constexpr int HG_TILE = 4096;
+constexpr int HG_SLOTS = 2048;
+constexpr uint32_t HG_EMPTY = 0xFFFFFFFFu;
+
 __global__ void __launch_bounds__(256)
 hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, const HgLevel *__restrict__ levels,
                    int64_t P, float bound, float *__restrict__ dtable) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+    __shared__ uint32_t keys[HG_SLOTS];
+    __shared__ float acc0[HG_SLOTS], acc1[HG_SLOTS];
+    for (int s = threadIdx.x; s < HG_SLOTS; s += 256) { keys[s] = HG_EMPTY; acc0[s] = 0.f; acc1[s] = 0.f; }
+    __syncthreads();
     const int level = blockIdx.y;
     const HgLevel L = levels[level];
-    const float g0 = dout[(int64_t)(2 * level) * P + p], g1 = dout[(int64_t)(2 * level + 1) * P + p];
-    if (g0 == 0.f && g1 == 0.f) return;
-    uint32_t c[3];
-    float w[3];
-    hg_cell(x, p, bound, L.scale, c, w);
     float *tab = dtable + 2 * (int64_t)L.offset;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t cx = c[0] + (k & 1), cy = c[1] + ((k >> 1) & 1), cz = c[2] + ((k >> 2) & 1);
-        const float wk = ((k & 1) ? w[0] : 1.f - w[0]) * (((k >> 1) & 1) ? w[1] : 1.f - w[1]) *
-                         (((k >> 2) & 1) ? w[2] : 1.f - w[2]);
-        const uint32_t idx = hg_index(cx, cy, cz, L.resolution, L.size);
-        unsafeAtomicAdd(tab + 2 * (int64_t)idx, wk * g0);
-        unsafeAtomicAdd(tab + 2 * (int64_t)idx + 1, wk * g1);
+    const int64_t p0 = (int64_t)blockIdx.x * HG_TILE;
+#pragma unroll 1
+    for (int it = 0; it < HG_TILE / 256; ++it) {
+        const int64_t p = p0 + it * 256 + threadIdx.x;
+        if (p >= P) break;
+        const float g0 = dout[(int64_t)(2 * level) * P + p], g1 = dout[(int64_t)(2 * level + 1) * P + p];
+        if (g0 == 0.f && g1 == 0.f) continue;
+        uint32_t c[3];
+        float w[3];
+        hg_cell(x, p, bound, L.scale, c, w);
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t cx = c[0] + (k & 1), cy = c[1] + ((k >> 1) & 1), cz = c[2] + ((k >> 2) & 1);
+            const float wk = ((k & 1) ? w[0] : 1.f - w[0]) * (((k >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                             (((k >> 2) & 1) ? w[2] : 1.f - w[2]);
+            const uint32_t idx = hg_index(cx, cy, cz, L.resolution, L.size);
+            uint32_t slot = (idx * 2654435761u) >> 21;                  // 11 bits
+            bool done = false;
+#pragma unroll 1
+            for (int probe = 0; probe < 4 && !done; ++probe) {
+                const uint32_t prev = atomicCAS(&keys[slot], HG_EMPTY, idx);
+                if (prev == HG_EMPTY || prev == idx) {
+                    atomicAdd(&acc0[slot], wk * g0);
+                    atomicAdd(&acc1[slot], wk * g1);
+                    done = true;
+                }
+                slot = (slot + 1) & (HG_SLOTS - 1);
+            }
+            if (!done) {
+                unsafeAtomicAdd(tab + 2 * (int64_t)idx, wk * g0);
+                unsafeAtomicAdd(tab + 2 * (int64_t)idx + 1, wk * g1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < HG_SLOTS; s += 256) {
+        const uint32_t k = keys[s];
+        if (k != HG_EMPTY) {
+            unsafeAtomicAdd(tab + 2 * (int64_t)k, acc0[s]);
+            unsafeAtomicAdd(tab + 2 * (int64_t)k + 1, acc1[s]);
+        }
     }
 }
 
@@ -153,7 +194,7 @@ extern "C" int mvip_hashgrid_backward(const float *x, const float *d_features, c
     if (P < 0) return MVIP_EINVAL;
     if (P == 0) return MVIP_OK;
     if (!x || !d_features || !levels || !d_table) return MVIP_EINVAL;
-    const dim3 grid((unsigned)((P + 255) / 256), HG_LEVELS);
+    const dim3 grid((unsigned)((P + HG_TILE - 1) / HG_TILE), HG_LEVELS);
     hipLaunchKernelGGL(hg_backward_kernel, grid, dim3(256), 0, as_stream(stream), x, d_features,
                        (const HgLevel *)levels, P, bound, d_table);
     return check_launch();

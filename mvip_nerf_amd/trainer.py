@@ -64,7 +64,8 @@ class SecondStageTrainer:
     def __init__(self, args, scene, device, guidance=None, world=1, rank=0, dist=None):
         self.args, self.scene, self.device = args, scene, device
         self.world, self.rank, self.dist = world, rank, dist
-        (self.kw_train, self.kw_test, self.start, self.grad_vars, self.optimizer) = run.create_nerf(args, device)
+        make = run.create_nerf if getattr(args, 'no_tcnn', True) else run.create_nerf_tcnn      # run.py:541-546
+        (self.kw_train, self.kw_test, self.start, self.grad_vars, self.optimizer) = make(args, device)
         self.global_step = self.start
         self.guidance = guidance                       # Pretrain_Model-like object with cal_loss(), or None
         self.rng = np.random.RandomState(1234)         # same draw on every rank (view choice must agree)
