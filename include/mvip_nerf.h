@@ -255,6 +255,21 @@ int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, co
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, void *stream);
 
+/* The same split-precision machinery as a plain GEMM (1x1 convolutions and the products of the VAE
+ * mid-block attention, vae.encode at DS_NeRF/guidance/sd_utils.py:207):
+ *   Y[n][m][p] = sum_k A[m][k] X[n][k][p] / (s_a s_x) + bias[m] + chan_add[n][m] + residual[n][m][p]
+ * A[m][k] = src[m*sm + k*sk] (src a dense block of M*K floats) is packed by mvip_gemm_pack_a into
+ * mvip_gemm_packed_bytes(M, K) bytes; X travels as split planes [N][K/16][2][2][P][8], written by
+ * mvip_split_planes_strided from x[n*sn + k*sc + p*sp] (times scale2[0] if given).
+ * M % 32 == 0, K % 32 == 0, P % 256 == 0. */
+int64_t mvip_gemm_packed_bytes(int64_t M, int64_t K);
+int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t sm, int64_t sk, void *packed, void *stream);
+int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc, int64_t sp,
+                              const float *scale2, void *xs, void *stream);
+int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                    const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                    float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * encodings of the reference's second model NeRF_TCNN
  * (DS_NeRF/run_nerf_helpers_tcnn.py:36-46 hash grid, :63-69 spherical harmonics, :91-101 forward), which

@@ -118,6 +118,28 @@ __global__ void cv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, i
     out[idx] = hl ? lo : hi;
 }
 
+// A operand of the plain GEMM (1x1 "convolution"): A[m][k] = src[m*sm + k*sk], packed [M/32][K/16][hl][lane][8]
+__global__ void gm_pack_kernel(const float *__restrict__ src, int M, int K, int64_t sm, int64_t sk,
+                               const float *__restrict__ scale2, uint4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CK = K / 16;
+    const int64_t total = (int64_t)(M / 32) * CK * 2 * 64;
+    if (idx >= total) return;
+    int64_t r = idx;
+    const int lane = (int)(r % 64); r /= 64;
+    const int hl = (int)(r % 2); r /= 2;
+    const int ck = (int)(r % CK); r /= CK;
+    const int m = (int)r * 32 + (lane & 31);
+    const int kg = lane >> 5;
+    const float s = scale2[0];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)m * sm + (int64_t)(ck * 16 + kg * 8 + j) * sk] * s;
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    out[idx] = hl ? lo : hi;
+}
+
 // ---- activation producers ------------------------------------------------------------------------------
 // grid (ceil(HW/256), N*C/16): thread = pixel, 16 channel rows read coalesced, 4 plane pieces written.
 // GN: z = act((x - mean)*rstd*gamma + beta) with per-group statistics; otherwise z = x * scale2[0].
@@ -125,7 +147,7 @@ template <bool GN, bool SILU>
 __global__ void __launch_bounds__(256)
 cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ scale2,
-                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs) {
+                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp) {
     __shared__ float pa[16], pb[16], pm[16];
     const int CK = C / 16;
     const int ck = (int)(blockIdx.y % CK);
@@ -144,10 +166,10 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const float s = (!GN && scale2) ? scale2[0] : 1.f;
-    const float *xr = x + (n * C + ck * 16) * HW + p;
+    const float *xr = x + n * sn + (int64_t)(ck * 16) * sc + p * sp;      // element (n, channel, pixel)
     float v[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = xr[c * HW];
+    for (int c = 0; c < 16; ++c) v[c] = xr[c * sc];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         if (GN) {
@@ -296,6 +318,117 @@ __global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
         }
 }
 
+// ---- plain GEMM (1x1 convolution, attention products) on the same operand formats -----------------------
+//   Y[n][m][p] = sum_k A[m][k] X[n][k][p] / (s_a s_x) + bias[m] + chan_add[n][m] + residual[n][m][p]
+// A packed by gm_pack_kernel, X in split planes [n][K/16][2][2][P][8].  Workgroup = 32*MT rows x 256
+// columns, stage = 32 k (two 16-channel chunks: 48 MFMAs per wave at MT=4), double-buffered DMA.
+constexpr int GM_PIX = 256;
+constexpr int GM_KC = 2;
+
+struct GemmArgs {
+    const char *xs, *wp;
+    const float *bias, *chan_add, *residual, *x_scale2, *w_scale2;
+    float *y;
+    int N, CK, M, MB, tiles;
+    int64_t P;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(256) gemm_f16x3_kernel(const GemmArgs a) {
+    constexpr int WB = GM_KC * MT * 2 * 1024;
+    constexpr int IB = GM_KC * 4 * GM_PIX * 16;
+    __shared__ __attribute__((aligned(16))) char lds[2 * WB + 2 * IB];
+    char *lds_w = lds, *lds_in = lds + 2 * WB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, kg = lane >> 5;
+    int id = blockIdx.x;
+    const int total = gridDim.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int mb = id % a.MB;
+    const int tile = id / a.MB;
+    const int tp = tile % a.tiles;
+    const int n = tile / a.tiles;
+    const int64_t p0 = (int64_t)tp * GM_PIX;
+    const int64_t plane = a.P * 16;
+    const char *xs_n = a.xs + (int64_t)n * a.CK * 4 * plane + (p0 + tid) * 16;
+
+    auto issue_input = [&](int s, int buf) {
+#pragma unroll
+        for (int kc = 0; kc < GM_KC; ++kc)
+#pragma unroll
+            for (int piece = 0; piece < 4; ++piece)
+                glds16b(xs_n + ((int64_t)(s * GM_KC + kc) * 4 + piece) * plane,
+                        lds_in + buf * IB + ((kc * 4 + piece) * GM_PIX + wave * 64) * 16);
+    };
+    auto issue_weights = [&](int s, int buf) {
+#pragma unroll
+        for (int b0 = 0; b0 < GM_KC * MT * 2; b0 += 4) {       // LDS block b = (kc*MT + m)*2 + hl
+            const int b = b0 + wave;
+            if (b < GM_KC * MT * 2) {
+                const int hl = b & 1, m = (b >> 1) % MT, kc = (b >> 1) / MT;
+                glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + s * GM_KC + kc) * 2 + hl) * 1024) + lane * 16,
+                        lds_w + buf * WB + b * 1024);
+            }
+        }
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    const int nstage = a.CK / GM_KC;
+    issue_input(0, 0);
+    issue_weights(0, 0);
+    for (int s = 0; s < nstage; ++s) {
+        __syncthreads();
+        if (s + 1 < nstage) { issue_weights(s + 1, (s + 1) & 1); issue_input(s + 1, (s + 1) & 1); }
+        const char *inb = lds_in + (s & 1) * IB;
+        const char *wb = lds_w + (s & 1) * WB + lane * 16;
+#pragma unroll
+        for (int kc = 0; kc < GM_KC; ++kc) {
+            h16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = (2 * wave + j) * 32 + l32;
+                bh[j] = *reinterpret_cast<const h16x8 *>(inb + ((kc * 4 + kg * 2 + 0) * GM_PIX + p) * 16);
+                bl[j] = *reinterpret_cast<const h16x8 *>(inb + ((kc * 4 + kg * 2 + 1) * GM_PIX + p) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const h16x8 ah = *reinterpret_cast<const h16x8 *>(wb + ((kc * MT + m) * 2 + 0) * 1024);
+                const h16x8 al = *reinterpret_cast<const h16x8 *>(wb + ((kc * MT + m) * 2 + 1) * 1024);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[m][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                float v = acc[m][j][r] * inv;
+                if (a.bias) v += a.bias[row];
+                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
+                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
+                if (a.residual) v += a.residual[o];
+                a.y[o] = v;
+            }
+        }
+}
+
 // largest MT in {4, 2, 1} dividing Cout/32 whose grid still has >= 256 workgroups (else the smallest)
 static inline int cv_mt(int64_t Cout, int64_t tiles) {
     if (Cout % 32 != 0) return 0;
@@ -351,7 +484,18 @@ extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t H
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs);
+                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, C * HW, HW, (int64_t)1);
+    return check_launch();
+}
+
+extern "C" int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc,
+                                         int64_t sp, const float *scale2, void *xs, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0) return MVIP_EINVAL;
+    if (N == 0 || HW == 0) return MVIP_OK;
+    if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
+    hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
+                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, sn, sc, sp);
     return check_launch();
 }
 
@@ -364,10 +508,10 @@ extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, c
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     if (silu)
         hipLaunchKernelGGL((cv_to_split_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
-                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs);
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1);
     else
         hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
-                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs);
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1);
     return check_launch();
 }
 
@@ -393,5 +537,49 @@ extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const floa
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     else
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    return check_launch();
+}
+
+/* ---- plain GEMM ---------------------------------------------------------------------------------------- */
+extern "C" int64_t mvip_gemm_packed_bytes(int64_t M, int64_t K) {
+    if (M <= 0 || K <= 0) return 0;
+    return M * K * 4 + 256;
+}
+
+extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t sm, int64_t sk, void *packed,
+                                void *stream) {
+    if (!src || !packed || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    char *tail = (char *)packed + M * K * 4;
+    if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
+    hipLaunchKernelGGL(cv_absmax_kernel, dim3(1024), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 8));
+    hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
+    const int64_t total = (M / 32) * (K / 16) * 2 * 64;
+    hipLaunchKernelGGL(gm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, (int)M, (int)K, sm,
+                       sk, (const float *)tail, (uint4 *)packed);
+    return check_launch();
+}
+
+extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                               const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                               float *y, void *stream) {
+    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!xs || !packed || !y) return MVIP_EINVAL;
+    GemmArgs a;
+    a.xs = (const char *)xs; a.wp = (const char *)packed;
+    a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
+    a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
+    a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P; a.tiles = (int)(P / GM_PIX);
+    const int MT = cv_mt(M, N * a.tiles);
+    a.MB = (int)(M / (32 * MT));
+    const int64_t blocks = N * a.tiles * a.MB;
+    if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+    if (MT == 4)
+        hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else if (MT == 2)
+        hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     return check_launch();
 }

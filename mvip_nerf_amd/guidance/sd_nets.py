@@ -265,6 +265,10 @@ class VAEAttention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
 
     def forward(self, x):
+        if x.is_cuda:
+            from .. import ops
+            if ops.vae_attention_supported(x):          # split-precision MFMA products (csrc/conv3x3.hip GEMM)
+                return ops.vae_attention(x, self)
         B, C, H, W = x.shape
         h = self.group_norm(x).reshape(B, C, H * W).transpose(1, 2)
         o = F.scaled_dot_product_attention(self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None])[:, 0]

@@ -624,3 +624,146 @@ def sh4(dirs):
     out = torch.empty((16, dc.shape[0]), device=dc.device, dtype=torch.float32)
     call('mvip_sh4', ptr(dc), dc.shape[0], ptr(out), stream())
     return out
+
+
+# Split-precision GEMM building blocks and the VAE mid-block attention built from them ------------------------
+
+def absmax_scale(t):
+    """Device-side {s, 1/s, scratch, scratch}: power of two with |t|max * s in [2^9, 2^10)."""
+    tc = t.contiguous()
+    scale2 = torch.empty(4, device=t.device, dtype=torch.float32)
+    call('mvip_absmax_scale', ptr(tc), tc.numel(), ptr(scale2), stream())
+    return scale2
+
+
+def gemm_pack_a(src, M, K, sm, sk):
+    """A[m][k] = src.flatten()[m*sm + k*sk] (src a dense block of M*K floats) -> packed split-precision image."""
+    s = src.contiguous()
+    assert s.numel() == M * K
+    packed = torch.empty(int(_lib.load().mvip_gemm_packed_bytes(M, K)), device=s.device, dtype=torch.uint8)
+    call('mvip_gemm_pack_a', ptr(s), M, K, sm, sk, ptr(packed, torch.uint8), stream())
+    return packed
+
+
+def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
+    """X[n][k][p] = x.flatten()[n*sn + k*sc + p*sp] (* scale2[0]) -> fp16 hi/lo split planes."""
+    xc = x.contiguous()
+    xs = _split_buffer(N, K, P, xc.device)
+    call('mvip_split_planes_strided', ptr(xc), N, K, P, sn, sc, sp, ptr(scale2), ptr(xs, torch.float16), stream())
+    return xs
+
+
+def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None):
+    """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P]."""
+    y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
+    call('mvip_gemm_f16x3', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
+         ptr(x_scale2), N, K, M, P, ptr(y), stream())
+    return y
+
+
+def _scaled_planes(x, N, K, P, sn, sc, sp):
+    s2 = absmax_scale(x)
+    return split_planes_strided(x, N, K, P, sn, sc, sp, s2), s2
+
+
+def vae_attention_supported(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 32 == 0
+            and (x.shape[2] * x.shape[3]) % 256 == 0)
+
+
+def _attn_weights(mod):
+    """Cached packed images of the attention block's four linears (frozen): [Wq;Wk;Wv] and Wo with their
+    transposes for the backward."""
+    ws = (mod.to_q.weight, mod.to_k.weight, mod.to_v.weight, mod.to_out[0].weight)
+    key = tuple((w.data_ptr(), w._version) for w in ws)
+    cache = mod.__dict__.setdefault('_mvip_packed', {})
+    if cache.get('key') != key:
+        C = ws[0].shape[0]
+        wqkv = torch.cat([w.detach() for w in ws[:3]], 0).contiguous()          # [3C, C]
+        wo = ws[3].detach().contiguous()
+        cache.clear()
+        cache.update(key=key,
+                     qkv=gemm_pack_a(wqkv, 3 * C, C, C, 1), qkv_t=gemm_pack_a(wqkv, C, 3 * C, 1, C),
+                     o=gemm_pack_a(wo, C, C, C, 1), o_t=gemm_pack_a(wo, C, C, 1, C),
+                     bqkv=torch.cat([mod.to_q.bias.detach(), mod.to_k.bias.detach(), mod.to_v.bias.detach()]).contiguous(),
+                     bo=mod.to_out[0].bias.detach().contiguous())
+    return cache
+
+
+class _VAEAttention(torch.autograd.Function):
+    """x + proj(softmax(q^T k / sqrt(C)) v) of the VAE mid block (single head over H*W tokens, channel-first),
+    every product on the split-precision MFMA GEMM; the [L, L] score matrix is materialised (67 MB at 64x64).
+    Backward: the six transposed products + GroupNorm backward.  Parameter gradients are not produced."""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        for p in mod.parameters():
+            if p.requires_grad:
+                raise NotImplementedError('vae_attention: parameter gradients are not implemented (frozen networks only)')
+        xc = x.contiguous()
+        N, C, H, W = xc.shape
+        L, dev, norm = H * W, xc.device, mod.group_norm
+        G = norm.num_groups
+        wts = _attn_weights(mod)
+        mean = torch.empty((N, G), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = _gn_workspace(N, C, L, dev)
+        gw, gb = norm.weight.detach().contiguous(), norm.bias.detach().contiguous()
+        call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
+             ptr(ws, torch.float64), stream())
+        hs = _split_buffer(N, C, L, dev)
+        call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, L, G, 0,
+             ptr(hs, torch.float16), stream())
+        qkv = gemm_f16x3(hs, wts['qkv'], N, C, 3 * C, L, bias=wts['bqkv'])           # [N, 3C, L]
+        del hs
+        probs, O = [], torch.empty((N, C, L), device=dev, dtype=torch.float32)
+        for n in range(N):
+            q, k, v = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:]
+            ks, s2 = _scaled_planes(k, 1, C, L, 0, L, 1)
+            S = gemm_f16x3(ks, gemm_pack_a(q, L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]        # S[i][j] = q_i . k_j
+            Pm = torch.softmax(S * (C ** -0.5), -1)
+            del S
+            pts, s2 = _scaled_planes(Pm, 1, L, L, 0, 1, L)                                    # X[k=j][p=i] = P[i][j]
+            O[n] = gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]
+            probs.append(Pm)
+        os_, s2 = _scaled_planes(O, N, C, L, C * L, L, 1)
+        out = gemm_f16x3(os_, wts['o'], N, C, C, L, bias=wts['bo'], residual=xc.reshape(N, C, L), x_scale2=s2)
+        ctx.save_for_backward(xc, gw, gb, mean, rstd, qkv, *probs)
+        ctx.mod = mod
+        return out.reshape(N, C, H, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, gw, gb, mean, rstd, qkv, *probs = ctx.saved_tensors
+        mod = ctx.mod
+        N, C, H, W = xc.shape
+        L, dev, norm = H * W, xc.device, mod.group_norm
+        wts = _attn_weights(mod)
+        d = dout.contiguous().float().reshape(N, C, L)
+        ds, s2 = _scaled_planes(d, N, C, L, C * L, L, 1)
+        dO = gemm_f16x3(ds, wts['o_t'], N, C, C, L, x_scale2=s2)                               # Wo^T dOut
+        dqkv = torch.empty_like(qkv)
+        for n in range(N):
+            q, k, v, Pm = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:], probs[n]
+            ps, s2 = _scaled_planes(Pm, 1, L, L, 0, L, 1)                                      # X[k=i][p=j] = P[i][j]
+            dqkv[n, 2 * C:] = gemm_f16x3(ps, gemm_pack_a(dO[n], C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]      # dV
+            vs, s2 = _scaled_planes(v, 1, C, L, 0, L, 1)
+            dP = gemm_f16x3(vs, gemm_pack_a(dO[n], L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]    # dP[i][j] = dO_i . v_j
+            dS = Pm * (dP - (dP * Pm).sum(-1, keepdim=True)) * (C ** -0.5)
+            del dP
+            s2 = absmax_scale(dS)
+            dst = split_planes_strided(dS, 1, L, L, 0, 1, L, s2)                               # X[k=j][p=i] = dS[i][j]
+            dqkv[n, :C] = gemm_f16x3(dst, gemm_pack_a(k, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]             # dQ
+            dsn = split_planes_strided(dS, 1, L, L, 0, L, 1, s2)                               # X[k=i][p=j] = dS[i][j]
+            dqkv[n, C:2 * C] = gemm_f16x3(dsn, gemm_pack_a(q, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]        # dK
+        dqs, s2 = _scaled_planes(dqkv, N, 3 * C, L, 3 * C * L, L, 1)
+        dh = gemm_f16x3(dqs, wts['qkv_t'], N, 3 * C, C, L, x_scale2=s2)                         # Wqkv^T dqkv
+        dx = torch.empty_like(xc)
+        ws = _gn_workspace(N, C, L, dev)
+        call('mvip_groupnorm_backward', ptr(xc), ptr(dh.reshape(N, C, H, W)), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N,
+             C, L, norm.num_groups, 0, 0, ptr(dx), ptr(ws, torch.float64), stream())
+        return dx + d.reshape(N, C, H, W), None
+
+
+def vae_attention(x, mod):
+    return _VAEAttention.apply(x, mod)

@@ -279,3 +279,47 @@ def test_resnet_block_fused_equals_library_path(cuda):
     x48 = torch.nn.functional.pad(x, (0, 0, 0, 0))          # same data; library path via the CPU module
     ref = blk.to('cpu').double()(x48.cpu().double(), temb.cpu().double())
     np.testing.assert_allclose(N(fused), ref.float().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+def test_gemm_f16x3(cuda):
+    """Y = A X on the split-precision GEMM with strided operand sources vs fp64; tiny-magnitude operands (the
+    gradients of the SDS step are ~1e-6) keep fp32-grade accuracy through the power-of-two scaling."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(0)
+    M, K, P = 96, 64, 512
+    A = torch.randn(M, K, generator=g) * 3e-6
+    X = torch.randn(2, K, P, generator=g) * 2e-5
+    bias, res = torch.randn(M, generator=g) * 1e-10, torch.randn(2, M, P, generator=g) * 1e-10
+    ref = torch.einsum('mk,nkp->nmp', A.double(), X.double()) + bias.double()[None, :, None] + res.double()
+    Xd = X.to(cuda)
+    s2 = ops.absmax_scale(Xd)
+    xs = ops.split_planes_strided(Xd, 2, K, P, K * P, P, 1, s2)
+    y = ops.gemm_f16x3(xs, ops.gemm_pack_a(A.to(cuda), M, K, K, 1), 2, K, M, P, bias=bias.to(cuda),
+                       residual=res.to(cuda), x_scale2=s2)
+    np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+    # transposed sources: A given as [K, M], X given as [P, K]
+    At, Xt = A.T.contiguous().to(cuda), X[0].T.contiguous().to(cuda)
+    xs = ops.split_planes_strided(Xt, 1, K, P, 0, 1, K, None)
+    y2 = ops.gemm_f16x3(xs, ops.gemm_pack_a(At, M, K, 1, M), 1, K, M, P)
+    ref2 = A.double() @ X[0].double()
+    np.testing.assert_allclose(N(y2[0]), ref2.float().numpy(), rtol=0, atol=1e-3 * float(ref2.abs().max()))
+
+
+def test_vae_attention_vs_fp64(cuda):
+    from mvip_nerf_amd.guidance.sd_nets import VAEAttention
+    from mvip_nerf_amd import ops
+    torch.manual_seed(1)
+    att = VAEAttention(64)
+    att.requires_grad_(False)
+    x = torch.randn(1, 64, 16, 32) * 1.5
+    dy = torch.randn(1, 64, 16, 32) * 1e-5
+    xr = x.double().requires_grad_(True)
+    ref = att.double()(xr)
+    ref.backward(dy.double())
+    att_d = att.float().to(cuda)
+    xd = x.to(cuda).requires_grad_(True)
+    assert ops.vae_attention_supported(xd)
+    y = att_d(xd)
+    np.testing.assert_allclose(N(y), ref.detach().float().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    y.backward(dy.to(cuda))
+    np.testing.assert_allclose(N(xd.grad), xr.grad.float().numpy(), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
