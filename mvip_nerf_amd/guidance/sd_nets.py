@@ -16,6 +16,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Which layers take the hand-written split-precision kernels (csrc/conv3x3.hip) instead of the library ones;
+# switches exist for A/B timing (tools/sds_bench.py), every combination computes the same function.
+USE_MFMA_CONV3X3 = True
+USE_MFMA_CONV1X1 = False      # measured slower than the library at these small K (A/B: +4 ms per step)
+USE_MFMA_VAE_ATTENTION = True
+
+
 # ---------------------------------------------------------------------------------------------- blocks
 class GroupNorm(nn.GroupNorm):
     """nn.GroupNorm (same parameters and state-dict keys) whose device path is the HIP kernel pair of
@@ -37,7 +44,7 @@ def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
     launches; every other shape takes the GroupNorm kernel pair followed by the library convolution."""
     if x.is_cuda:
         from .. import ops
-        if ops.conv3x3_supported(conv, x):
+        if USE_MFMA_CONV3X3 and ops.conv3x3_supported(conv, x):
             return ops.norm_act_conv3x3(x, norm, conv, True, chan_add, residual)
     h = conv(norm(x, silu=True))
     if chan_add is not None:
@@ -58,8 +65,17 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb=None):
         t = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
         h = norm_act_conv(self.norm1, self.conv1, x, chan_add=t)
-        return norm_act_conv(self.norm2, self.conv2, h,
-                             residual=x if self.conv_shortcut is None else self.conv_shortcut(x))
+        if self.conv_shortcut is None:
+            sc = x
+        else:
+            sc = None
+            if x.is_cuda:
+                from .. import ops
+                if USE_MFMA_CONV1X1 and ops.conv1x1_supported(self.conv_shortcut, x):
+                    sc = ops.conv1x1(x, self.conv_shortcut)
+            if sc is None:
+                sc = self.conv_shortcut(x)
+        return norm_act_conv(self.norm2, self.conv2, h, residual=sc)
 
 
 class Attention(nn.Module):
@@ -123,9 +139,18 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ctx):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        fast = False
+        if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
+            from .. import ops
+            fast = USE_MFMA_CONV1X1 and ops.conv1x1_supported(self.proj_in, x)       # 1x1 projections on the split-precision GEMM
+        if fast:
+            h = ops.norm_conv1x1(x, self.norm, self.proj_in).permute(0, 2, 1)
+        else:
+            h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
+        if fast:
+            return ops.tokens_conv1x1(h, self.proj_out, x)
         return x + self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
 
 
@@ -267,7 +292,7 @@ class VAEAttention(nn.Module):
     def forward(self, x):
         if x.is_cuda:
             from .. import ops
-            if ops.vae_attention_supported(x):          # split-precision MFMA products (csrc/conv3x3.hip GEMM)
+            if USE_MFMA_VAE_ATTENTION and ops.vae_attention_supported(x):          # split-precision MFMA products (csrc/conv3x3.hip GEMM)
                 return ops.vae_attention(x, self)
         B, C, H, W = x.shape
         h = self.group_norm(x).reshape(B, C, H * W).transpose(1, 2)

@@ -767,3 +767,91 @@ class _VAEAttention(torch.autograd.Function):
 
 def vae_attention(x, mod):
     return _VAEAttention.apply(x, mod)
+
+
+# 1x1 convolutions of the SDS networks on the split-precision GEMM ------------------------------------------------
+
+def conv1x1_supported(conv, x, tokens=False):
+    """x: [N, Cin, H, W] (or [N, L, Cin] token-major when tokens=True), fp32 on the device."""
+    if not (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.weight.dtype == torch.float32):
+        return False
+    L = x.shape[1] if tokens else x.shape[2] * x.shape[3]
+    return conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and L % 256 == 0
+
+
+def _conv1x1_packed(conv, transpose):
+    cache = conv.__dict__.setdefault('_mvip_packed', {})
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    if cache.get('key') != key:
+        cache.clear()
+        cache['key'] = key
+    if transpose not in cache:
+        Cout, Cin = conv.out_channels, conv.in_channels
+        w = conv.weight.detach().reshape(Cout, Cin).contiguous()
+        cache[transpose] = gemm_pack_a(w, Cin, Cout, 1, Cin) if transpose else gemm_pack_a(w, Cout, Cin, Cin, 1)
+    return cache[transpose]
+
+
+class _Conv1x1(torch.autograd.Function):
+    """conv1x1(x) + bias [+ residual] for x [N, Cin, H, W]; the data gradient runs the transposed image."""
+
+    @staticmethod
+    def forward(ctx, x, residual, conv):
+        if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+            raise NotImplementedError('conv1x1: parameter gradients are not implemented (frozen networks only)')
+        xc = x.contiguous()
+        N, C, H, W = xc.shape
+        L, Cout = H * W, conv.out_channels
+        xs, s2 = _scaled_planes(xc, N, C, L, C * L, L, 1)
+        bias = None if conv.bias is None else conv.bias.detach().contiguous()
+        rs = None if residual is None else residual.detach().contiguous()
+        y = gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, Cout, L, bias=bias, residual=rs, x_scale2=s2)
+        ctx.conv, ctx.shape = conv, (N, C, H, W)
+        return y.reshape(N, Cout, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        conv = ctx.conv
+        N, C, H, W = ctx.shape
+        L, Cout = H * W, conv.out_channels
+        d = dy.contiguous().float()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ds, s2 = _scaled_planes(d, N, Cout, L, Cout * L, L, 1)
+            dx = gemm_f16x3(ds, _conv1x1_packed(conv, True), N, Cout, C, L, x_scale2=s2).reshape(N, C, H, W)
+        return dx, (d if ctx.needs_input_grad[1] else None), None
+
+
+def conv1x1(x, conv, residual=None):
+    return _Conv1x1.apply(x, residual, conv)
+
+
+def norm_conv1x1(x, norm, conv):
+    """conv1x1(group_norm(x)) + bias, forward only (the UNet's transformer proj_in; runs under no_grad)."""
+    xc = x.detach().contiguous()
+    N, C, H, W = xc.shape
+    L, G, dev = H * W, norm.num_groups, xc.device
+    mean = torch.empty((N, G), device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    ws = _gn_workspace(N, C, L, dev)
+    call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, ptr(mean), ptr(rstd), ptr(ws, torch.float64),
+         stream())
+    xs = _split_buffer(N, C, L, dev)
+    call('mvip_groupnorm_split_planes', ptr(xc), ptr(norm.weight.detach().contiguous()),
+         ptr(norm.bias.detach().contiguous()), ptr(mean), ptr(rstd), N, C, L, G, 0, ptr(xs, torch.float16), stream())
+    bias = None if conv.bias is None else conv.bias.detach().contiguous()
+    return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias)     # [N, Cout, L]
+
+
+def tokens_conv1x1(h, conv, residual):
+    """conv1x1 of token-major activations h [N, L, Cin] back to channel-first, + bias + residual [N, Cout, H, W];
+    forward only (the UNet's transformer proj_out).  The token -> channel-first permute is folded into the
+    split-plane writer's strides."""
+    hc = h.detach().contiguous()
+    N, L, C = hc.shape
+    xs, s2 = _scaled_planes(hc, N, C, L, L * C, 1, C)
+    bias = None if conv.bias is None else conv.bias.detach().contiguous()
+    rs = residual.detach().contiguous()
+    return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias, residual=rs,
+                      x_scale2=s2).reshape(rs.shape)

@@ -323,3 +323,33 @@ def test_vae_attention_vs_fp64(cuda):
     np.testing.assert_allclose(N(y), ref.detach().float().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
     y.backward(dy.to(cuda))
     np.testing.assert_allclose(N(xd.grad), xr.grad.float().numpy(), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
+
+
+def test_conv1x1_paths_vs_library(cuda):
+    """1x1 convolutions on the split-precision GEMM (ResNet shortcut with gradient; transformer proj_in with
+    GroupNorm; proj_out from token-major activations + residual) against the library convolution."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(64, 96, 1).to(cuda).requires_grad_(False)
+    norm = GroupNorm(32, 64, eps=1e-6).to(cuda).requires_grad_(False)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(64) + 0.5); norm.bias.copy_(torch.randn(64) * 0.2)
+    x = torch.randn(2, 64, 16, 32, device=cuda)
+    assert ops.conv1x1_supported(conv, x)
+    xr = x.clone().requires_grad_(True)
+    xd = x.clone().requires_grad_(True)
+    dy = torch.randn(2, 96, 16, 32, device=cuda) * 1e-5
+    ref = conv(xr); ref.backward(dy)
+    got = ops.conv1x1(xd, conv); got.backward(dy)
+    np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    np.testing.assert_allclose(N(xd.grad), N(xr.grad), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
+    with torch.no_grad():
+        ref = conv(torch.nn.functional.group_norm(x, 32, norm.weight, norm.bias, 1e-6))
+        got = ops.norm_conv1x1(x, norm, conv).reshape(2, 96, 16, 32)
+        np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-5 * float(ref.abs().max()))
+        conv2 = torch.nn.Conv2d(96, 64, 1).to(cuda).requires_grad_(False)
+        h = torch.randn(2, 512, 96, device=cuda)
+        ref = x + conv2(h.reshape(2, 16, 32, 96).permute(0, 3, 1, 2))
+        got = ops.tokens_conv1x1(h, conv2, x)
+        np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-5 * float(ref.abs().max()))

@@ -31,9 +31,12 @@ def run(fp16, steps=5):
             'mem_GB': torch.cuda.max_memory_allocated() / 1e9}
 
 if __name__ == '__main__':
-    for fp16 in (False, True):
-        try:
-            print(json.dumps(run(fp16)), flush=True)
-        except Exception as e:
-            print('FAILED', fp16, repr(e)[:500], flush=True)
+    from mvip_nerf_amd.guidance import sd_nets
+    for c3, c1, at in ((True, True, True), (True, False, True), (True, False, False), (False, False, False), (True, True, True)):
+        sd_nets.USE_MFMA_CONV3X3, sd_nets.USE_MFMA_CONV1X1, sd_nets.USE_MFMA_VAE_ATTENTION = c3, c1, at
+        r = run(False)
+        r.update(conv3x3=c3, conv1x1=c1, vae_attention=at)
+        print(json.dumps(r), flush=True)
         torch.cuda.empty_cache()
+    sd_nets.USE_MFMA_CONV3X3 = sd_nets.USE_MFMA_CONV1X1 = sd_nets.USE_MFMA_VAE_ATTENTION = True
+    print(json.dumps(run(True)), flush=True)
