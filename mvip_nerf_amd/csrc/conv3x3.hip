@@ -68,7 +68,15 @@ __global__ void __launch_bounds__(256) cv_absmax_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    __shared__ float wm[4];                 // one atomic per workgroup: same-address atomics serialise (~10 ns each)
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
+static inline unsigned absmax_blocks(int64_t n) {
+    int64_t b = (n + 256 * 32 - 1) / (256 * 32);
+    return (unsigned)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 // scale2 = {s, 1/s} with s a power of two such that absmax*s lies in [2^9, 2^10)
@@ -460,7 +468,8 @@ extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin,
     hipStream_t st = as_stream(stream);
     char *tail = (char *)packed + co * ci * 36;
     if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
-    hipLaunchKernelGGL(cv_absmax_kernel, dim3(256), dim3(256), 0, st, weight, Cout * Cin * 9, (unsigned *)(tail + 8));
+    hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(Cout * Cin * 9)), dim3(256), 0, st, weight, Cout * Cin * 9,
+                       (unsigned *)(tail + 8));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
     const int64_t total = (co / 32) * (ci / 16) * 9 * 2 * 64;
     hipLaunchKernelGGL(cv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, (int)co, (int)ci,
@@ -472,7 +481,7 @@ extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void 
     if (n < 0 || !scale2 || (n > 0 && !x)) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(scale2, 0, 16, st) != hipSuccess) return check_launch();
-    if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(2048), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
+    if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(n)), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(scale2 + 2), scale2);
     return check_launch();
 }
@@ -552,7 +561,7 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     hipStream_t st = as_stream(stream);
     char *tail = (char *)packed + M * K * 4;
     if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
-    hipLaunchKernelGGL(cv_absmax_kernel, dim3(1024), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 8));
+    hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(M * K)), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 8));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
     const int64_t total = (M / 32) * (K / 16) * 2 * 64;
     hipLaunchKernelGGL(gm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, (int)M, (int)K, sm,

@@ -50,7 +50,7 @@ constexpr int T_FLOATS = T_TOTAL_BLOCKS * BLOCK_FLOATS;
 static_assert(T_VIEWS_BLOCKS % (NSLOT * CHUNK_BLOCKS) == 0, "ring phase");
 
 __device__ __forceinline__ float packed_w(const float *__restrict__ packed, int blk_off, int KG, int out, int k) {
-    const int blk = blk_off + (out >> 5) * KG + (k >> 3);
+    const int blk = blk_off + block_pos(out >> 5, k >> 3, KG);
     return packed[(int64_t)blk * BLOCK_FLOATS + ((k & 7) >> 2) * 128 + (out & 31) * 4 + (k & 3)];
 }
 
@@ -61,12 +61,14 @@ __global__ void mlp_pack_transposed_kernel(const float *__restrict__ packed, flo
     const int h = r / 128, i = (r % 128) / 4, s = r % 4;
     float v;
     if (blk < T_VIEWS_BLOCKS) {
-        const int ti = blk / 16, kg = blk % 16;
+        int ti, kg;
+        block_tile(blk, 16, ti, kg);
         v = packed_w(packed, OFF_VIEWS, LV_KG, 8 * kg + 4 * h + s, 32 * ti + i);
     } else {
         const int m = (blk - T_VIEWS_BLOCKS) / T_LAYER_BLOCKS;      // 0: feature, 1..7: layers 7..1
         const int local = (blk - T_VIEWS_BLOCKS) % T_LAYER_BLOCKS;
-        const int ti = local / 32, kg = local % 32;
+        int ti, kg;
+        block_tile(local, 32, ti, kg);
         const int out = 8 * kg + 4 * h + s, in = 32 * ti + i;
         if (m == 0) v = packed_w(packed, OFF_FEAT, LH_KG, out, in);
         else {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_kernel(
 
     __syncthreads();
     const float *sb = lds + RING_FLOATS;
-    f32x4 a = st.first_block();
+    APair32 a = st.first_pair();
 
     // grad wrt view-branch pre-activation: relu'(v) . (W_rgb^T d_rgb)
     f32x16 gv[4];

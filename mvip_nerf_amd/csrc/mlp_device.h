@@ -36,6 +36,8 @@ __device__ __forceinline__ void glds16(const float *src_lane, float *dst_wave) {
 // chunk g; the __syncthreads at the end of chunk g (which waits vmcnt(0)) makes chunk g+2
 // visible to every wave.  Hence chunk g+1 is already complete while g is computed, which is
 // what allows reading the first block of g+1 before that barrier (A-operand prefetch).
+struct APair32 { f32x4 x, y; };          // A operands of the two tiles of a pair for one k-group
+
 struct Stream {
     const float *packed;     // section A base (a section B may follow at SEC_A_FLOATS)
     float *lds;
@@ -48,6 +50,14 @@ struct Stream {
 #pragma unroll
             for (int b = 0; b < 4; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
         }
+    }
+    // one quarter of issue_chunk: the q-th of this wave's four 1-KB pieces.  run_layer issues the four pieces
+    // in four different MFMA gaps rather than back to back (tools/micro/mfma_lds.hip: LDS-DMA issue costs
+    // ~1.9 cycles per MFMA in an otherwise 64.0-cycle loop, the per-chunk barrier another ~1.1).
+    __device__ __forceinline__ void issue_piece(int g, int slot, int q, int total_chunks = TOTAL_CHUNKS) const {
+        if (g < total_chunks)
+            glds16(packed + (int64_t)g * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS) + lane * 4 + q * BLOCK_FLOATS,
+                   lds + slot * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS) + q * BLOCK_FLOATS);
     }
     __device__ __forceinline__ void load_section_b(const float *secb) const {
         for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 4)
@@ -64,48 +74,79 @@ struct Stream {
         return *reinterpret_cast<const f32x4 *>(lds + off + lane * 4);
     }
     __device__ __forceinline__ f32x4 first_block() const { return read_block<0>(); }
+    __device__ __forceinline__ struct APair32 first_pair() const;
 };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ APair32 Stream::first_pair() const { return APair32{read_block<0>(), read_block<1>()}; }
+
 // One linear layer on the wave's 32 columns: NT output tiles x KG k-groups, A from the ring,
-// B from registers through bop(kg, s).  pre(ti) runs before a tile's MFMA chain (e.g. to start
-// loads the epilogue needs) and its result is handed to epi(ti, acc, pre_value), which consumes
-// each finished 32x32 tile.  `g0` = chunk index of the layer's first block (a multiple of NSLOT).
+// B from registers through bop(kg, s).  Tiles run in PAIRS on two independent accumulator chains whose
+// MFMAs alternate (see mlp_layout.h), the stream holding the pair's blocks interleaved.  pre(ti) runs
+// before a tile's chain (e.g. to start loads the epilogue needs) and its result is handed to
+// epi(ti, acc, pre_value), which consumes each finished 32x32 tile.  `g0` = chunk index of the layer's
+// first block (a multiple of NSLOT).
 template <int NT, int KG, bool LAST, class BOp, class Pre, class Epi>
-__device__ __forceinline__ void run_layer(const Stream &st, int g0, f32x4 &a, BOp bop, Pre pre, Epi epi,
+__device__ __forceinline__ void run_layer(const Stream &st, int g0, APair32 &a, BOp bop, Pre pre, Epi epi,
                                           int total_chunks = TOTAL_CHUNKS) {
-    // Two accumulator tiles alternate and the epilogue of tile ti-1 is issued two blocks into tile
-    // ti: its accumulator is long complete by then, so no MFMA->read wait states are needed and its
-    // VALU work hides under the dependency-paced MFMA chain of the current tile.
+    static_assert(NT % 2 == 0, "tiles are consumed in pairs");
+    // Two pairs of accumulator tiles alternate and the epilogues of pair P-1 are issued two k-groups into
+    // pair P: their accumulators are long complete by then, so no MFMA->read wait states are needed and
+    // the VALU work hides under the MFMA chains of the current pair.
     using PV = decltype(pre(ic<0>{}));
-    f32x16 accs[2];
-    PV pvs[2];
-    static_for<NT>([&](auto ti) {
-        constexpr int T = decltype(ti)::value;
-        pvs[T & 1] = pre(ti);
-        f32x16 &acc = accs[T & 1];
+    f32x16 accs[4];
+    PV pvs[4];
+    static_for<NT / 2>([&](auto pi) {
+        constexpr int P = decltype(pi)::value;
+        constexpr int S = 2 * (P & 1);
+        pvs[S] = pre(ic<2 * P>{});
+        pvs[S + 1] = pre(ic<2 * P + 1>{});
+        f32x16 &acc0 = accs[S], &acc1 = accs[S + 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         static_for<KG>([&](auto kg) {
-            constexpr int bi = T * KG + decltype(kg)::value;
-            constexpr bool last_block = LAST && (bi == NT * KG - 1);
-            if constexpr (bi % CHUNK_BLOCKS == 0)
-                st.issue_chunk(g0 + bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT, total_chunks);
-            f32x4 an = a;
-            if constexpr (!last_block) an = st.template read_block<bi + 1>();
-            acc = mfma(a[0], bop(kg, ic<0>{}), acc);
-            acc = mfma(a[1], bop(kg, ic<1>{}), acc);
-            acc = mfma(a[2], bop(kg, ic<2>{}), acc);
-            acc = mfma(a[3], bop(kg, ic<3>{}), acc);
-            if constexpr (bi % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
+            constexpr int bi = P * 2 * KG + 2 * decltype(kg)::value;          // blocks bi (tile 2P), bi+1 (tile 2P+1)
+            constexpr bool last_step = LAST && (bi + 1 == NT * KG - 1);
+            acc0 = mfma(a.x[0], bop(kg, ic<0>{}), acc0);
+            acc1 = mfma(a.y[0], bop(kg, ic<0>{}), acc1);
+            // The next step's two A operands are read HERE, six MFMAs (384 cycles) ahead of their use, and pinned
+            // by scheduling barriers: left to itself the scheduler sinks the reads to just before the next
+            // step's first MFMA (s_waitcnt lgkmcnt(0) right behind them), and issued at the very top of the step
+            // the compiler's wait for the CURRENT operands (lgkmcnt(0)) would cover them as well.
+            __builtin_amdgcn_sched_barrier(0);
+            APair32 an = a;
+            if constexpr (!last_step) an = APair32{st.template read_block<bi + 2>(), st.template read_block<bi + 3>()};
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = mfma(a.x[1], bop(kg, ic<1>{}), acc0);
+            acc1 = mfma(a.y[1], bop(kg, ic<1>{}), acc1);
+            if constexpr ((bi % CHUNK_BLOCKS) / 2 < 4) {         // chunk g+2, one piece in each of the first 4 steps of chunk g
+                st.issue_piece(g0 + bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT, (bi % CHUNK_BLOCKS) / 2,
+                               total_chunks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc0 = mfma(a.x[2], bop(kg, ic<2>{}), acc0);
+            acc1 = mfma(a.y[2], bop(kg, ic<2>{}), acc1);
+            acc0 = mfma(a.x[3], bop(kg, ic<3>{}), acc0);
+            acc1 = mfma(a.y[3], bop(kg, ic<3>{}), acc1);
+#ifdef MVIP_EXPERIMENT_NO_BARRIER          // timing experiment only: results are wrong without the barrier
+            if constexpr ((bi + 1) % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __builtin_amdgcn_s_waitcnt(0);
+#else
+            if constexpr ((bi + 1) % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
+#endif
             a = an;
-            if constexpr (decltype(kg)::value == 1 && T > 0) epi(ic<T - 1>{}, accs[(T - 1) & 1], pvs[(T - 1) & 1]);
+            if constexpr (decltype(kg)::value == 1 && P > 0) {
+                constexpr int Q = 2 * ((P - 1) & 1);
+                epi(ic<2 * P - 2>{}, accs[Q], pvs[Q]);
+                epi(ic<2 * P - 1>{}, accs[Q + 1], pvs[Q + 1]);
+            }
         });
     });
-    epi(ic<NT - 1>{}, accs[(NT - 1) & 1], pvs[(NT - 1) & 1]);
+    constexpr int Q = 2 * ((NT / 2 - 1) & 1);
+    epi(ic<NT - 2>{}, accs[Q], pvs[Q]);
+    epi(ic<NT - 1>{}, accs[Q + 1], pvs[Q + 1]);
 }
 struct NoPre { template <class T> __device__ __forceinline__ int operator()(T) const { return 0; } };
 

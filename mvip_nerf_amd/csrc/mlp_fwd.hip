@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(
     MVIP_STAMP(0);                                    // inputs loaded + encoded
     __syncthreads();                                  // chunks 0,1 and section B have landed
     const float *sb = lds + RING_FLOATS;
-    f32x4 a = st.first_block();
+    APair32 a = st.first_pair();
     MVIP_STAMP(1);                                    // weight ring primed
 
     f32x16 h[8], o[8];

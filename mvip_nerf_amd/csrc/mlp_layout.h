@@ -12,12 +12,26 @@
 // of a K=2 MFMA step therefore contributes input units {32t+8q+s (h=0), 32t+8q+s+4 (h=1)};
 // the block layout above is exactly the matching A operand.  Activations never leave registers.
 //
+// Order of the blocks of one layer in the stream: output tiles are consumed in PAIRS -- blocks of tiles
+// (2P, 2P+1) alternate, k-group by k-group -- so that a wave runs two independent accumulator chains, reads
+// both A operands of a step with one pair of LDS reads and has eight MFMAs (512 cycles) between barriers,
+// DMA issues and operand waits.  (Measured effect on the forward: 0.6 %; tools/micro/mfma_rate.hip shows the
+// matrix pipe itself sustains 64.0 cycles per fp32 32x32x2 MFMA for dependent and independent chains alike.)
+//
 // Section B -- small vectors (biases, the 256->1 sigma row, the 128->3 rgb rows), natural order.
 #pragma once
 
 namespace mvip { namespace mlp {
 
 constexpr int BLOCK_FLOATS = 256;
+
+// position of block (tile ti, k-group kg) inside a layer with KG k-groups per tile, and its inverse
+__host__ __device__ constexpr int block_pos(int ti, int kg, int KG) { return (ti >> 1) * (2 * KG) + 2 * kg + (ti & 1); }
+__host__ __device__ inline void block_tile(int local, int KG, int &ti, int &kg) {
+    const int pair = local / (2 * KG), rem = local % (2 * KG);
+    kg = rem >> 1;
+    ti = 2 * pair + (rem & 1);
+}
 constexpr int CHUNK_BLOCKS = 16;                         // 16 KB staged per barrier
 constexpr int CHUNK_FLOATS = CHUNK_BLOCKS * BLOCK_FLOATS;
 

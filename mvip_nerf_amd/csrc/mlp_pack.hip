@@ -16,7 +16,7 @@ __device__ __forceinline__ void packed_source(int idx, int &param, int &off) {
         const int h = r / 128, i = (r % 128) / 4, s = r % 4;
         int local, kgn, ti, kg;
         if (blk < OFF_L1) {
-            local = blk; kgn = L0_KG; ti = local / kgn; kg = local % kgn;
+            local = blk; kgn = L0_KG; block_tile(local, kgn, ti, kg);
             const int k = 8 * kg + 4 * h + s, row = 32 * ti + i;
             if (k < 63) { param = P_W0; off = row * 63 + k; }
         } else if (blk < OFF_L5 || (blk >= OFF_L6 && blk < OFF_VIEWS)) {
@@ -24,17 +24,17 @@ __device__ __forceinline__ void packed_source(int idx, int &param, int &off) {
             if (blk < OFF_L5) { layer = 1 + (blk - OFF_L1) / LH_BLOCKS; local = (blk - OFF_L1) % LH_BLOCKS; }
             else if (blk < OFF_FEAT) { layer = 6 + (blk - OFF_L6) / LH_BLOCKS; local = (blk - OFF_L6) % LH_BLOCKS; }
             else { layer = -1; local = blk - OFF_FEAT; }
-            ti = local / LH_KG; kg = local % LH_KG;
+            block_tile(local, LH_KG, ti, kg);
             const int k = 8 * kg + 4 * h + s, row = 32 * ti + i;
             param = layer >= 0 ? 2 * layer : P_WF;
             off = row * 256 + k;
         } else if (blk < OFF_L6) {
-            local = blk - OFF_L5; ti = local / L5_KG; kg = local % L5_KG;
+            local = blk - OFF_L5; block_tile(local, L5_KG, ti, kg);
             const int k = 8 * kg + 4 * h + s, row = 32 * ti + i;
             if (k < 63) { param = 2 * 5; off = row * 319 + k; }
             else if (k >= 64) { param = 2 * 5; off = row * 319 + 63 + (k - 64); }
         } else {
-            local = blk - OFF_VIEWS; ti = local / LV_KG; kg = local % LV_KG;
+            local = blk - OFF_VIEWS; block_tile(local, LV_KG, ti, kg);
             const int k = 8 * kg + 4 * h + s, row = 32 * ti + i;
             if (k < 283) { param = P_WV; off = row * 283 + k; }
         }
