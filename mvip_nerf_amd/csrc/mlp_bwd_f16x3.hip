@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_f16x3_kernel(
     const bool live = pl < p_count;
 
     StreamF st{img_t, lds, wave, lane, T16_TOTAL_BLOCKS};
+    st.init_bases();
     for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 4)
         glds16(secb + b * BLOCK_FLOATS + lane * 4, lds + F_RING_FLOATS + b * BLOCK_FLOATS);
     st.issue_group(0);

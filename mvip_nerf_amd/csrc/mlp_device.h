@@ -31,6 +31,14 @@ __device__ __forceinline__ void glds16(const float *src_lane, float *dst_wave) {
                                      (__attribute__((address_space(3))) void *)dst_wave, 16, 0, 0);
 }
 
+// the same with an immediate byte offset that the instruction adds to BOTH addresses: the four 1-KB pieces a
+// wave stages per chunk share one address computation and one M0 write
+template <int OFF>
+__device__ __forceinline__ void glds16o(const float *src_lane, float *dst_wave) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                     (__attribute__((address_space(3))) void *)dst_wave, 16, OFF, 0);
+}
+
 // The weight stream: section A of a packed image consumed front to back through the LDS ring.
 // Protocol (g = chunk being computed): loads of chunk g+2 are issued at the first block of
 // chunk g; the __syncthreads at the end of chunk g (which waits vmcnt(0)) makes chunk g+2
@@ -47,17 +55,11 @@ struct Stream {
         if (g < total_chunks) {
             const float *src = packed + (int64_t)g * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS) + lane * 4;
             float *dst = lds + slot * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+            glds16o<0>(src, dst);
+            glds16o<1024>(src, dst);
+            glds16o<2048>(src, dst);
+            glds16o<3072>(src, dst);
         }
-    }
-    // one quarter of issue_chunk: the q-th of this wave's four 1-KB pieces.  run_layer issues the four pieces
-    // in four different MFMA gaps rather than back to back (tools/micro/mfma_lds.hip: LDS-DMA issue costs
-    // ~1.9 cycles per MFMA in an otherwise 64.0-cycle loop, the per-chunk barrier another ~1.1).
-    __device__ __forceinline__ void issue_piece(int g, int slot, int q, int total_chunks = TOTAL_CHUNKS) const {
-        if (g < total_chunks)
-            glds16(packed + (int64_t)g * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS) + lane * 4 + q * BLOCK_FLOATS,
-                   lds + slot * CHUNK_FLOATS + wave * (4 * BLOCK_FLOATS) + q * BLOCK_FLOATS);
     }
     __device__ __forceinline__ void load_section_b(const float *secb) const {
         for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 4)
@@ -122,9 +124,8 @@ __device__ __forceinline__ void run_layer(const Stream &st, int g0, APair32 &a, 
             __builtin_amdgcn_sched_barrier(0);
             acc0 = mfma(a.x[1], bop(kg, ic<1>{}), acc0);
             acc1 = mfma(a.y[1], bop(kg, ic<1>{}), acc1);
-            if constexpr ((bi % CHUNK_BLOCKS) / 2 < 4) {         // chunk g+2, one piece in each of the first 4 steps of chunk g
-                st.issue_piece(g0 + bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT, (bi % CHUNK_BLOCKS) / 2,
-                               total_chunks);
+            if constexpr (bi % CHUNK_BLOCKS == 0) {              // chunk g+2 is staged during the first step of chunk g
+                st.issue_chunk(g0 + bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT, total_chunks);
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc0 = mfma(a.x[2], bop(kg, ic<2>{}), acc0);
@@ -151,16 +152,34 @@ __device__ __forceinline__ void run_layer(const Stream &st, int g0, APair32 &a, 
 struct NoPre { template <class T> __device__ __forceinline__ int operator()(T) const { return 0; } };
 
 // accumulator tile (+ bias row, natural unit order) -> activation tile
+// The epilogue is VALU work squeezed between MFMAs (tools/clock_probe.py: ~450 cycles per tile, 60 % of the
+// kernel's non-MFMA time when ReLU was compare + select), so it is kept to the fewest instructions: packed
+// fp32 adds (v_pk_add_f32, two elements each) and ReLU as ONE integer max: for IEEE floats max_i32(bits, 0)
+// is x for x > 0, +0 for x <= -0 and keeps a (positive-sign) NaN a NaN like x < 0 ? 0 : x does.
 template <bool RELU>
 __device__ __forceinline__ f32x16 bias_relu(const f32x16 &acc, const float *bias32, int hh) {
+#ifdef MVIP_EXPERIMENT_NO_EPILOGUE         // timing experiment only
+    return acc;
+#endif
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x16 r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 b = *reinterpret_cast<const f32x4 *>(bias32 + 8 * q + 4 * hh);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float x = acc[4 * q + s] + b[s];
-            r[4 * q + s] = RELU ? (x < 0.f ? 0.f : x) : x;
+        for (int s = 0; s < 4; s += 2) {
+            const f32x2 a2 = {acc[4 * q + s], acc[4 * q + s + 1]};
+            const f32x2 b2 = {b[s], b[s + 1]};
+            const f32x2 x = a2 + b2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = x[e];
+                if (RELU) {
+                    const int bits = __builtin_bit_cast(int, v);
+                    v = __builtin_bit_cast(float, bits > 0 ? bits : 0);
+                }
+                r[4 * q + s + e] = v;
+            }
         }
     }
     return r;

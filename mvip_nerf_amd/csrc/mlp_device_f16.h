@@ -22,20 +22,45 @@ struct StreamF {
     float *lds;
     int wave, lane;
     int total_blocks = TOTAL_BLOCKS;
-    // issue the 64 blocks of barrier group g into ring half (g & 1): 16 blocks per wave
+    // issue the 64 blocks of barrier group g into ring half (g & 1): wave w stages the 16 consecutive blocks
+    // 16w .. 16w+15 as four runs of four, each run sharing one address computation and one M0 write through the
+    // instruction's immediate offset (every extra SALU/VALU instruction costs this single-wave-per-SIMD kernel
+    // ~4 cycles of matrix-pipe idle time)
     __device__ __forceinline__ void issue_group(int g) const {
         if (g * F_GROUP_BLOCKS < total_blocks) {
             const int nblk = (total_blocks - g * F_GROUP_BLOCKS) < F_GROUP_BLOCKS ? (total_blocks - g * F_GROUP_BLOCKS)
                                                                                  : F_GROUP_BLOCKS;
-            const float *src = img + (int64_t)g * F_GROUP_BLOCKS * BLOCK_FLOATS + lane * 4;
-            float *dst = lds + (g & 1) * (F_GROUP_BLOCKS * BLOCK_FLOATS);
-            for (int b = wave; b < nblk; b += 4) glds16(src + b * BLOCK_FLOATS, dst + b * BLOCK_FLOATS);
+            const float *src = img + (int64_t)g * F_GROUP_BLOCKS * BLOCK_FLOATS + wave * (16 * BLOCK_FLOATS) + lane * 4;
+            float *dst = lds + (g & 1) * (F_GROUP_BLOCKS * BLOCK_FLOATS) + wave * (16 * BLOCK_FLOATS);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (wave * 16 + 4 * c < nblk) {              // groups are whole multiples of 4 blocks
+                    glds16o<0>(src + c * 4 * BLOCK_FLOATS, dst + c * 4 * BLOCK_FLOATS);
+                    glds16o<1024>(src + c * 4 * BLOCK_FLOATS, dst + c * 4 * BLOCK_FLOATS);
+                    glds16o<2048>(src + c * 4 * BLOCK_FLOATS, dst + c * 4 * BLOCK_FLOATS);
+                    glds16o<3072>(src + c * 4 * BLOCK_FLOATS, dst + c * 4 * BLOCK_FLOATS);
+                }
+            }
         }
+    }
+    // The 128 KB ring is wider than ds_read's 16-bit immediate offset.  Left alone the compiler materialises a
+    // separate address for every block of the upper half (and parks those addresses in AGPRs): two extra
+    // instructions per operand read.  `hi` is the lane's address in the upper half made opaque to the
+    // optimiser, so every read is `ds_read_b128 v, base offset:imm` off one of two live registers.
+    unsigned hi_addr = 0;
+    __device__ __forceinline__ void init_bases() {
+        unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)(lds + F_GROUP_BLOCKS * BLOCK_FLOATS) + lane * 16;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(hi_addr) : "v"(a));
     }
     template <int BLK>      // BLK = absolute block index in the stream (compile time)
     __device__ __forceinline__ h16x8 read_block() const {
-        constexpr int off = (BLK % (2 * F_GROUP_BLOCKS)) * BLOCK_FLOATS;
-        return *reinterpret_cast<const h16x8 *>(lds + off + lane * 4);
+        constexpr int blk = BLK % (2 * F_GROUP_BLOCKS);
+        if constexpr (blk < F_GROUP_BLOCKS) {
+            return *reinterpret_cast<const h16x8 *>(lds + blk * BLOCK_FLOATS + lane * 4);
+        } else {
+            typedef __attribute__((address_space(3))) const h16x8 *lds_ptr;
+            return *(lds_ptr)(uintptr_t)(hi_addr + (blk - F_GROUP_BLOCKS) * (BLOCK_FLOATS * 4));
+        }
     }
 };
 
@@ -46,6 +71,8 @@ __device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
 struct Frag { h16x8 hi[2], lo[2]; };            // one 32-unit activation tile as B operands (k-steps 0,1)
 
 __device__ __forceinline__ Frag split_tile(const f32x16 &x) {
+    // (a v_fma_mix_f32 per element for the residual was tried: fewer conversions, but the register allocator
+    //  answered with more AGPR<->VGPR moves and the kernel got 3 % slower)
     Frag f;
 #pragma unroll
     for (int s = 0; s < 2; ++s)

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
     };
 
     StreamF st{img, lds, wave, lane, TOTAL_BLOCKS};
+    st.init_bases();
     for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 4)        // section B (fp32 small vectors)
         glds16(img + SEC_A_FLOATS + b * BLOCK_FLOATS + lane * 4, lds + F_RING_FLOATS + b * BLOCK_FLOATS);
     st.issue_group(0);
