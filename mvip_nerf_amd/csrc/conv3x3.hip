@@ -30,8 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CV_TH = 8, CV_TW = 32;
 constexpr int CV_HW = CV_TW + 2;                    // haloed tile width
 constexpr int CV_PIX = (CV_TH + 2) * CV_HW;         // 340 haloed pixels
-constexpr int CV_IN_ROUNDS = 6;                     // 4 planes x 340 = 1360 slots, padded to 6 x 256
-constexpr int CV_IN_BYTES = CV_IN_ROUNDS * 256 * 16;
+constexpr int CV_IN_ROUNDS = 6;                     // 4 planes x 340 = 1360 slots in 6 rounds of 256 lanes (last one partial)
+constexpr int CV_IN_BYTES = 4 * CV_PIX * 16;        // 21,760 B
 
 __device__ __forceinline__ void glds16b(const void *src_lane, void *dst_wave) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
@@ -208,11 +208,13 @@ struct ConvArgs {
     int N, CK, Cout, H, W, tilesX, tilesY, MB;
 };
 
+// MT <= 2: 80 KB of LDS and 256 registers, i.e. TWO workgroups per CU = two waves per SIMD, so one wave's LDS
+// reads, waits and epilogue run under the other wave's MFMAs.
 template <int MT>
-__global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(const ConvArgs a) {
     constexpr int WB = 3 * MT * 2 * 1024;              // weights of one stage (kernel row, 16 channels)
-    __shared__ __attribute__((aligned(16))) char lds[2 * WB + 2 * CV_IN_BYTES];
-    char *lds_w = lds, *lds_in = lds + 2 * WB;
+    __shared__ __attribute__((aligned(16))) char lds[3 * WB + 2 * CV_IN_BYTES];
+    char *lds_w = lds, *lds_in = lds + 3 * WB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kg = lane >> 5;
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < CV_IN_ROUNDS; ++r) {
         const int s = r * 256 + tid;
-        in_off[r] = -1;
+        in_off[r] = s < 4 * CV_PIX ? -1 : -2;          // -1: halo outside the image (zero page), -2: no slot
         if (s < 4 * CV_PIX) {
             const int piece = s / CV_PIX, p = s - piece * CV_PIX;
             const int row = p / CV_HW, col = p - row * CV_HW;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
         char *dst = lds_in + buf * CV_IN_BYTES + wave * 1024;
 #pragma unroll
         for (int r = 0; r < CV_IN_ROUNDS; ++r)
-            glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * 4096);
+            if (in_off[r] != -2) glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * 4096);
     };
     auto issue_weights = [&](int t, int buf) {
         const char *src = wp_b + (int64_t)t * WROW + lane * 16;
@@ -272,37 +274,75 @@ __global__ void __launch_bounds__(256) conv3x3_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
+    // Software pipeline.  A "group" = one tap (kx) of one 32-channel output row block m: two A fragments (hi, lo),
+    // the tap's four B fragments, six MFMAs on two independent accumulators.  Fragments are read from LDS TWO
+    // groups ahead of their use, right after the first pair of MFMAs of a group and pinned there by scheduling
+    // barriers: this kernel runs one wave per SIMD, so nothing hides an exposed LDS latency (the first version
+    // read, waited and multiplied group by group and kept the matrix pipe 34 % busy).  Weights are staged TWO
+    // stages ahead in three LDS buffers so that the next stage's fragments can be read before the barrier.
+    constexpr int NG = 3 * MT;                          // groups per stage, kx-major
     const int nstage = a.CK * 3;
+    const int jrow0 = 2 * wave;
+    h16x8 Ah[3], Al[3];                                 // set = group % 3  (NG % 3 == 0: the rotation survives stages)
+    h16x8 Bh[3][2], Bl[3][2];                           // set = kx
+    auto load_a = [&](const char *wb, int g, int set) {
+        const int kx = g / MT, m = g % MT;
+        Ah[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
+        Al[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
+    };
+    auto load_b = [&](const char *inb, int ky, int kx) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = (jrow0 + j + ky) * CV_HW + l32 + kx;
+            Bh[kx][j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
+            Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + CV_PIX * 16 + p * 16);
+        }
+    };
+    auto w_base = [&](int t) { return lds_w + (t % 3) * WB + lane * 16; };
+    auto in_base = [&](int t) { return lds_in + ((t / 3) & 1) * CV_IN_BYTES + (kg * 2) * (CV_PIX * 16); };
+
     issue_input(0, 0);
     issue_weights(0, 0);
-    const int jrow0 = 2 * wave;
+    if (nstage > 1) issue_weights(1, 1);
+    __syncthreads();                                    // stages 0 and 1 (and input chunk 0) have landed
+    if (nstage > 2) issue_weights(2, 2);
+    if (a.CK > 1) issue_input(1, 1);
+    load_b(in_base(0), 0, 0);
+    load_a(w_base(0), 0, 0);
+    if (NG > 1) load_a(w_base(0), 1, 1);
+    if (MT == 1) load_b(in_base(0), 0, 1);
     for (int t = 0; t < nstage; ++t) {
         const int ck = t / 3, ky = t - ck * 3;
-        __syncthreads();                       // stage t landed (vmcnt(0)); every wave is done with stage t-1
-        if (t + 1 < nstage) issue_weights(t + 1, (t + 1) & 1);
-        if (ky == 0 && ck + 1 < a.CK) issue_input(ck + 1, (ck + 1) & 1);
-        const char *inb = lds_in + (ck & 1) * CV_IN_BYTES + (kg * 2) * (CV_PIX * 16);
-        const char *wb = lds_w + (t & 1) * WB + lane * 16;
+        if (t > 0) {
+            __syncthreads();                   // stage t+1 landed (vmcnt(0)); every wave is done with stage t-1
+            if (t + 2 < nstage) issue_weights(t + 2, (t + 2) % 3);
+            if (ky == 0 && ck + 1 < a.CK) issue_input(ck + 1, (ck + 1) & 1);
+        }
+        const char *wb = w_base(t), *inb = in_base(t);
+        const char *wb_n = w_base(t + 1), *inb_n = in_base(t + 1);
+        const int ky_n = (ky == 2) ? 0 : ky + 1;
+        const bool more = t + 1 < nstage;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            h16x8 bh[2], bl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int p = (jrow0 + j + ky) * CV_HW + l32 + kx;
-                bh[j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
-                bl[j] = *reinterpret_cast<const h16x8 *>(inb + CV_PIX * 16 + p * 16);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const h16x8 ah = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
-                const h16x8 al = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[m][j], 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+            const int kx = g / MT, m = g % MT, set = g % 3;
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][1], acc[m][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // fragments of group g+2 (this stage or the next one)
+                const int g2 = g + 2;
+                if (g2 < NG) {
+                    load_a(wb, g2, g2 % 3);
+                    if (g2 % MT == 0) load_b(inb, ky, g2 / MT);
+                } else if (more) {
+                    load_a(wb_n, g2 - NG, g2 % 3);
+                    if ((g2 - NG) % MT == 0) load_b(inb_n, ky_n, (g2 - NG) / MT);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][1], acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][0], acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][1], acc[m][1], 0, 0, 0);
         }
     }
 
@@ -441,8 +481,8 @@ __global__ void __launch_bounds__(256) gemm_f16x3_kernel(const GemmArgs a) {
 static inline int cv_mt(int64_t Cout, int64_t tiles) {
     if (Cout % 32 != 0) return 0;
     const int64_t rows = Cout / 32;
-    for (int mt = 4; mt > 1; mt >>= 1)
-        if (rows % mt == 0 && tiles * (rows / mt) >= 256) return mt;
+    for (int mt = 2; mt > 1; mt >>= 1)                 // MT = 4 (one workgroup per CU) measured slower than two MT = 2
+        if (rows % mt == 0 && tiles * (rows / mt) >= 512) return mt;
     return 1;
 }
 
