@@ -382,7 +382,7 @@ struct GemmArgs {
 };
 
 template <int MT>
-__global__ void __launch_bounds__(256) gemm_f16x3_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(const GemmArgs a) {
     constexpr int WB = GM_KC * MT * 2 * 1024;
     constexpr int IB = GM_KC * 4 * GM_PIX * 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * WB + 2 * IB];
