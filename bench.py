@@ -17,6 +17,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -291,11 +292,13 @@ def main():
             (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
         sds_step(1000)
         barrier()
-        t2 = time.perf_counter()
-        for k in range(args.sds_steps):
+        sds_times = []                        # per-step timing: the leg reports the MEDIAN step (a library
+        for k in range(args.sds_steps):       # autotune or allocator hiccup in one step was seen to cost 600 ms)
+            t2 = time.perf_counter()
             sds_step(1000 + k)
-        barrier()
-        dt_sds = time.perf_counter() - t2
+            barrier()
+            sds_times.append(time.perf_counter() - t2)
+        dt_sds = float(np.median(sds_times)) * args.sds_steps
         opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                     text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                     colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
@@ -355,7 +358,8 @@ def main():
                                           'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
         result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': dt_sds / args.sds_steps * 1e3,
                          'dtype': 'f32 tensors; 3x3 ResNet convolutions on fp16 MFMA in split precision (f16x3, ~1e-6 relative), the rest library fp32',
-                         'what': 'train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
+                         'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
+                         'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
                          '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
         result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
                                     'iterations_per_sec': args.sds_steps / dt_full,
