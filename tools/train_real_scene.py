@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--iters', type=int, default=3000)
 ap.add_argument('--rays', type=int, default=4096)
 ap.add_argument('--train-precision', type=int, default=0)
+ap.add_argument('--tcnn', action='store_true', help='train the hash-grid model (NeRF_TCNN) instead of the 8x256 MLPs')
 ap.add_argument('--oracle-view', type=int, default=1, help='render this many held-out views with the CPU oracle')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -29,7 +30,11 @@ args = types.SimpleNamespace(multires=10, i_embed=0, use_viewdirs=True, multires
                              no_reload=True, perturb=1., N_samples=64, white_bkgd=False, raw_noise_std=1.,
                              dataset_type='llff', no_ndc=True, lindisp=False, sigma_loss=False)
 torch.manual_seed(0)
-tr, te, _, grad_vars, opt = run.create_nerf(args, device=dev)
+if a.tcnn:
+    args.netchunk, args.lrate = 1 << 20, 1e-2
+    tr, te, _, grad_vars, opt = run.create_nerf_tcnn(args, device=dev)
+else:
+    tr, te, _, grad_vars, opt = run.create_nerf(args, device=dev)
 kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
 for _n in (tr['network_fn'], tr['network_fine']):
     _n.train_precision = a.train_precision
@@ -47,7 +52,7 @@ for it in range(a.iters):
     loss.backward()
     opt.step()
     for pg in opt.param_groups:
-        pg['lr'] = 5e-4 * (0.1 ** (it / 250000))
+        pg['lr'] = args.lrate * (0.1 ** (it / 250000))
     if it % 500 == 0 or it == a.iters - 1:
         log.append((it, float(loss)))
         print(it, float(loss), flush=True)
@@ -63,6 +68,12 @@ with torch.no_grad():
         renders.append(rgb)
         psnr_hip.append(float(mse2psnr(img2mse(rgb, images[v]))))
 res['psnr_heldout_hip'] = psnr_hip
+if a.tcnn:
+    res['model'] = 'NeRF_TCNN (hash grid)'
+    print(json.dumps(res))
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'real_scene_r1_tcnn.json'), 'w'), indent=1)
+    sys.exit(0)
 # the same trained weights rendered by the CPU oracle (the reference restatement)
 from oracle import nerf_oracle as O
 pc = {k: p.detach().cpu() for k, p in tr['network_fn'].named_parameters()}
