@@ -327,7 +327,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
         # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
-        # collaborative SDS over <=5 neighbour views); NeRF kernels at train_precision=1
+        # collaborative SDS over <=5 neighbour views); NeRF kernels in split precision (train_ and inference_precision = 1)
         for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
             a2 = make_args()
             a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
@@ -336,7 +336,7 @@ def main():
             tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
                                      rank=rank, dist=dist)
             for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
-                n.train_precision = 1
+                n.train_precision = n.inference_precision = 1       # split precision for every NeRF kernel of the step
             tr2.step(1000)
             barrier()
             t5 = time.perf_counter()
