@@ -1,7 +1,7 @@
 """Sustained shader clock and cycles per workgroup of the fused MLP forward (diagnostic entry point)."""
 import ctypes, sys, json
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvip_nerf_amd import ops, _lib
 import bench
 dev = torch.device('cuda', 0)

@@ -1,5 +1,5 @@
 import sys, json, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mvip_nerf_amd import ops, run
 dev = torch.device('cuda', 0)

@@ -2,7 +2,7 @@
 HBM3E peak (6.3 TB/s achievable per MI355X_MICROARCH.md).  One JSON object per kernel."""
 import json, sys, time
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvip_nerf_amd import ops
 
 PEAK = 8000.0  # GB/s

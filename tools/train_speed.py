@@ -1,5 +1,5 @@
 import sys, json, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
 dev = torch.device('cuda', 0)
