@@ -133,7 +133,10 @@ def mlp_unpack_grads(grad_packed, like):
 
 
 _WORKSPACE = {}
-BWD_TILE_POINTS = 65536          # points per recompute/backward tile (1.3 GB of stash workspace)
+import os as _os
+# points per backward tile: delta + weight-gradient launches per tile, 20 KB of G/activation workspace per point
+# (5.2 GB at 262,144; 65,536-point tiles were 3-4 % slower: per-launch tail and gradient flush)
+BWD_TILE_POINTS = int(_os.environ.get('MVIP_BWD_TILE_POINTS', 262144))
 
 
 def _zero_grads(device):
