@@ -377,3 +377,34 @@ def test_mlp_backward_f16x3_golden(golden, cuda):
         (raw * T(g['gout'], cuda)).sum().backward()
         _check_grads(g, '', {k: p.grad for k, p in zip(ops.PARAM_ORDER, ps)}, 2e-5, 2e-4)
     ops.STASH_BUDGET_BYTES = 96 << 30
+
+
+def test_empty_and_ragged_inputs(cuda, golden):
+    """Zero-size batches are legal through every entry point (empty tensors out, no launch), and ragged
+    point counts (not a multiple of the 32-point wave tile / 128-point workgroup) give the same values as
+    the same points inside a full batch."""
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    ps = params_dev(g['seed'], cuda)
+    packed = ops.mlp_pack(ps)
+    z0 = torch.zeros(0, 64, device=cuda)
+    rows0 = torch.zeros(0, 11, device=cuda)
+    assert ops.stratified_z(rows0, 64, True).shape == (0, 64)
+    assert ops.mlp_rays(rows0, z0, packed, ps).shape == (0, 64, 4)
+    assert ops.mlp_points(torch.zeros(0, 3, device=cuda), torch.zeros(0, 3, device=cuda), packed, ps).shape == (0, 4)
+    assert ops.posenc(torch.zeros(0, 3, device=cuda), 10).shape == (0, 63)
+    out = ops.composite(torch.zeros(0, 64, 4, device=cuda), z0, torch.zeros(0, 6, device=cuda))
+    assert out[0].shape == (0, 3) and out[3].shape == (0, 64)
+    s, zm, zs, _, _ = ops.sample_pdf_merge(z0, torch.zeros(0, 64, device=cuda), torch.zeros(0, 64, device=cuda))
+    assert s.shape == (0, 64) and zm.shape == (0, 128) and zs.shape[0] == 0
+    from mvip_nerf_amd.run_nerf_helpers_tcnn import level_table
+    tab, n = level_table(100)
+    f = ops.hashgrid_encode(torch.zeros(0, 3, device=cuda), torch.zeros(2 * n, device=cuda),
+                            torch.from_numpy(tab.copy()).to(cuda), 100.0)
+    assert f.shape == (32, 0)
+    # ragged point counts
+    pts, dirs = T(g['pts'], cuda), T(g['dirs'], cuda)
+    full = ops.mlp_points(pts, dirs, packed, ps)
+    for n_ in (1, 31, 33, 127, 129, 200):
+        part = ops.mlp_points(pts[:n_].contiguous(), dirs[:n_].contiguous(), packed, ps)
+        np.testing.assert_array_equal(N(part), N(full[:n_]))
