@@ -84,6 +84,48 @@ __global__ void stratified_z_kernel(const float *__restrict__ rows, int ncols, i
     z[i] = lower + (upper - lower) * t_rand[i];
 }
 
+// Four consecutive samples of one ray per thread (S % 4 == 0): the two per-ray reciprocals are taken once and
+// the six depths a perturbed quad needs (s-1 .. s+4) cost six divides instead of 36 -- the one-sample kernel is
+// bound by IEEE divides (0.2 of HBM).  Same expressions in the same order as z_at, so results are identical.
+__global__ void stratified_z4_kernel(const float *__restrict__ rows, int ncols, int64_t B, int S,
+                                     const float *__restrict__ t_vals, int lindisp,
+                                     const float *__restrict__ t_rand, float *__restrict__ z) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // quad index
+    const int Q = S / 4;
+    if (q >= B * Q) return;
+    const int64_t r = q / Q;
+    const int s0 = (int)(q % Q) * 4;
+    const float near = rows[r * ncols + 6], far = rows[r * ncols + 7];
+    const float inear = 1.f / near, ifar = 1.f / far;
+    auto at = [&](int s) {
+        const float t = t_vals[s];
+        if (lindisp) return 1.f / (inear * (1.f - t) + ifar * t);
+        return near * (1.f - t) + far * t;
+    };
+    float zc[6];                                             // samples s0-1 .. s0+4 (clamped at the ends)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int s = s0 - 1 + k;
+        s = s < 0 ? 0 : (s > S - 1 ? S - 1 : s);
+        zc[k] = (t_rand || (k >= 1 && k <= 4)) ? at(s) : 0.f;
+    }
+    float4 out;
+    float *o = &out.x;
+    float4 tr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_rand) tr = *reinterpret_cast<const float4 *>(t_rand + r * S + s0);
+    const float *trp = &tr.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = s0 + k;
+        const float c = zc[k + 1];
+        if (!t_rand) { o[k] = c; continue; }
+        const float upper = s < S - 1 ? .5f * (zc[k + 2] + c) : c;
+        const float lower = s > 0 ? .5f * (c + zc[k]) : c;
+        o[k] = lower + (upper - lower) * trp[k];
+    }
+    *reinterpret_cast<float4 *>(z + r * S + s0) = out;
+}
+
 // run_nerf_helpers.py:27-52: channel c<3: x[c]; else m=c-3: octave m/6, fn (m%6)/3, dim m%3
 __global__ void posenc_kernel(const float *__restrict__ x, int64_t N, int L, float *__restrict__ y) {
     const int C = 3 + 6 * L;
@@ -141,8 +183,13 @@ extern "C" int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S,
                                  int lindisp, const float *t_rand, float *z, void *stream) {
     if (B < 0 || S <= 0 || ncols < 8 || !t_vals || (B > 0 && (!rows || !z))) return MVIP_EINVAL;
     if (B == 0) return MVIP_OK;
-    hipLaunchKernelGGL(stratified_z_kernel, dim3(blocks_for(B * S, 256)), dim3(256), 0, as_stream(stream), rows,
-                       ncols, B, S, t_vals, lindisp, t_rand, z);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(t_rand)) & 15) == 0;
+    if (S % 4 == 0 && aligned)
+        hipLaunchKernelGGL(stratified_z4_kernel, dim3(blocks_for(B * (S / 4), 256)), dim3(256), 0, as_stream(stream),
+                           rows, ncols, B, S, t_vals, lindisp, t_rand, z);
+    else
+        hipLaunchKernelGGL(stratified_z_kernel, dim3(blocks_for(B * S, 256)), dim3(256), 0, as_stream(stream), rows,
+                           ncols, B, S, t_vals, lindisp, t_rand, z);
     return check_launch();
 }
 

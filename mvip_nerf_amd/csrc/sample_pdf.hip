@@ -30,10 +30,59 @@ __device__ __forceinline__ float strided_get(const float (&v)[IT], int e) {
 
 // bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
 // Produces samples (strided) and inds; cdf_out strided (nb entries).
+// Up to 64 bins (the reference configuration: 63 midpoints of 64 coarse samples): everything in one register
+// per lane.  The normaliser is an fp64 butterfly sum, the CDF an fp64 Hillis-Steele scan rounded to fp32 per
+// entry (torch's CPU cumsum accumulates in fp64 in index order; a different summation ORDER changes the fp64
+// value by ~1e-16 relative, i.e. the rounded fp32 entry in ~1 of 1e8 cases), and searchsorted(right=True) is a
+// six-step binary search on cross-lane reads of the sorted CDF.  ~150 instructions per ray instead of ~2000.
+// Returns false (nothing written) if some pdf entry is negative: the CDF is then not sorted and the caller
+// takes the index-ordered path.
+__device__ __forceinline__ bool inverse_cdf_fast(const float bins, const float wts, int nb, const float u,
+                                                 float &sample, int &ind, float &cdf_out) {
+    const int l = lane_id();
+    const int nw = nb - 1;
+    const float w5 = wts + 1e-5f;
+    double tot = l < nw ? (double)w5 : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const float total = (float)tot;
+    const float pdf = l < nw ? w5 / total : 0.f;
+    if (__any(pdf < 0.f)) return false;
+    double run = (double)pdf;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(run, o, 64); if (l >= o) run += t; }
+    const float incl = (float)run;                              // cdf[l + 1]
+    const float up = __shfl_up(incl, 1, 64);
+    const float cdf = l == 0 ? 0.f : up;                        // cdf[l], valid for l < nb
+    const float key = l < nb ? cdf : INFINITY;
+    int cnt = 0;                                                // #{k < nb : cdf[k] <= u}
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int probe = cnt + step;
+        const float c = __shfl(key, (probe - 1) & 63, 64);
+        if (probe <= 64 && c <= u) cnt = probe;
+    }
+    const float c63 = __shfl(key, 63, 64);                      // the steps sum to at most 63: one more probe for 64
+    if (cnt == 63 && c63 <= u) cnt = 64;
+    const int below = max(0, cnt - 1), above = min(nb - 1, cnt);
+    const float cb = __shfl(cdf, below, 64), ca = __shfl(cdf, above, 64);
+    const float bb = __shfl(bins, below, 64), ba = __shfl(bins, above, 64);
+    float den = ca - cb;
+    den = den < 1e-5f ? 1.f : den;
+    const float t = (u - cb) / den;
+    sample = bb + t * (ba - bb);
+    ind = cnt;
+    cdf_out = cdf;
+    return true;
+}
+
 template <int IT>
 __device__ __forceinline__ void inverse_cdf(const float (&bins)[IT], const float (&wts)[IT], int nb,
                                             const float (&u)[IT], int nf, float (&samples)[IT],
                                             int (&inds)[IT], float (&cdf)[IT]) {
+    if constexpr (IT == 1) {
+        if (inverse_cdf_fast(bins[0], wts[0], nb, u[0], samples[0], inds[0], cdf[0])) return;
+    }
     const int l = lane_id();
     const int nw = nb - 1;
     // weights + 1e-5, total in index order
