@@ -106,6 +106,16 @@ int mvip_mlp_forward_rays(const float *packed, const float *rows, const float *z
 int mvip_mlp_forward_points(const float *packed, const float *pts, const float *dirs, int64_t P,
                             float *raw, int precision, void *stream);
 
+/* Inference-only forward with two waves per SIMD (csrc/mlp_fwd16.hip): 16 points per wave on
+ * v_mfma_f32_16x16x4_f32, exact fp32, same results to rounding as mvip_mlp_forward_* with precision 0.
+ * packed16 (mvip_mlp_packed_floats() floats) = the same weights in the 16-point block order, built from the 24
+ * parameter tensors and the small-vector section of an up-to-date mvip_mlp_pack image. */
+int mvip_mlp_pack16(const float *const *params_host, const float *packed, float *packed16, void *stream);
+int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
+                            float *raw, void *stream);
+int mvip_mlp_forward_points16(const float *packed16, const float *pts, const float *dirs, int64_t P,
+                              float *raw, void *stream);
+
 /* Backward: d_raw [P,4] -> the 24 parameter gradients.  grads_host is a HOST array of 24 device
  * pointers (state-dict order, natural [out][in] shapes) that are ACCUMULATED into with fp32
  * atomics (zero them, or pass .grad buffers).  Inputs are re-encoded and activations recomputed

@@ -1,0 +1,322 @@
+// Inference forward of the 8x256 NeRF MLP with TWO waves per SIMD (exact fp32, v_mfma_f32_16x16x4_f32).
+// STATUS: correct (tests/test_hip_kernels.py) but measured 3 % SLOWER than the tuned one-wave kernel of mlp_fwd.hip
+// (210.8 vs 204.0 ms on the bench's fine pass; staggering the SIMD partners' epilogues made it 218 ms), so the
+// NeRF module does not use it unless `NeRF.two_wave_inference` is set.  Kept as the starting point for the next
+// attempt at hiding the non-MFMA instructions.
+//
+// mlp_fwd.hip gives every wave 32 points: 256 units x 32 points of activations are 128 registers per set and
+// the kernel needs ~450 registers, i.e. ONE wave per SIMD -- and with one wave per SIMD nothing co-issues with
+// that wave's own MFMAs: every LDS read, wait, DMA set-up and epilogue instruction costs ~4 cycles of
+// matrix-pipe idle time (measured: 0.90 of peak after trimming them to ~950 per layer).  Here a wave owns 16
+// points and works on 16x16 accumulator tiles (4 registers): an activation set is 64 registers, the kernel fits
+// 256, a workgroup is 8 waves = 2 per SIMD sharing ONE weight ring, and each wave's non-MFMA instructions issue
+// under the other wave's MFMAs.  Same MFMA rate (1024 MACs per 32 cycles), same L2->LDS weight traffic per point
+// (128 points per workgroup), twice the LDS operand reads per point (64 B/clk/CU of 128).
+//
+// Register trick, 16x16 edition: accumulator register i of lane (n = lane & 15, g = lane >> 4) holds row 4g+i of
+// the tile, column (point) n -- which is a legal B operand of a K=4 step whose k-slot g is unit 16T + 4g + i.
+// The packed image stores the matching A operands: block (to, ti) = 64 lanes x 4 floats, lane (m, g) holds
+// W[16 to + m][16 ti + 4g + 0..3], i.e. four consecutive input units: one ds_read_b128 feeds four MFMAs.
+// Blocks are streamed layer by layer, output tile by output tile: a 256-wide layer is 16 chunks of 16 KB.
+// Forward only (no stash): training keeps the 32-point kernels, whose stash layout the backward shares.
+#include "common.h"
+#include "mlp_layout.h"
+#include <type_traits>
+
+namespace mvip {
+using namespace mlp;
+
+namespace f16p {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int V> using ic = std::integral_constant<int, V>;
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(ic<I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
+}
+
+constexpr int NSLOT16 = 4;
+constexpr int RING16_FLOATS = NSLOT16 * CHUNK_FLOATS;            // 64 KB
+constexpr int LDS16_FLOATS = RING16_FLOATS + SEC_B_FLOATS;       // + 13 KB of small vectors
+constexpr int WG_POINTS = 128;
+
+// in-tiles (of 16 input units) per output tile, per layer
+constexpr int NTI_L0 = 4, NTI_LH = 16, NTI_L5 = 20, NTI_LV = 18;
+static_assert(16 * NTI_L0 == L0_BLOCKS && 16 * NTI_LH == LH_BLOCKS && 16 * NTI_L5 == L5_BLOCKS &&
+              8 * NTI_LV == LV_BLOCKS, "same block counts as the 32-point image");
+
+template <int OFF>
+__device__ __forceinline__ void glds(const float *src_lane, float *dst_wave) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                     (__attribute__((address_space(3))) void *)dst_wave, 16, OFF, 0);
+}
+
+struct Stream16 {
+    const float *packed;
+    float *lds;
+    int wave, lane;
+    // 16 KB chunk g into ring slot `slot`: 2 KB per wave, one address set-up for both pieces
+    __device__ __forceinline__ void issue_chunk(int g, int slot) const {
+        if (g < TOTAL_CHUNKS) {
+            const float *src = packed + (int64_t)g * CHUNK_FLOATS + wave * 512 + lane * 4;
+            float *dst = lds + slot * CHUNK_FLOATS + wave * 512;
+            glds<0>(src, dst);
+            glds<1024>(src, dst);
+        }
+    }
+    template <int BI>
+    __device__ __forceinline__ f32x4 read_block() const {
+        constexpr int off = ((BI / CHUNK_BLOCKS) % NSLOT16) * CHUNK_FLOATS + (BI % CHUNK_BLOCKS) * BLOCK_FLOATS;
+        return *reinterpret_cast<const f32x4 *>(lds + off + lane * 4);
+    }
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// One layer: NTO output tiles x NTI input tiles; BASE = absolute index of the layer's first block.
+// bsrc(ti) -> the activation tile (f32x4) feeding input units 16 ti .. 16 ti + 15; epi(to, acc) consumes a tile.
+template <int BASE, int NTO, int NTI, bool LAST, class BSrc, class Epi>
+__device__ __forceinline__ void layer16(const Stream16 &st, f32x4 &a, BSrc bsrc, Epi epi) {
+    static_for<NTO>([&](auto to_) {
+        constexpr int TO = decltype(to_)::value;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        static_for<NTI>([&](auto ti_) {
+            constexpr int TI = decltype(ti_)::value;
+            constexpr int bi = BASE + TO * NTI + TI;
+            constexpr bool last_block = LAST && (TO == NTO - 1) && (TI == NTI - 1);
+            if constexpr (bi % CHUNK_BLOCKS == 0) st.issue_chunk(bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT16);
+            // exactly one operand block ahead, pinned: left alone the scheduler hoists whole chunks of operand
+            // reads to the top and then spills them (5 KB of scratch in the first build)
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 an = a;
+            if constexpr (!last_block) an = st.template read_block<bi + 1>();
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 b = bsrc(ti_);
+            acc = mfma4(a[0], b[0], acc);
+            acc = mfma4(a[1], b[1], acc);
+            acc = mfma4(a[2], b[2], acc);
+            acc = mfma4(a[3], b[3], acc);
+            // keep the tile's chain inside the tile: in the view layer the optimiser otherwise sinks all MFMAs below
+            // all operand reads (reads first, 4 KB of them spilled, then the MFMAs fed from scratch)
+            if constexpr (TI == NTI - 1) asm volatile("" : "+v"(acc));
+            if constexpr (bi % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
+            a = an;
+        });
+        epi(to_, acc);
+    });
+}
+
+template <bool RELU>
+__device__ __forceinline__ f32x4 bias_act16(const f32x4 &acc, const float *bias16, int g) {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias16 + 4 * g);
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = acc[i] + b[i];
+        if (RELU) {                       // NaN-preserving ReLU as one integer max (see mlp_device.h)
+            const int bits = __builtin_bit_cast(int, v);
+            v = __builtin_bit_cast(float, bits > 0 ? bits : 0);
+        }
+        r[i] = v;
+    }
+    return r;
+}
+
+// channel c of the sinusoidal encoding of (x, y, z) with C real channels (Embedder.embed order)
+template <int C>
+__device__ __forceinline__ float enc_channel(float x, float y, float z, int c) {
+    const int m = c >= 3 ? c - 3 : 0;
+    const int oct = m / 6, rem = m - 6 * oct;
+    const int d = rem >= 3 ? rem - 3 : rem;
+    const int dsel = c < 3 ? c : d;
+    const float xv = dsel == 0 ? x : (dsel == 1 ? y : z);
+    const float arg = xv * __int_as_float((127 + oct) << 23);
+    float val = rem < 3 ? sinf(arg) : cosf(arg);
+    if (c < 3) val = xv;
+    if (c >= C) val = 0.f;
+    return val;
+}
+
+template <bool FROM_RAYS>
+__global__ void __launch_bounds__(512, 2)
+mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__ in_a, const float *__restrict__ in_b,
+                     int64_t P, int S, float *__restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS16_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    int64_t p = (int64_t)blockIdx.x * WG_POINTS + wave * 16 + n;
+    const bool live = p < P;
+    if (!live) p = P - 1;
+
+    Stream16 st{packed, lds, wave, lane};
+    for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 8)
+        glds<0>(packed + SEC_A_FLOATS + b * BLOCK_FLOATS + lane * 4, lds + RING16_FLOATS + b * BLOCK_FLOATS);
+    st.issue_chunk(0, 0);
+    st.issue_chunk(1, 1);
+
+    float px, py, pz, vx, vy, vz;
+    if constexpr (FROM_RAYS) {
+        const int64_t ray = p / S;
+        const float *row = in_a + ray * 11;
+        const float zz = in_b[p];
+        px = row[0] + row[3] * zz; py = row[1] + row[4] * zz; pz = row[2] + row[5] * zz;
+        vx = row[8]; vy = row[9]; vz = row[10];
+    } else {
+        px = in_a[p * 3]; py = in_a[p * 3 + 1]; pz = in_a[p * 3 + 2];
+        vx = in_b[p * 3]; vy = in_b[p * 3 + 1]; vz = in_b[p * 3 + 2];
+    }
+    f32x4 emb[4], edir[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) emb[t][i] = enc_channel<63>(px, py, pz, 16 * t + 4 * g + i);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) edir[t][i] = enc_channel<27>(vx, vy, vz, 16 * t + 4 * g + i);
+
+    __syncthreads();                                   // chunks 0, 1 and section B have landed
+    const float *sb = lds + RING16_FLOATS;
+    f32x4 a = st.read_block<0>();
+    f32x4 h[16], o[16];
+
+    // layer 0: 63(+1) -> 256
+    layer16<OFF_L0, 16, NTI_L0, false>(st, a, [&](auto ti) { return emb[ti.value]; },
+        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + 16 * to.value, g); });
+#pragma unroll
+    for (int t = 0; t < 16; ++t) h[t] = o[t];
+    // layers 1..4
+    static_for<4>([&](auto li) {
+        constexpr int l = 1 + decltype(li)::value;
+        layer16<OFF_L1 + (l - 1) * LH_BLOCKS, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
+            [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + l * 256 + 16 * to.value, g); });
+#pragma unroll
+        for (int t = 0; t < 16; ++t) h[t] = o[t];
+    });
+    // layer 5: cat[encoded point (64), h4 (256)] -> 256
+    layer16<OFF_L5, 16, NTI_L5, false>(st, a,
+        [&](auto ti) { if constexpr (ti.value < 4) return emb[ti.value]; else return h[ti.value - 4]; },
+        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + 5 * 256 + 16 * to.value, g); });
+#pragma unroll
+    for (int t = 0; t < 16; ++t) h[t] = o[t];
+    // layers 6, 7; sigma = alpha_linear(h7) is accumulated tile by tile in layer 7's epilogue (one weight quad
+    // live at a time: reading all 16 up front made the register allocator spill)
+    float sigma = 0.f;
+    static_for<2>([&](auto li) {
+        constexpr int l = 6 + decltype(li)::value;
+        layer16<OFF_L6 + (l - 6) * LH_BLOCKS, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
+            [&](auto to, const f32x4 &acc) {
+                o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + l * 256 + 16 * to.value, g);
+                if constexpr (l == 7) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(sb + SB_WALPHA + 16 * to.value + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sigma = fmaf(w[i], o[to.value][i], sigma);
+                }
+            });
+#pragma unroll
+        for (int t = 0; t < 16; ++t) h[t] = o[t];
+    });
+    sigma += __shfl_xor(sigma, 16, 64);
+    sigma += __shfl_xor(sigma, 32, 64);
+    sigma += sb[SB_BALPHA];
+    // feature = feature_linear(h7), no activation
+    layer16<OFF_FEAT, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
+        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<false>(acc, sb + SB_BFEAT + 16 * to.value, g); });
+    // view branch: cat[feature (256), encoded dir (27+5)] -> 128, relu
+    // rgb = rgb_linear(v), accumulated in the view layer's epilogue
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    layer16<OFF_VIEWS, 8, NTI_LV, true>(st, a,
+        [&](auto ti) { if constexpr (ti.value < 16) return o[ti.value]; else return edir[ti.value - 16]; },
+        [&](auto to, const f32x4 &acc) {
+            const f32x4 v = bias_act16<true>(acc, sb + SB_BVIEWS + 16 * to.value, g);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 16 * to.value + 4 * g);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 128 + 16 * to.value + 4 * g);
+            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 256 + 16 * to.value + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r0 = fmaf(w0[i], v[i], r0);
+                r1 = fmaf(w1[i], v[i], r1);
+                r2 = fmaf(w2[i], v[i], r2);
+            }
+        });
+    r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
+    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
+    if (live && g == 0)
+        reinterpret_cast<float4 *>(raw)[p] = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
+}
+
+// ---- packing ---------------------------------------------------------------------------------------------------
+struct ParamPtrsC16 { const float *p[P_COUNT]; };
+
+__global__ void mlp_pack16_kernel(ParamPtrsC16 pp, float *__restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SEC_A_FLOATS) return;
+    const int blk = idx / BLOCK_FLOATS, r = idx % BLOCK_FLOATS;
+    const int lane = r / 4, s = r % 4, m = lane & 15, g = lane >> 4;
+    int local, nti, param;
+    int layer = -1;                                   // 0..7 hidden, 8 feature, 9 views
+    if (blk < OFF_L1) { local = blk; nti = NTI_L0; layer = 0; }
+    else if (blk < OFF_L5) { layer = 1 + (blk - OFF_L1) / LH_BLOCKS; local = (blk - OFF_L1) % LH_BLOCKS; nti = NTI_LH; }
+    else if (blk < OFF_L6) { layer = 5; local = blk - OFF_L5; nti = NTI_L5; }
+    else if (blk < OFF_FEAT) { layer = 6 + (blk - OFF_L6) / LH_BLOCKS; local = (blk - OFF_L6) % LH_BLOCKS; nti = NTI_LH; }
+    else if (blk < OFF_VIEWS) { layer = 8; local = blk - OFF_FEAT; nti = NTI_LH; }
+    else { layer = 9; local = blk - OFF_VIEWS; nti = NTI_LV; }
+    const int to = local / nti, ti = local % nti;
+    const int row = 16 * to + m, col = 16 * ti + 4 * g + s;
+    float v = 0.f;
+    if (layer == 0) { if (col < 63) v = pp.p[P_W0][row * 63 + col]; }
+    else if (layer == 5) {
+        if (col < 63) v = pp.p[10][row * 319 + col];
+        else if (col >= 64) v = pp.p[10][row * 319 + 63 + (col - 64)];
+    }
+    else if (layer == 8) v = pp.p[P_WF][row * 256 + col];
+    else if (layer == 9) { if (col < 283) v = pp.p[P_WV][row * 283 + col]; }
+    else { param = 2 * layer; v = pp.p[param][row * 256 + col]; }
+    packed[idx] = v;
+}
+
+}  // namespace f16p
+}  // namespace mvip
+
+using namespace mvip;
+using namespace mvip::f16p;
+
+// packed16 = [section A in 16-point block order | section B copied from the 32-point image]
+extern "C" int mvip_mlp_pack16(const float *const *params_host, const float *packed32, float *packed16, void *stream) {
+    if (!params_host || !packed32 || !packed16) return MVIP_EINVAL;
+    ParamPtrsC16 pp;
+    for (int i = 0; i < mlp::P_COUNT; ++i) {
+        if (!params_host[i]) return MVIP_EINVAL;
+        pp.p[i] = params_host[i];
+    }
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(mlp_pack16_kernel, dim3((mlp::SEC_A_FLOATS + 255) / 256), dim3(256), 0, st, pp, packed16);
+    if (hipMemcpyAsync(packed16 + mlp::SEC_A_FLOATS, packed32 + mlp::SEC_A_FLOATS, mlp::SEC_B_FLOATS * sizeof(float),
+                       hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return check_launch();
+    return check_launch();
+}
+
+extern "C" int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
+                                       float *raw, void *stream) {
+    if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!packed16 || !rows || !z || !raw) return MVIP_EINVAL;
+    const int64_t P = B * S;
+    hipLaunchKernelGGL((mlp_forward16_kernel<true>), dim3((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), dim3(512), 0,
+                       as_stream(stream), packed16, rows, z, P, S, raw);
+    return check_launch();
+}
+
+extern "C" int mvip_mlp_forward_points16(const float *packed16, const float *pts, const float *dirs, int64_t P,
+                                         float *raw, void *stream) {
+    if (P < 0) return MVIP_EINVAL;
+    if (P == 0) return MVIP_OK;
+    if (!packed16 || !pts || !dirs || !raw) return MVIP_EINVAL;
+    hipLaunchKernelGGL((mlp_forward16_kernel<false>), dim3((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), dim3(512), 0,
+                       as_stream(stream), packed16, pts, dirs, P, 1, raw);
+    return check_launch();
+}

@@ -118,6 +118,14 @@ def mlp_pack(params):
     return packed
 
 
+def mlp_pack16(params, packed_f32):
+    """Image for the two-waves-per-SIMD inference kernel (16 points per wave, csrc/mlp_fwd16.hip)."""
+    ps = [_f32c(p.detach()) for p in params]
+    img = torch.empty(packed_floats(), device=ps[0].device, dtype=_F32)
+    call('mvip_mlp_pack16', _lib.ptr_array(ps), ptr(packed_f32), ptr(img), stream())
+    return img
+
+
 def mlp_pack_f16x3(params, packed_f32):
     """Image for the split-precision forward (precision=1); same size as the fp32 image."""
     ps = [_f32c(p.detach()) for p in params]
@@ -240,11 +248,12 @@ class _MLPPoints(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
     routes the gradients back to them; with no grad needed the Function is skipped.
     `packed_f16x3` selects the split-precision kernel (precision = 1) for no-grad calls,
-    `train_f16x3` (the same kind of image) for calls that will be back-propagated."""
+    `train_f16x3` (the same kind of image) for calls that will be back-propagated, `packed16` the exact-fp32
+    two-waves-per-SIMD inference kernel (no-grad calls at precision 0)."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
@@ -254,12 +263,14 @@ def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None):
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
     if packed_f16x3 is not None:
         call('mvip_mlp_forward_rays', ptr(packed_f16x3), ptr(rows), ptr(z), B, S, ptr(raw), 1, stream())
+    elif packed16 is not None:
+        call('mvip_mlp_forward_rays16', ptr(packed16), ptr(rows), ptr(z), B, S, ptr(raw), stream())
     else:
         call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), 0, stream())
     return raw
 
 
-def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None):
+def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None):
     pts, dirs = _f32c(pts), _f32c(dirs)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
@@ -268,6 +279,8 @@ def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None):
     raw = torch.empty((pts.shape[0], 4), device=pts.device, dtype=_F32)
     if packed_f16x3 is not None:
         call('mvip_mlp_forward_points', ptr(packed_f16x3), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 1, stream())
+    elif packed16 is not None:
+        call('mvip_mlp_forward_points16', ptr(packed16), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), stream())
     else:
         call('mvip_mlp_forward_points', ptr(packed), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 0, stream())
     return raw

@@ -71,6 +71,9 @@ class NeRF(nn.Module):
         self._packed_key = None
         self._packed16 = None
         self._packed16_key = None
+        self._packed_w16 = None
+        self._packed_w16_key = None
+        self.two_wave_inference = False   # csrc/mlp_fwd16.hip (16 points per wave): correct, measured 3 % slower
         # 0: exact fp32 MFMA.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative, fp32 accumulate).
         self.inference_precision = 0  # forward passes that need no gradient (rendering)
         self.train_precision = 0      # stash-writing forward, delta and weight-gradient kernels
@@ -113,6 +116,18 @@ class NeRF(nn.Module):
             self._packed16_key = self._packed_key
         return self._packed16
 
+    def packed_w16(self):
+        """Image of the two-waves-per-SIMD exact-fp32 inference kernel (csrc/mlp_fwd16.hip)."""
+        packed = self.packed()
+        if self._packed_w16 is None or self._packed_w16_key != self._packed_key:
+            self._packed_w16 = ops.mlp_pack16(self.param_list(), packed)
+            self._packed_w16_key = self._packed_key
+        return self._packed_w16
+
+    def _infer16(self):
+        no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        return self.packed_w16() if (self.two_wave_inference and no_grad and self.inference_precision == 0) else None
+
     def _fast_image(self):
         return self.packed_f16x3() if self.inference_precision == 1 else None
 
@@ -120,10 +135,12 @@ class NeRF(nn.Module):
         return self.packed_f16x3() if self.train_precision == 1 else None
 
     def query_points(self, pts, dirs):
-        return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image(), self._train_image())
+        return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
+                              self._infer16())
 
     def query_rays(self, rows, z):
-        return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image())
+        return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
+                            self._infer16())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

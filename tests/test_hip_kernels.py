@@ -408,3 +408,29 @@ def test_empty_and_ragged_inputs(cuda, golden):
     for n_ in (1, 31, 33, 127, 129, 200):
         part = ops.mlp_points(pts[:n_].contiguous(), dirs[:n_].contiguous(), packed, ps)
         np.testing.assert_array_equal(N(part), N(full[:n_]))
+
+
+def test_mlp_forward_two_waves_per_simd_kernel(golden, cuda):
+    """csrc/mlp_fwd16.hip (16 points per wave, v_mfma_f32_16x16x4_f32, the inference path of the NeRF module)
+    against the golden forward, against the 32-point kernel, from rays and from points, ragged sizes."""
+    from mvip_nerf_amd import ops
+    g = golden('mlp_fwd_bwd')
+    ps = params_dev(g['seed'], cuda)
+    packed = ops.mlp_pack(ps)
+    p16 = ops.mlp_pack16(ps, packed)
+    pts, dirs = T(g['pts'], cuda), T(g['dirs'], cuda)
+    with torch.no_grad():
+        raw16 = ops.mlp_points(pts, dirs, packed, ps, packed16=p16)
+        raw32 = ops.mlp_points(pts, dirs, packed, ps)
+    np.testing.assert_allclose(N(raw16), g['out'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(N(raw16), N(raw32), rtol=2e-5, atol=2e-6)
+    for n_ in (1, 15, 17, 127, 129, 250):
+        with torch.no_grad():
+            part = ops.mlp_points(pts[:n_].contiguous(), dirs[:n_].contiguous(), packed, ps, packed16=p16)
+        np.testing.assert_array_equal(N(part), N(raw16[:n_]))
+    rows = torch.from_numpy(bench_like_rays(37, seed=3)).float().to(cuda)
+    z = ops.stratified_z(rows, 64, True)
+    with torch.no_grad():
+        r16 = ops.mlp_rays(rows, z, packed, ps, packed16=p16)
+        r32 = ops.mlp_rays(rows, z, packed, ps)
+    np.testing.assert_allclose(N(r16), N(r32), rtol=2e-5, atol=2e-6)
