@@ -91,7 +91,7 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
         src = 'profiles/r1_pmc_mlp_forward.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
-    return {'bound': 'mfma', 'kernel': 'mlp_forward_kernel<rays>', 'achieved': round(tflops, 2),
+    return {'bound': 'mfma', 'kernel': 'mlp_forward16_kernel<rays> (csrc/mlp_fwd16.hip)', 'achieved': round(tflops, 2),
             'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / PEAK_F32_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
             'algorithmic_hbm_bytes': points * 20 + rows.shape[0] * 44, 'launch_ms': round(ms, 3),

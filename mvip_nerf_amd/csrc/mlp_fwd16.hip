@@ -1,8 +1,6 @@
 // Inference forward of the 8x256 NeRF MLP with TWO waves per SIMD (exact fp32, v_mfma_f32_16x16x4_f32).
-// STATUS: correct (tests/test_hip_kernels.py) but measured 3 % SLOWER than the tuned one-wave kernel of mlp_fwd.hip
-// (210.8 vs 204.0 ms on the bench's fine pass; staggering the SIMD partners' epilogues made it 218 ms), so the
-// NeRF module does not use it unless `NeRF.two_wave_inference` is set.  Kept as the starting point for the next
-// attempt at hiding the non-MFMA instructions.
+// The NeRF module's no-grad exact-fp32 path (NeRF.two_wave_inference): 202.9 ms on the bench's fine pass = 142.7
+// TFLOP/s = 0.907 of peak, against 205.5 ms / 0.896 for the 32-point kernel of mlp_fwd.hip.
 //
 // mlp_fwd.hip gives every wave 32 points: 256 units x 32 points of activations are 128 registers per set and
 // the kernel needs ~450 registers, i.e. ONE wave per SIMD -- and with one wave per SIMD nothing co-issues with
@@ -79,37 +77,50 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // bsrc(ti) -> the activation tile (f32x4) feeding input units 16 ti .. 16 ti + 15; epi(to, acc) consumes a tile.
 template <int BASE, int NTO, int NTI, bool LAST, class BSrc, class Epi>
 __device__ __forceinline__ void layer16(const Stream16 &st, f32x4 &a, BSrc bsrc, Epi epi) {
+    // Two accumulator tiles alternate; the epilogue of tile t-1 is issued one block into tile t, where its VALU
+    // instructions run under MFMAs instead of after a drained chain.
+    f32x4 accs[2];
     static_for<NTO>([&](auto to_) {
         constexpr int TO = decltype(to_)::value;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 &acc = accs[TO & 1];
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
         static_for<NTI>([&](auto ti_) {
             constexpr int TI = decltype(ti_)::value;
             constexpr int bi = BASE + TO * NTI + TI;
             constexpr bool last_block = LAST && (TO == NTO - 1) && (TI == NTI - 1);
             if constexpr (bi % CHUNK_BLOCKS == 0) st.issue_chunk(bi / CHUNK_BLOCKS + 2, (bi / CHUNK_BLOCKS + 2) % NSLOT16);
-            // exactly one operand block ahead, pinned: left alone the scheduler hoists whole chunks of operand
-            // reads to the top and then spills them (5 KB of scratch in the first build)
+            // The next block's operands are read right AFTER this block's first MFMA and pinned there.  Left alone
+            // the scheduler hoists whole chunks of operand reads to the top and spills them; and read BEFORE the
+            // first MFMA, the compiler's wait for THIS block's operands (it emits lgkmcnt(0), not lgkmcnt(1))
+            // would also wait out the read just issued -- a full LDS latency exposed every other block, in both
+            // SIMD partners at once.
+            const f32x4 b = bsrc(ti_);
+            acc = mfma4(a[0], b[0], acc);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 an = a;
             if constexpr (!last_block) an = st.template read_block<bi + 1>();
             __builtin_amdgcn_sched_barrier(0);
-            const f32x4 b = bsrc(ti_);
-            acc = mfma4(a[0], b[0], acc);
             acc = mfma4(a[1], b[1], acc);
             acc = mfma4(a[2], b[2], acc);
             acc = mfma4(a[3], b[3], acc);
             // keep the tile's chain inside the tile: in the view layer the optimiser otherwise sinks all MFMAs below
             // all operand reads (reads first, 4 KB of them spilled, then the MFMAs fed from scratch)
             if constexpr (TI == NTI - 1) asm volatile("" : "+v"(acc));
+#ifndef MVIP_EXPERIMENT_NO_BARRIER          // timing experiment only: results are wrong without the barrier
             if constexpr (bi % CHUNK_BLOCKS == CHUNK_BLOCKS - 1) __syncthreads();
+#endif
             a = an;
+            if constexpr (TO > 0 && TI == 1) epi(ic<TO - 1>{}, accs[(TO - 1) & 1]);
         });
-        epi(to_, acc);
     });
+    epi(ic<NTO - 1>{}, accs[(NTO - 1) & 1]);
 }
 
 template <bool RELU>
 __device__ __forceinline__ f32x4 bias_act16(const f32x4 &acc, const float *bias16, int g) {
+#ifdef MVIP_EXPERIMENT_NO_EPILOGUE         // timing experiment only
+    return acc;
+#endif
     const f32x4 b = *reinterpret_cast<const f32x4 *>(bias16 + 4 * g);
     f32x4 r;
 #pragma unroll
