@@ -47,10 +47,25 @@ struct StreamF {
     // separate address for every block of the upper half (and parks those addresses in AGPRs): two extra
     // instructions per operand read.  `hi` is the lane's address in the upper half made opaque to the
     // optimiser, so every read is `ds_read_b128 v, base offset:imm` off one of two live registers.
-    unsigned hi_addr = 0;
+    unsigned hi_addr = 0, lo_addr = 0;
     __device__ __forceinline__ void init_bases() {
         unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)(lds + F_GROUP_BLOCKS * BLOCK_FLOATS) + lane * 16;
         asm volatile("v_mov_b32 %0, %1" : "=v"(hi_addr) : "v"(a));
+        lo_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)lds + lane * 16;
+    }
+    // Operand prefetch the compiler's wait-count pass does not see: the pass answers every pending LDS read with
+    // s_waitcnt lgkmcnt(0) in front of the next MFMA, i.e. it waits out the prefetch issued one MFMA earlier --
+    // a full LDS latency per 96-cycle k-step (matrix pipe 48 % busy).  These reads are paired with explicit
+    // s_waitcnt lgkmcnt(N) in run_layer_f (LDS operations complete in order).
+    template <int BLK>
+    __device__ __forceinline__ h16x8 read_block_async() const {
+        constexpr int blk = BLK % (2 * F_GROUP_BLOCKS);
+        h16x8 v;
+        if constexpr (blk < F_GROUP_BLOCKS)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lo_addr), "n"(blk * 1024));
+        else
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(hi_addr), "n"((blk - F_GROUP_BLOCKS) * 1024));
+        return v;
     }
     template <int BLK>      // BLK = absolute block index in the stream (compile time)
     __device__ __forceinline__ h16x8 read_block() const {
@@ -127,10 +142,15 @@ __device__ __forceinline__ void run_layer_f(const StreamF &st, APair &a0, APair 
             constexpr bool group_end = (blk + 2) % F_GROUP_BLOCKS == 0;       // this is the last k-step of its group
             constexpr bool next_is_group_end = (blk + 4) % F_GROUP_BLOCKS == 0;
             if constexpr (blk % F_GROUP_BLOCKS == 0) st.issue_group(blk / F_GROUP_BLOCKS + 1);
+            // a0 (this step's fragments) must have landed.  If the previous step issued an asynchronous prefetch
+            // (a1's two reads), exactly those two may still be in flight: lgkmcnt(2); otherwise drain.
+            constexpr bool prev_async = (blk % F_GROUP_BLOCKS != 0) && ((blk + 2) % F_GROUP_BLOCKS != 0) && left >= 1;
+            if constexpr (prev_async) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0.h), "+v"(a0.l));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0.h), "+v"(a0.l));
             APair a2 = a1;
             // fragments of k-step +2 live in the same group iff neither this nor the next step ends it
             if constexpr (left >= 2 && !group_end && !next_is_group_end)
-                a2 = APair{st.template read_block<blk + 4>(), st.template read_block<blk + 5>()};
+                a2 = APair{st.template read_block_async<blk + 4>(), st.template read_block_async<blk + 5>()};
             const auto b = bfrag(ks);
             acc = mfma16(a0.h, b.first, acc);
             acc = mfma16(a0.h, b.second, acc);
