@@ -203,7 +203,8 @@ def main():
             'render_rays_per_sec': H * W * world * args.steps / dt_h, 'render_ms_per_frame': dt_h / args.steps * 1e3,
             'train_ms_per_step': dt_ht / max(args.train_steps, 1) * 1e3,
             'what': 'NeRF_TCNN (16-level hash grid + 64-wide MLPs, coarse+fine), same frames and same training '
-                    'iteration as the 8x256 legs; parity unpinned (tiny-cuda-nn absent)'}
+                    'iteration as the 8x256 legs; renders through the fused gather + fp32-MFMA kernel '
+                    '(csrc/hashgrid_fused.hip); parity unpinned (tiny-cuda-nn absent)'}
         del tr_h
 
     # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on

@@ -294,6 +294,15 @@ int mvip_hashgrid_backward(const float *x, const float *d_features, const void *
                            float *d_table, void *stream);
 int mvip_sh4(const float *dirs, int64_t P, float *out, void *stream);
 
+/* Fused no-grad NeRF_TCNN.forward (run_nerf_helpers_tcnn.py:88-112): x [P,3], dirs [P,3] -> raw [P,4] =
+ * (colour 0..2, sigma), in exact fp32 on the matrix pipe.  sigma_params = [64x32 | 16x64] floats, colour_params =
+ * [64x32 | 64x64 | 16x64] floats ([out][in] row-major, layer order = the tiny-cuda-nn `params` vectors);
+ * mvip_hashgrid_mlp_pack writes the kernel's operand image (mvip_hashgrid_mlp_packed_floats() floats). */
+int64_t mvip_hashgrid_mlp_packed_floats(void);
+int mvip_hashgrid_mlp_pack(const float *sigma_params, const float *colour_params, float *img, void *stream);
+int mvip_hashgrid_nerf_forward(const float *x, const float *dirs, const float *table, const void *levels,
+                               const float *img, int64_t P, float bound, float *raw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -642,6 +642,25 @@ def sh4(dirs):
     return out
 
 
+def hashgrid_mlp_pack(sigma_params, colour_params):
+    """Operand image of NeRF_TCNN's five bias-free matrices for `hashgrid_nerf_forward`."""
+    sp, cp = _f32c(sigma_params.detach()), _f32c(colour_params.detach())
+    assert sp.numel() == 3072 and cp.numel() == 7168
+    img = torch.empty(int(_lib.load().mvip_hashgrid_mlp_packed_floats()), device=sp.device, dtype=torch.float32)
+    call('mvip_hashgrid_mlp_pack', ptr(sp), ptr(cp), ptr(img), stream())
+    return img
+
+
+def hashgrid_nerf_forward(x, dirs, table, levels, img, bound):
+    """Fused no-grad NeRF_TCNN.forward: x [P,3], dirs [P,3] -> [P,4] = (colour, sigma)."""
+    xc, dc = _f32c(x.detach()), _f32c(dirs.detach())
+    P = xc.shape[0]
+    out = torch.empty((P, 4), device=xc.device, dtype=torch.float32)
+    call('mvip_hashgrid_nerf_forward', ptr(xc), ptr(dc), ptr(table.detach().contiguous()), ptr(levels, torch.int32),
+         ptr(img), P, float(bound), ptr(out), stream())
+    return out
+
+
 # Split-precision GEMM building blocks and the VAE mid-block attention built from them ------------------------
 
 def absmax_scale(t):

@@ -74,10 +74,21 @@ class NeRF_TCNN(nn.Module):
         return (s[:2048].view(64, 32), s[2048:3072].view(16, 64),
                 c[:2048].view(64, 32), c[2048:6144].view(64, 64), c[6144:7168].view(16, 64))
 
+    fused_inference = True          # no-grad forwards run the fused gather + MFMA kernel (csrc/hashgrid_fused.hip)
+
+    def _packed_mlps(self):
+        key = (self.sigma_net.params._version, self.color_net.params._version, self.sigma_net.params.data_ptr())
+        if getattr(self, '_packed_key', None) != key:
+            self._packed_img = ops.hashgrid_mlp_pack(self.sigma_net.params, self.color_net.params)
+            self._packed_key = key
+        return self._packed_img
+
     def forward(self, input):
         """input [N, 6] = cat[x in [-bound, bound], d in [-1, 1]] -> [N, 4] = cat[colour, sigma]."""
         x = input[:, :3].contiguous()
         d = input[:, 3:].contiguous()
+        if self.fused_inference and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return ops.hashgrid_nerf_forward(x, d, self.encoder.params, self.levels, self._packed_mlps(), float(self.bound))
         W1, W2, C1, C2, C3 = self.mlp_matrices()
         feats = ops.hashgrid_encode(x, self.encoder.params, self.levels, float(self.bound))      # [32, N]
         h = W2 @ torch.relu(W1 @ feats)                                                           # [16, N]

@@ -35,8 +35,19 @@ print(json.dumps({'kernel': 'hg_backward', 'points': P, 'ms': t_b * 1e3, 'algori
                   'frac_of_8TBps': alg_b / t_b / 8e12}), flush=True)
 inp = torch.cat([x[:1 << 20], torch.nn.functional.normalize(torch.randn(1 << 20, 3, device=dev), dim=-1)], -1)
 with torch.no_grad():
+    net.fused_inference = False
     t_m = timeit(lambda: net(inp))
-print(json.dumps({'module_forward_points_per_sec': (1 << 20) / t_m, 'ms_per_1M_points': t_m * 1e3}), flush=True)
+    net.fused_inference = True
+    t_u = timeit(lambda: net(inp))
+    # ray-ordered points (64 consecutive samples along each ray), the order the renderer produces
+    o = (torch.rand(1 << 14, 1, 3, device=dev) * 2 - 1) * 0.3
+    dd = torch.nn.functional.normalize(torch.randn(1 << 14, 1, 3, device=dev), dim=-1)
+    zz = torch.linspace(1.2, 7.7, 64, device=dev)[None, :, None]
+    inp_r = torch.cat([(o + dd * zz).reshape(-1, 3), dd.expand(-1, 64, -1).reshape(-1, 3)], -1)
+    t_ur = timeit(lambda: net(inp_r))
+print(json.dumps({'module_forward_points_per_sec': (1 << 20) / t_m, 'ms_per_1M_points': t_m * 1e3,
+                  'fused_points_per_sec': (1 << 20) / t_u, 'fused_ms_per_1M_points': t_u * 1e3,
+                  'fused_ray_ordered_ms_per_1M_points': t_ur * 1e3}), flush=True)
 
 args = types.SimpleNamespace(use_viewdirs=True, N_importance=64, alpha_model_path=None, netchunk=1 << 20, lrate=1e-2,
                              basedir='/tmp/x', expname='none', ft_path=None, no_reload=True, perturb=0., N_samples=64,
