@@ -661,6 +661,45 @@ def hashgrid_nerf_forward(x, dirs, table, levels, img, bound):
     return out
 
 
+def skinny_wgrad(dY, X):
+    """dW [M, N] = dY [M, P] @ X [N, P]^T for the hash-grid model's small layers (M, N <= 64, P % 32 == 0)."""
+    dYc, Xc = _f32c(dY), _f32c(X)
+    M, P = dYc.shape
+    N = Xc.shape[0]
+    slabs = torch.empty((int(_lib.load().mvip_skinny_wgrad_slabs(P)), M, N), device=dYc.device, dtype=torch.float32)
+    call('mvip_skinny_wgrad', ptr(dYc), ptr(Xc), M, N, P, ptr(slabs), stream())
+    return slabs.sum(0)
+
+
+class _LinearCM(torch.autograd.Function):
+    """Y [M, P] = W [M, N] @ X [N, P] (channel-major activations).  Forward and data gradient are streaming library
+    matmuls; the weight gradient (a [M, N] result contracted over millions of points, which the BLAS library runs
+    on a handful of workgroups) is csrc/skinny_gemm.hip."""
+
+    @staticmethod
+    def forward(ctx, W, X):
+        ctx.save_for_backward(W, X)
+        return W @ X
+
+    @staticmethod
+    def backward(ctx, dY):
+        W, X = ctx.saved_tensors
+        dW = dX = None
+        if ctx.needs_input_grad[1]:
+            dX = W.t() @ dY
+        if ctx.needs_input_grad[0]:
+            P = X.shape[1]
+            if P % 32 == 0 and P >= 4096 and W.shape[0] <= 64 and W.shape[1] <= 64:
+                dW = skinny_wgrad(dY, X)
+            else:
+                dW = dY @ X.t()
+        return dW, dX
+
+
+def linear_cm(W, X):
+    return _LinearCM.apply(W, X)
+
+
 # Split-precision GEMM building blocks and the VAE mid-block attention built from them ------------------------
 
 def absmax_scale(t):

@@ -7,7 +7,8 @@ The reference obtains the encodings and the bias-free "FullyFusedMLP"s from tiny
 tensor-core arithmetic, not in the reference tree and not installable here), so this model is restated from
 the published algorithm and is **parity unpinned** (DESIGN.md): the hash-grid gather/scatter and the SH basis
 are HIP kernels (csrc/hashgrid.hip), the five small GEMMs are library fp32 matmuls on level-major [C, P]
-activations.  Parameter names follow the tiny-cuda-nn torch binding (`encoder.params`, `sigma_net.params`,
+activations with the weight gradients on csrc/skinny_gemm.hip; no-grad passes run one fused kernel
+(csrc/hashgrid_fused.hip).  Parameter names follow the tiny-cuda-nn torch binding (`encoder.params`, `sigma_net.params`,
 `color_net.params`, `encoder_dir.params` (empty)); matrices are [out, in] row-major, in layer order.
 """
 import numpy as np
@@ -91,10 +92,10 @@ class NeRF_TCNN(nn.Module):
             return ops.hashgrid_nerf_forward(x, d, self.encoder.params, self.levels, self._packed_mlps(), float(self.bound))
         W1, W2, C1, C2, C3 = self.mlp_matrices()
         feats = ops.hashgrid_encode(x, self.encoder.params, self.levels, float(self.bound))      # [32, N]
-        h = W2 @ torch.relu(W1 @ feats)                                                           # [16, N]
+        h = ops.linear_cm(W2, torch.relu(ops.linear_cm(W1, feats)))                               # [16, N]
         sh = ops.sh4(d)                                                                           # [16, N]
         # the colour network's 31 inputs are padded to 32 with ones (tiny-cuda-nn pads network inputs to a
         # multiple of 16 with 1.0)
         cin = torch.cat([sh, h[1:16], torch.ones_like(h[:1])], 0)
-        c = C3 @ torch.relu(C2 @ torch.relu(C1 @ cin))
+        c = ops.linear_cm(C3, torch.relu(ops.linear_cm(C2, torch.relu(ops.linear_cm(C1, cin)))))
         return torch.stack([c[0], c[1], c[2], h[0]], -1)

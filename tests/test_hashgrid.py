@@ -157,3 +157,29 @@ def test_fused_inference_kernel_matches_unfused_model(cuda):
     # with gradients enabled and trainable parameters the module takes the differentiable path
     net.fused_inference = True
     assert net(inp[:64]).requires_grad
+
+
+@pytest.mark.gpu
+def test_skinny_weight_gradient_kernel(cuda):
+    """csrc/skinny_gemm.hip: dW = dY @ X^T for the model's layer shapes, against the same contraction in fp64."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for M, Nn, P in ((64, 32, 65536), (16, 64, 8192), (64, 64, 200000), (3, 17, 4096), (64, 32, 1 << 21)):
+        dY = torch.randn(M, P, generator=g).to(cuda)
+        X = torch.randn(Nn, P, generator=g).to(cuda)
+        got = ops.skinny_wgrad(dY, X)
+        ref = (dY.double() @ X.double().t())
+        assert got.shape == (M, Nn)
+        err = float((got.double() - ref).abs().max())
+        assert err < 2e-5 * float(ref.abs().max()) + 1e-3 * (P ** 0.5) * 1e-3, (M, Nn, P, err)
+        assert torch.equal(got, ops.skinny_wgrad(dY, X))                 # fixed summation order
+    # through autograd: linear_cm's gradients == torch matmul's
+    W = torch.randn(16, 64, generator=g).to(cuda).requires_grad_(True)
+    X = torch.randn(64, 16384, generator=g).to(cuda).requires_grad_(True)
+    dY = torch.randn(16, 16384, generator=g).to(cuda)
+    ops.linear_cm(W, X).backward(dY)
+    gw, gx = W.grad.clone(), X.grad.clone()
+    W.grad = X.grad = None
+    (W @ X).backward(dY)
+    np.testing.assert_allclose(N(gw), N(W.grad), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(N(gx), N(X.grad), rtol=1e-5, atol=1e-5)
