@@ -128,7 +128,9 @@ hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, 
             }
             if (!done) {
                 unsafeAtomicAdd(tab + 2 * (int64_t)idx, wk * g0);
+#ifndef MVIP_EXPERIMENT_HG_ONE_ATOMIC
                 unsafeAtomicAdd(tab + 2 * (int64_t)idx + 1, wk * g1);
+#endif
             }
         }
     }
@@ -137,7 +139,9 @@ hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, 
         const uint32_t k = keys[s];
         if (k != HG_EMPTY) {
             unsafeAtomicAdd(tab + 2 * (int64_t)k, acc0[s]);
+#ifndef MVIP_EXPERIMENT_HG_ONE_ATOMIC
             unsafeAtomicAdd(tab + 2 * (int64_t)k + 1, acc1[s]);
+#endif
         }
     }
 }
