@@ -300,6 +300,31 @@ def main():
             barrier()
             sds_times.append(time.perf_counter() - t2)
         dt_sds = float(np.median(sds_times)) * args.sds_steps
+
+        # the same step replayed as ONE captured hipGraph (fp32), and the reference's --fp16 mode replayed the same way
+        def graphed_ms(sd_g, scale):
+            sd_g.use_graphs = True
+            pg = pred.detach().clone().requires_grad_(True)
+
+            def one(i):
+                pg.grad = None
+                (scale * sd_g.train_step_sd(i, mask, 'a stone bench in a park', pg, guidance_scale=7.5)).sum().backward()
+            one(1000)
+            one(1001)
+            barrier()
+            ts = []
+            for k in range(max(args.sds_steps, 3)):
+                tg = time.perf_counter()
+                one(1002 + k)
+                barrier()
+                ts.append(time.perf_counter() - tg)
+            sd_g.use_graphs = False
+            return float(np.median(ts)) * 1e3
+        ms_graph32 = graphed_ms(sd, 1e-4)
+        sd16 = StableDiffusion(device, True, False)
+        ms_graph16 = graphed_ms(sd16, 1.0)
+        del sd16
+        torch.cuda.empty_cache()
         opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                     text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                     colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
@@ -360,6 +385,7 @@ def main():
         result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': dt_sds / args.sds_steps * 1e3,
                          'dtype': 'f32 tensors; 3x3 ResNet convolutions on fp16 MFMA in split precision (f16x3, ~1e-6 relative), the rest library fp32',
                          'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
+                         'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
                          'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
                          '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
         result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,

@@ -18,6 +18,17 @@ static inline int check_launch() {
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zeroing of small scratch words as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the 16-byte memset
+// node in front of an atomicMax reduction was seen to leave stale values on replay (the conv data-gradient scale of
+// the graphed SDS step drifted from replay to replay); a kernel node is ordered like every other launch.
+static __global__ void mvip_zero_words_kernel(unsigned *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static inline void zero_words(void *p, int n_words, hipStream_t st) {
+    hipLaunchKernelGGL(mvip_zero_words_kernel, dim3((n_words + 63) / 64), dim3(64), 0, st, (unsigned *)p, n_words);
+}
+
 // ---- wave-level primitives (64 lanes) -------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -507,7 +507,7 @@ extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin,
     if (!weight || !packed || co <= 0 || co % 32 != 0 || ci <= 0 || ci % 16 != 0) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     char *tail = (char *)packed + co * ci * 36;
-    if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
+    zero_words(tail, 64, st);
     hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(Cout * Cin * 9)), dim3(256), 0, st, weight, Cout * Cin * 9,
                        (unsigned *)(tail + 8));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
@@ -520,7 +520,7 @@ extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin,
 extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *stream) {
     if (n < 0 || !scale2 || (n > 0 && !x)) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(scale2, 0, 16, st) != hipSuccess) return check_launch();
+    zero_words(scale2, 4, st);
     if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(n)), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(scale2 + 2), scale2);
     return check_launch();
@@ -600,7 +600,7 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     if (!src || !packed || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     char *tail = (char *)packed + M * K * 4;
-    if (hipMemsetAsync(tail, 0, 256, st) != hipSuccess) return check_launch();
+    zero_words(tail, 64, st);
     hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(M * K)), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 8));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
     const int64_t total = (M / 32) * (K / 16) * 2 * 64;

@@ -581,7 +581,7 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
     hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
     unsigned *absmax = reinterpret_cast<unsigned *>(ws + T_FLOATS + TABLE_FLOATS - 4);   // tail of the table block
     if (precision == 1) {
-        hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
+        zero_words(absmax, 1, s);
         hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, s, d_raw, P * 4, absmax);
     }
     const int64_t n_pt_all = n_point_tiles(P);

@@ -157,7 +157,10 @@ class _GraphedStep:
 
     def run(self, pred, mask, t):
         abar = self.sd._alphas_host[t]
-        self.scal.copy_(torch.tensor([abar ** 0.5, (1.0 - abar) ** 0.5, 1.0 - abar, float(t)]), non_blocking=True)
+        # scalars travel as kernel arguments of four fill launches: an asynchronous copy from a temporary host
+        # tensor can execute after that tensor's memory has been reused (seen as sporadic garbage timesteps)
+        for k, v in enumerate((abar ** 0.5, (1.0 - abar) ** 0.5, 1.0 - abar, float(t))):
+            self.scal[k].fill_(v)
         self.pred.data.copy_(pred.detach())
         self.mask.copy_(mask)
         self.graph.replay()
