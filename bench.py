@@ -320,11 +320,16 @@ def main():
                 ts.append(time.perf_counter() - tg)
             sd_g.use_graphs = False
             return float(np.median(ts)) * 1e3
-        ms_graph32 = graphed_ms(sd, 1e-4)
-        sd16 = StableDiffusion(device, True, False)
-        ms_graph16 = graphed_ms(sd16, 1.0)
-        del sd16
-        torch.cuda.empty_cache()
+        ms_graph32 = ms_graph16 = None
+        if world == 1:       # per-GPU numbers; not captured next to a live RCCL communicator (its watchdog thread may
+            try:             # touch the device during a global-mode capture)
+                ms_graph32 = graphed_ms(sd, 1e-4)
+                sd16 = StableDiffusion(device, True, False)
+                ms_graph16 = graphed_ms(sd16, 1.0)
+                del sd16
+            except Exception as e:                            # reported, never fatal for the bench line
+                print(f'[bench] hipGraph leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
+            torch.cuda.empty_cache()
         opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                     text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                     colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
