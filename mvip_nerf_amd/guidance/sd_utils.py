@@ -26,7 +26,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
 from .._lib import ptr, stream, call
 
 img2mse = lambda x, y: torch.mean((x - y) ** 2)

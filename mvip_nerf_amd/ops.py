@@ -3,7 +3,6 @@
 Every function here launches HIP kernels from libmvipnerf.so on the current torch stream.
 Nothing falls back to torch ops or the CPU: inputs must be dense fp32 tensors on the GPU.
 """
-import ctypes
 import weakref
 
 import torch

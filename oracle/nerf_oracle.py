@@ -15,7 +15,6 @@ explicit arguments, which is what the reference's own `pytest=True` hooks do
 Reference citations are relative to /root/reference/.
 """
 import math
-import numpy as np
 import torch
 import torch.nn.functional as F
 
