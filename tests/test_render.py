@@ -121,6 +121,40 @@ def test_render_chunking_and_rays_argument(cuda):
     np.testing.assert_array_equal(N(a[3]).reshape(-1), N(b[3]))
 
 
+def test_full_size_frame_properties(cuda):
+    """BASELINE's full size (378x504 rays, 64 + 128 samples, 36.6 M points) through properties that do not need
+    the oracle: chunk invariance and ray-permutation equivariance are BIT-exact (every ray is independent, whatever
+    tile of whichever kernel it lands in), the compositing identities hold per ray, and a strided sample of the
+    frame equals the oracle."""
+    from mvip_nerf_amd import run, ops
+    tr, te, _, _ = build(0, 1, cuda)
+    H, W, f = 378, 504, 383.65
+    c2w = O.bench_poses(1)[0].to(cuda)
+    ro, rd = ops.get_rays(H, W, f, c2w)
+    rays = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    perm = torch.randperm(H * W, generator=torch.Generator().manual_seed(0)).to(cuda)
+    kw = dict(te, retraw=False)
+    with torch.no_grad():
+        a = run.render(H, W, f, chunk=1 << 15, c2w=c2w, near=1.2, far=7.74, **kw)
+        b = run.render(H, W, f, chunk=H * W, rays=rays, near=1.2, far=7.74, **kw)
+        c = run.render(H, W, f, chunk=77777, rays=rays[:, perm], near=1.2, far=7.74, **kw)
+    for k in range(4):
+        flat = a[k].reshape(H * W, -1)
+        assert torch.equal(flat, b[k].reshape(H * W, -1)), k
+        assert torch.equal(flat[perm], c[k].reshape(H * W, -1)), k
+    acc, w = a[2].reshape(-1), a[4]['weights'].reshape(H * W, -1)
+    assert torch.isfinite(a[0]).all() and float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-5
+    np.testing.assert_allclose(N(w.sum(-1)), N(acc), rtol=0, atol=2e-6)
+    z = a[4]['z_vals'].reshape(H * W, -1)
+    assert z.shape[1] == 128 and bool((z[:, 1:] >= z[:, :-1]).all())              # merged depths stay sorted
+    sel = torch.arange(0, H * W, 997, device=cuda)
+    rows = O.assemble_ray_batch(ro.reshape(-1, 3)[sel].cpu(), rd.reshape(-1, 3)[sel].cpu(), 1.2, 7.74)
+    ref = O.render_rays(rows, {k: torch.from_numpy(v) for k, v in seeded_state_dict(0).items()},
+                        {k: torch.from_numpy(v) for k, v in seeded_state_dict(1).items()}, 64, 64, lindisp=True,
+                        white_bkgd=True)
+    np.testing.assert_allclose(N(a[0].reshape(-1, 3)[sel]), N(ref['rgb_map']), rtol=1e-4, atol=1e-5)
+
+
 def test_train_mode_rng_stream_matches_reference_order(cuda):
     """Seeded train-mode render consumes torch's device RNG as the reference does: rand[B,Nc],
     randn[B,Nc], rand[B,Nf], randn[B,Nc+Nf].  Reproduce the draws by hand and feed the oracle."""
