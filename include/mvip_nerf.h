@@ -293,6 +293,11 @@ int mvip_hashgrid_forward(const float *x, const float *table, const void *levels
 int mvip_hashgrid_backward(const float *x, const float *d_features, const void *levels, int64_t P, float bound,
                            float *d_table, void *stream);
 int mvip_sh4(const float *dirs, int64_t P, float *out, void *stream);
+/* Opt-in table gradient with tiny-cuda-nn's own arithmetic for the scattered contributions (half-precision pair
+ * atomics): scale2 = {s, 1/s} from mvip_absmax_scale(d_features); d_table (fp32) and d_table_h2 ([n_entries] fp16
+ * pairs) zeroed by the caller; gradient = d_table + d_table_h2 * (16 * scale2[1]). */
+int mvip_hashgrid_backward_half2(const float *x, const float *d_features, const void *levels, int64_t P, float bound,
+                                 const float *scale2, float *d_table, void *d_table_h2, void *stream);
 
 /* Fused no-grad NeRF_TCNN.forward (run_nerf_helpers_tcnn.py:88-112): x [P,3], dirs [P,3] -> raw [P,4] =
  * (colour 0..2, sigma), in exact fp32 on the matrix pipe.  sigma_params = [64x32 | 16x64] floats, colour_params =

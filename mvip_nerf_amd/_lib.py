@@ -75,6 +75,7 @@ _SIGNATURES = {
     'mvip_hashgrid_forward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_hashgrid_backward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_sh4': (_int, [_c_f, _i64, _c_f, _c_f]),
+    'mvip_hashgrid_backward_half2': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f, _c_f, _c_f]),
     'mvip_hashgrid_mlp_packed_floats': (_i64, []),
     'mvip_hashgrid_mlp_pack': (_int, [_c_f, _c_f, _c_f, _c_f]),
     'mvip_hashgrid_nerf_forward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),

@@ -88,9 +88,20 @@ constexpr int HG_TILE = 4096;
 constexpr int HG_SLOTS = 2048;
 constexpr uint32_t HG_EMPTY = 0xFFFFFFFFu;
 
+//
+// HALF2 (opt-in, NeRF_TCNN.table_grad_atomics = 'half2'): the memory-side atomic COUNT bounds this kernel,
+// and gfx950 has a packed pair atomic only for 16-bit floats.  Contributions that miss the LDS map (the scattered
+// fine levels) then go out as ONE global_atomic_pk_add_f16 carrying both features, scaled by a power of two taken
+// from max|dout| (`scale2`, device memory), into a separate half-precision table; the per-tile sums of the LDS map
+// stay fp32 atomics into the fp32 table.  The caller adds table_h / scale to the fp32 table.  This is the arithmetic
+// tiny-cuda-nn itself uses for these gradients (__half2 atomics); fp32 pairs remain the default.
+typedef _Float16 hg_h2 __attribute__((ext_vector_type(2)));
+
+template <bool HALF2>
 __global__ void __launch_bounds__(256)
 hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, const HgLevel *__restrict__ levels,
-                   int64_t P, float bound, float *__restrict__ dtable) {
+                   int64_t P, float bound, float *__restrict__ dtable, hg_h2 *__restrict__ dtable_h,
+                   const float *__restrict__ scale2) {
     __shared__ uint32_t keys[HG_SLOTS];
     __shared__ float acc0[HG_SLOTS], acc1[HG_SLOTS];
     for (int s = threadIdx.x; s < HG_SLOTS; s += 256) { keys[s] = HG_EMPTY; acc0[s] = 0.f; acc1[s] = 0.f; }
@@ -98,6 +109,8 @@ hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, 
     const int level = blockIdx.y;
     const HgLevel L = levels[level];
     float *tab = dtable + 2 * (int64_t)L.offset;
+    hg_h2 *tab_h = HALF2 ? dtable_h + L.offset : nullptr;
+    const float hs = HALF2 ? scale2[0] * 0.0625f : 1.f;        // max|dout| * hs in [2^5, 2^6): 2^10 of headroom
     const int64_t p0 = (int64_t)blockIdx.x * HG_TILE;
 #pragma unroll 1
     for (int it = 0; it < HG_TILE / 256; ++it) {
@@ -127,10 +140,15 @@ hg_backward_kernel(const float *__restrict__ x, const float *__restrict__ dout, 
                 slot = (slot + 1) & (HG_SLOTS - 1);
             }
             if (!done) {
-                unsafeAtomicAdd(tab + 2 * (int64_t)idx, wk * g0);
+                if constexpr (HALF2) {
+                    const hg_h2 v = {(_Float16)(wk * g0 * hs), (_Float16)(wk * g1 * hs)};
+                    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) hg_h2 *)(tab_h + idx), v);
+                } else {
+                    unsafeAtomicAdd(tab + 2 * (int64_t)idx, wk * g0);
 #ifndef MVIP_EXPERIMENT_HG_ONE_ATOMIC
-                unsafeAtomicAdd(tab + 2 * (int64_t)idx + 1, wk * g1);
+                    unsafeAtomicAdd(tab + 2 * (int64_t)idx + 1, wk * g1);
 #endif
+                }
             }
         }
     }
@@ -199,8 +217,23 @@ extern "C" int mvip_hashgrid_backward(const float *x, const float *d_features, c
     if (P == 0) return MVIP_OK;
     if (!x || !d_features || !levels || !d_table) return MVIP_EINVAL;
     const dim3 grid((unsigned)((P + HG_TILE - 1) / HG_TILE), HG_LEVELS);
-    hipLaunchKernelGGL(hg_backward_kernel, grid, dim3(256), 0, as_stream(stream), x, d_features,
-                       (const HgLevel *)levels, P, bound, d_table);
+    hipLaunchKernelGGL((hg_backward_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, d_features,
+                       (const HgLevel *)levels, P, bound, d_table, (hg_h2 *)nullptr, (const float *)nullptr);
+    return check_launch();
+}
+
+// opt-in variant: d_table (fp32, [n_entries][2]) receives the per-tile sums, d_table_h2 ([n_entries] half pairs) the
+// scattered contributions multiplied by scale2[0] / 16; scale2 = {s, 1/s} from mvip_absmax_scale(d_features).
+// Zero both tables first; the table gradient is d_table + d_table_h2 * (16 * scale2[1]).
+extern "C" int mvip_hashgrid_backward_half2(const float *x, const float *d_features, const void *levels, int64_t P,
+                                            float bound, const float *scale2, float *d_table, void *d_table_h2,
+                                            void *stream) {
+    if (P < 0) return MVIP_EINVAL;
+    if (P == 0) return MVIP_OK;
+    if (!x || !d_features || !levels || !scale2 || !d_table || !d_table_h2) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((P + HG_TILE - 1) / HG_TILE), HG_LEVELS);
+    hipLaunchKernelGGL((hg_backward_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, d_features,
+                       (const HgLevel *)levels, P, bound, d_table, (hg_h2 *)d_table_h2, scale2);
     return check_launch();
 }
 

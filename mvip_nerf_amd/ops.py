@@ -603,34 +603,42 @@ def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None):
 
 class _HashGrid(torch.autograd.Function):
     """Multiresolution hash-grid features [32, P] (level-major) of points x [P, 3]; gradient w.r.t. the table
-    by fp32 atomics (positions never need a gradient on this path)."""
+    by fp32 atomics (positions never need a gradient on this path).  half2=True: the scattered fine-level
+    contributions go out as half-precision pair atomics (tiny-cuda-nn's arithmetic; half the atomic count)."""
 
     @staticmethod
-    def forward(ctx, x, table, levels, bound):
+    def forward(ctx, x, table, levels, bound, half2):
         xc = _f32c(x.detach())
         tc = table.detach().contiguous()
         P = xc.shape[0]
         out = torch.empty((32, P), device=xc.device, dtype=torch.float32)
         call('mvip_hashgrid_forward', ptr(xc), ptr(tc), ptr(levels, torch.int32), P, float(bound), ptr(out), stream())
         ctx.save_for_backward(xc, levels)
-        ctx.meta = (float(bound), tc.numel())
+        ctx.meta = (float(bound), tc.numel(), bool(half2))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         xc, levels = ctx.saved_tensors
-        bound, n = ctx.meta
+        bound, n, half2 = ctx.meta
         d = dout.contiguous().float()
         dtable = torch.zeros(n, device=xc.device, dtype=torch.float32)
-        call('mvip_hashgrid_backward', ptr(xc), ptr(d), ptr(levels, torch.int32), xc.shape[0], bound, ptr(dtable),
-             stream())
-        return None, dtable, None, None
+        if half2:
+            scale2 = absmax_scale(d)
+            dtable_h = torch.zeros(n, device=xc.device, dtype=torch.float16)
+            call('mvip_hashgrid_backward_half2', ptr(xc), ptr(d), ptr(levels, torch.int32), xc.shape[0], bound,
+                 ptr(scale2), ptr(dtable), ptr(dtable_h, torch.float16), stream())
+            dtable += dtable_h.float() * (16.0 * scale2[1])
+        else:
+            call('mvip_hashgrid_backward', ptr(xc), ptr(d), ptr(levels, torch.int32), xc.shape[0], bound, ptr(dtable),
+                 stream())
+        return None, dtable, None, None, None
 
 
-def hashgrid_encode(x, table, levels, bound=0.0):
+def hashgrid_encode(x, table, levels, bound=0.0, half2_atomics=False):
     """x [P,3] (raw coordinates in [-bound, bound], or already in [0,1] when bound == 0), table flat
     [n_entries*2], levels [16,4] int32 -> [32, P]."""
-    return _HashGrid.apply(x, table, levels, bound)
+    return _HashGrid.apply(x, table, levels, bound, half2_atomics)
 
 
 def sh4(dirs):

@@ -76,6 +76,7 @@ class NeRF_TCNN(nn.Module):
                 c[:2048].view(64, 32), c[2048:6144].view(64, 64), c[6144:7168].view(16, 64))
 
     fused_inference = True          # no-grad forwards run the fused gather + MFMA kernel (csrc/hashgrid_fused.hip)
+    table_grad_atomics = 'float32'  # or 'half2': tiny-cuda-nn's half-pair atomics for the scattered contributions
 
     def _packed_mlps(self):
         key = (self.sigma_net.params._version, self.color_net.params._version, self.sigma_net.params.data_ptr())
@@ -91,7 +92,8 @@ class NeRF_TCNN(nn.Module):
         if self.fused_inference and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return ops.hashgrid_nerf_forward(x, d, self.encoder.params, self.levels, self._packed_mlps(), float(self.bound))
         W1, W2, C1, C2, C3 = self.mlp_matrices()
-        feats = ops.hashgrid_encode(x, self.encoder.params, self.levels, float(self.bound))      # [32, N]
+        feats = ops.hashgrid_encode(x, self.encoder.params, self.levels, float(self.bound),
+                                    self.table_grad_atomics == 'half2')      # [32, N]
         h = ops.linear_cm(W2, torch.relu(ops.linear_cm(W1, feats)))                               # [16, N]
         sh = ops.sh4(d)                                                                           # [16, N]
         # the colour network's 31 inputs are padded to 32 with ones (tiny-cuda-nn pads network inputs to a

@@ -183,3 +183,32 @@ def test_skinny_weight_gradient_kernel(cuda):
     (W @ X).backward(dY)
     np.testing.assert_allclose(N(gw), N(W.grad), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(N(gx), N(X.grad), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_half2_table_gradient_option(cuda):
+    """Opt-in half-pair atomics for the scattered table-gradient contributions (tiny-cuda-nn's arithmetic) against
+    the default fp32 atomics: same gradient to fp16 accumulation accuracy, nothing lost to under/overflow for
+    gradients 1e-9 .. 1e+3 in magnitude."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.run_nerf_helpers_tcnn import level_table
+    tab, n = level_table(100)
+    levels = torch.from_numpy(tab.copy()).to(cuda)
+    g = torch.Generator().manual_seed(8)
+    P = 65536
+    o = (torch.rand(P // 64, 1, 3, generator=g) * 2 - 1) * 0.3                    # ray-ordered points
+    dd = torch.nn.functional.normalize(torch.randn(P // 64, 1, 3, generator=g), dim=-1)
+    x = (o + dd * torch.linspace(1.2, 7.7, 64)[None, :, None]).reshape(-1, 3).to(cuda)
+    for mag in (1e-9, 1.0, 1e3):
+        dout = (torch.randn(32, P, generator=g) * mag).to(cuda)
+        grads = []
+        for half2 in (False, True):
+            t = torch.zeros(n * 2, device=cuda, requires_grad=True)
+            ops.hashgrid_encode(x, t, levels, 100.0, half2).backward(dout)
+            grads.append(t.grad)
+        a, b = grads
+        assert torch.isfinite(b).all()
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 3e-3, (mag, rel)
+        fine = 2 * int(tab.view(np.uint32)[12, 2])                                 # a scattered level on its own
+        assert float((a[fine:] - b[fine:]).norm() / a[fine:].norm()) < 3e-3

@@ -12,6 +12,9 @@ a = bench.make_args()
 a.no_tcnn, a.netchunk, a.lrate = False, 1 << 20, 1e-2
 scene = SyntheticScene(bench.H, bench.W, bench.FOCAL, bench.NEAR, bench.FAR, device=dev)
 tr = SecondStageTrainer(a, scene, dev, guidance=None)
+if os.environ.get('MVIP_HG_HALF2') == '1':
+    for net in (tr.kw_train['network_fn'], tr.kw_train['network_fine']):
+        net.table_grad_atomics = 'half2'
 for k in range(3):
     tr.step(k)
 torch.cuda.synchronize()

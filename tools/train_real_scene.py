@@ -13,6 +13,7 @@ ap.add_argument('--iters', type=int, default=3000)
 ap.add_argument('--rays', type=int, default=4096)
 ap.add_argument('--train-precision', type=int, default=0)
 ap.add_argument('--tcnn', action='store_true', help='train the hash-grid model (NeRF_TCNN) instead of the 8x256 MLPs')
+ap.add_argument('--half2-atomics', action='store_true', help='hash-grid model: half-pair atomics for the table gradient')
 ap.add_argument('--oracle-view', type=int, default=1, help='render this many held-out views with the CPU oracle')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -38,6 +39,8 @@ else:
 kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
 for _n in (tr['network_fn'], tr['network_fine']):
     _n.train_precision = a.train_precision
+    if a.tcnn and a.half2_atomics:
+        _n.table_grad_atomics = 'half2'
 g = torch.Generator(device=dev).manual_seed(0)
 t0 = time.perf_counter()
 log = []
@@ -69,10 +72,11 @@ with torch.no_grad():
         psnr_hip.append(float(mse2psnr(img2mse(rgb, images[v]))))
 res['psnr_heldout_hip'] = psnr_hip
 if a.tcnn:
-    res['model'] = 'NeRF_TCNN (hash grid)'
+    res['model'] = 'NeRF_TCNN (hash grid)' + (', half2 table-gradient atomics' if a.half2_atomics else '')
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'real_scene_r1_tcnn.json'), 'w'), indent=1)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'real_scene_r1_tcnn_half2.json' if a.half2_atomics else
+                                     'real_scene_r1_tcnn.json'), 'w'), indent=1)
     sys.exit(0)
 # the same trained weights rendered by the CPU oracle (the reference restatement)
 from oracle import nerf_oracle as O
