@@ -310,7 +310,7 @@ int mvip_hashgrid_nerf_forward(const float *x, const float *dirs, const float *t
 
 /* Weight gradient of one bias-free layer of that model's MLPs (what autograd derives for the reference's
  * tcnn.Network calls, run_nerf_helpers_tcnn.py:96-108): dW[M][N] = sum_p dY[m][p] X[n][p], operands channel-major
- * [C][P], 1 <= M, N <= 64, P % 32 == 0.  Writes mvip_skinny_wgrad_slabs(P) partial [M][N] slabs; their sum in
+ * [C][P], 1 <= M, N <= 64, P % 64 == 0.  Writes mvip_skinny_wgrad_slabs(P) partial [M][N] slabs; their sum in
  * index order is dW. */
 int64_t mvip_skinny_wgrad_slabs(int64_t P);
 int mvip_skinny_wgrad(const float *dY, const float *X, int64_t M, int64_t N, int64_t P, float *slabs, void *stream);

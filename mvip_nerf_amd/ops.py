@@ -669,7 +669,7 @@ def hashgrid_nerf_forward(x, dirs, table, levels, img, bound):
 
 
 def skinny_wgrad(dY, X):
-    """dW [M, N] = dY [M, P] @ X [N, P]^T for the hash-grid model's small layers (M, N <= 64, P % 32 == 0)."""
+    """dW [M, N] = dY [M, P] @ X [N, P]^T for the hash-grid model's small layers (M, N <= 64, P % 64 == 0)."""
     dYc, Xc = _f32c(dY), _f32c(X)
     M, P = dYc.shape
     N = Xc.shape[0]
@@ -696,7 +696,7 @@ class _LinearCM(torch.autograd.Function):
             dX = W.t() @ dY
         if ctx.needs_input_grad[0]:
             P = X.shape[1]
-            if P % 32 == 0 and P >= 4096 and W.shape[0] <= 64 and W.shape[1] <= 64:
+            if P % 64 == 0 and P >= 4096 and W.shape[0] <= 64 and W.shape[1] <= 64:
                 dW = skinny_wgrad(dY, X)
             else:
                 dW = dY @ X.t()
