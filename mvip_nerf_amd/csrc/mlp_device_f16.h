@@ -117,6 +117,15 @@ __device__ __forceinline__ f32x16 bias_act(const f32x16 &acc, const float *bias3
     return r;
 }
 
+// activation only (the bias came in through the MFMA C operand, see run_layer_f)
+template <bool RELU>
+__device__ __forceinline__ f32x16 act_only(const f32x16 &acc) {
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[q] = RELU ? fmaxf(acc[q], 0.f) : acc[q];
+    return r;
+}
+
 struct APair { h16x8 h, l; };      // [Ah | Al] fragments of one k-step
 
 // One layer: NT output tiles, KS k-steps of 16; BASE = absolute block offset of the layer.
@@ -124,8 +133,11 @@ struct APair { h16x8 h, l; };      // [Ah | Al] fragments of one k-step
 // (a k-step is only 96 MFMA cycles, less than the loaded LDS latency); `a0`/`a1` carry the fragments
 // of the current and the next k-step across tiles and layers.  Reads never cross a barrier-group
 // boundary early: the next group is only guaranteed to have landed after its barrier.
+// bias32 (optional): the layer's bias vector in LDS; it enters as the C operand of each tile's first MFMA, so the
+// epilogue has no additions left (acc register 4q + s of lane half hh holds output unit 32 T + 8q + 4hh + s).
 template <int BASE, int NT, int KS, bool LAST, class BFrag, class Pre, class Epi>
-__device__ __forceinline__ void run_layer_f(const StreamF &st, APair &a0, APair &a1, BFrag bfrag, Pre pre, Epi epi) {
+__device__ __forceinline__ void run_layer_f(const StreamF &st, APair &a0, APair &a1, BFrag bfrag, Pre pre, Epi epi,
+                                            const float *bias32 = nullptr) {
     using PV = decltype(pre(ic<0>{}));
     f32x16 accs[2];
     PV pvs[2];
@@ -133,8 +145,17 @@ __device__ __forceinline__ void run_layer_f(const StreamF &st, APair &a0, APair 
         constexpr int T = decltype(ti)::value;
         pvs[T & 1] = pre(ti);
         f32x16 &acc = accs[T & 1];
+        if (bias32) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bias32 + 32 * T + 8 * q + 4 * (st.lane >> 5));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[4 * q + r] = b[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
         static_for<KS>([&](auto ks) {
             constexpr int K = decltype(ks)::value;
             constexpr int blk = BASE + 2 * (T * KS + K);                     // Ah block of this k-step

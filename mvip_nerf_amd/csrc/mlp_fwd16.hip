@@ -76,14 +76,16 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // One layer: NTO output tiles x NTI input tiles; BASE = absolute index of the layer's first block.
 // bsrc(ti) -> the activation tile (f32x4) feeding input units 16 ti .. 16 ti + 15; epi(to, acc) consumes a tile.
 template <int BASE, int NTO, int NTI, bool LAST, class BSrc, class Epi>
-__device__ __forceinline__ void layer16(const Stream16 &st, f32x4 &a, BSrc bsrc, Epi epi) {
+__device__ __forceinline__ void layer16(const Stream16 &st, f32x4 &a, const float *bias, BSrc bsrc, Epi epi) {
     // Two accumulator tiles alternate; the epilogue of tile t-1 is issued one block into tile t, where its VALU
     // instructions run under MFMAs instead of after a drained chain.
     f32x4 accs[2];
     static_for<NTO>([&](auto to_) {
         constexpr int TO = decltype(to_)::value;
         f32x4 &acc = accs[TO & 1];
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the layer's bias enters as the C operand of the tile's first MFMA (one LDS read per tile instead of a read
+        // plus four adds in the epilogue: 202.9 -> 201.0 ms on the bench launch)
+        acc = *reinterpret_cast<const f32x4 *>(bias + 16 * TO + 4 * (st.lane >> 4));
         static_for<NTI>([&](auto ti_) {
             constexpr int TI = decltype(ti_)::value;
             constexpr int bi = BASE + TO * NTI + TI;
@@ -116,17 +118,18 @@ __device__ __forceinline__ void layer16(const Stream16 &st, f32x4 &a, BSrc bsrc,
     epi(ic<NTO - 1>{}, accs[(NTO - 1) & 1]);
 }
 
+// epilogue of one output tile: the bias already entered through the MFMA C operand (layer16), what is left is the
+// NaN-preserving ReLU -- one integer max per value (see mlp_device.h)
 template <bool RELU>
-__device__ __forceinline__ f32x4 bias_act16(const f32x4 &acc, const float *bias16, int g) {
+__device__ __forceinline__ f32x4 act16(const f32x4 &acc) {
 #ifdef MVIP_EXPERIMENT_NO_EPILOGUE         // timing experiment only
     return acc;
 #endif
-    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias16 + 4 * g);
     f32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float v = acc[i] + b[i];
-        if (RELU) {                       // NaN-preserving ReLU as one integer max (see mlp_device.h)
+        float v = acc[i];
+        if (RELU) {
             const int bits = __builtin_bit_cast(int, v);
             v = __builtin_bit_cast(float, bits > 0 ? bits : 0);
         }
@@ -195,22 +198,22 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     f32x4 h[16], o[16];
 
     // layer 0: 63(+1) -> 256
-    layer16<OFF_L0, 16, NTI_L0, false>(st, a, [&](auto ti) { return emb[ti.value]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + 16 * to.value, g); });
+    layer16<OFF_L0, 16, NTI_L0, false>(st, a, sb + SB_BIAS, [&](auto ti) { return emb[ti.value]; },
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
 #pragma unroll
     for (int t = 0; t < 16; ++t) h[t] = o[t];
     // layers 1..4
     static_for<4>([&](auto li) {
         constexpr int l = 1 + decltype(li)::value;
-        layer16<OFF_L1 + (l - 1) * LH_BLOCKS, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
-            [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + l * 256 + 16 * to.value, g); });
+        layer16<OFF_L1 + (l - 1) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
+            [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
 #pragma unroll
         for (int t = 0; t < 16; ++t) h[t] = o[t];
     });
     // layer 5: cat[encoded point (64), h4 (256)] -> 256
-    layer16<OFF_L5, 16, NTI_L5, false>(st, a,
+    layer16<OFF_L5, 16, NTI_L5, false>(st, a, sb + SB_BIAS + 5 * 256,
         [&](auto ti) { if constexpr (ti.value < 4) return emb[ti.value]; else return h[ti.value - 4]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + 5 * 256 + 16 * to.value, g); });
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
 #pragma unroll
     for (int t = 0; t < 16; ++t) h[t] = o[t];
     // layers 6, 7; sigma = alpha_linear(h7) is accumulated tile by tile in layer 7's epilogue (one weight quad
@@ -218,9 +221,9 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     float sigma = 0.f;
     static_for<2>([&](auto li) {
         constexpr int l = 6 + decltype(li)::value;
-        layer16<OFF_L6 + (l - 6) * LH_BLOCKS, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
+        layer16<OFF_L6 + (l - 6) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
             [&](auto to, const f32x4 &acc) {
-                o[to.value] = bias_act16<true>(acc, sb + SB_BIAS + l * 256 + 16 * to.value, g);
+                o[to.value] = act16<true>(acc);
                 if constexpr (l == 7) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(sb + SB_WALPHA + 16 * to.value + 4 * g);
 #pragma unroll
@@ -234,15 +237,15 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     sigma += __shfl_xor(sigma, 32, 64);
     sigma += sb[SB_BALPHA];
     // feature = feature_linear(h7), no activation
-    layer16<OFF_FEAT, 16, NTI_LH, false>(st, a, [&](auto ti) { return h[ti.value]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = bias_act16<false>(acc, sb + SB_BFEAT + 16 * to.value, g); });
+    layer16<OFF_FEAT, 16, NTI_LH, false>(st, a, sb + SB_BFEAT, [&](auto ti) { return h[ti.value]; },
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<false>(acc); });
     // view branch: cat[feature (256), encoded dir (27+5)] -> 128, relu
     // rgb = rgb_linear(v), accumulated in the view layer's epilogue
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    layer16<OFF_VIEWS, 8, NTI_LV, true>(st, a,
+    layer16<OFF_VIEWS, 8, NTI_LV, true>(st, a, sb + SB_BVIEWS,
         [&](auto ti) { if constexpr (ti.value < 16) return o[ti.value]; else return edir[ti.value - 16]; },
         [&](auto to, const f32x4 &acc) {
-            const f32x4 v = bias_act16<true>(acc, sb + SB_BVIEWS + 16 * to.value, g);
+            const f32x4 v = act16<true>(acc);
             const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 16 * to.value + 4 * g);
             const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 128 + 16 * to.value + 4 * g);
             const f32x4 w2 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 256 + 16 * to.value + 4 * g);

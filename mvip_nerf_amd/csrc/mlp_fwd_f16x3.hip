@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
     run_layer_f<OFF_L0, L0_NT, L0_KG / 2, false>(st, a0, a1,
         [&](auto ks) { return from(emb, ks.value >> 1, ks.value & 1); },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 a = bias_act<true>(acc, sb + SB_BIAS + 32 * ti.value, hh);
+            const f32x16 a = act_only<true>(acc);
             stash_tile(AT_H + ti.value, a);
             o[ti.value] = split_tile(a);
-        });
+        }, sb + SB_BIAS);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
     // layers 1..4
@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
         run_layer_f<OFF_L1 + (l - 1) * LH_BLOCKS, LH_NT, LH_KG / 2, false>(st, a0, a1,
             [&](auto ks) { return from(h, ks.value >> 1, ks.value & 1); },
             NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-                const f32x16 a = bias_act<true>(acc, sb + SB_BIAS + l * 256 + 32 * ti.value, hh);
+                const f32x16 a = act_only<true>(acc);
                 stash_tile(AT_H + 8 * l + ti.value, a);
                 o[ti.value] = split_tile(a);
-            });
+            }, sb + SB_BIAS + l * 256);
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[t] = o[t];
     });
@@ -129,20 +129,20 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
             else return from(h, (ks.value - 4) >> 1, (ks.value - 4) & 1);
         },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 a = bias_act<true>(acc, sb + SB_BIAS + 5 * 256 + 32 * ti.value, hh);
+            const f32x16 a = act_only<true>(acc);
             stash_tile(AT_H + 40 + ti.value, a);
             o[ti.value] = split_tile(a);
-        });
+        }, sb + SB_BIAS + 5 * 256);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
     // layer 6
     run_layer_f<OFF_L6, LH_NT, LH_KG / 2, false>(st, a0, a1,
         [&](auto ks) { return from(h, ks.value >> 1, ks.value & 1); },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 a = bias_act<true>(acc, sb + SB_BIAS + 6 * 256 + 32 * ti.value, hh);
+            const f32x16 a = act_only<true>(acc);
             stash_tile(AT_H + 48 + ti.value, a);
             o[ti.value] = split_tile(a);
-        });
+        }, sb + SB_BIAS + 6 * 256);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
     // layer 7 (+ the fp32 sigma head accumulated from the fp32 activations in the epilogue)
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
     run_layer_f<OFF_L6 + LH_BLOCKS, LH_NT, LH_KG / 2, false>(st, a0, a1,
         [&](auto ks) { return from(h, ks.value >> 1, ks.value & 1); },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 a7 = bias_act<true>(acc, sb + SB_BIAS + 7 * 256 + 32 * ti.value, hh);
+            const f32x16 a7 = act_only<true>(acc);
             stash_tile(AT_H + 56 + ti.value, a7);
             sigma += dot_tiles<1>(&a7, sb + SB_WALPHA + 32 * ti.value, hh);
             o[ti.value] = split_tile(a7);
-        });
+        }, sb + SB_BIAS + 7 * 256);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = o[t];
     sigma += __shfl_xor(sigma, 32, 64);
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
     run_layer_f<OFF_FEAT, LH_NT, LH_KG / 2, false>(st, a0, a1,
         [&](auto ks) { return from(h, ks.value >> 1, ks.value & 1); },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 a = bias_act<false>(acc, sb + SB_BFEAT + 32 * ti.value, hh);
+            const f32x16 a = act_only<false>(acc);
             stash_tile(AT_FEAT + ti.value, a);
             o[ti.value] = split_tile(a);
-        });
+        }, sb + SB_BFEAT);
     // view branch (+ the fp32 rgb head); the direction encoding is formed only now (16 fewer live
     // registers through the trunk)
     Frag edir;
@@ -182,12 +182,12 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
             else return FragPair{edir.hi[ks.value - 16], edir.lo[ks.value - 16]};
         },
         NoPre{}, [&](auto ti, const f32x16 &acc, int) {
-            const f32x16 v = bias_act<true>(acc, sb + SB_BVIEWS + 32 * ti.value, hh);
+            const f32x16 v = act_only<true>(acc);
             stash_tile(AT_V + ti.value, v);
             r0 += dot_tiles<1>(&v, sb + SB_WRGB + 32 * ti.value, hh);
             r1 += dot_tiles<1>(&v, sb + SB_WRGB + 128 + 32 * ti.value, hh);
             r2 += dot_tiles<1>(&v, sb + SB_WRGB + 256 + 32 * ti.value, hh);
-        });
+        }, sb + SB_BVIEWS);
     r0 += __shfl_xor(r0, 32, 64);
     r1 += __shfl_xor(r1, 32, 64);
     r2 += __shfl_xor(r2, 32, 64);
