@@ -84,7 +84,10 @@ hg_forward_kernel(const float *__restrict__ x, const float2 *__restrict__ table,
 // first sums contributions per entry in an LDS hash map (8192 slots, open addressing, 4 probes, ds_add_f32); at the end of
 // the tile every occupied slot is flushed with one pair of global atomics.  Contributions that find no slot
 // (fine levels: nearly every entry distinct) go to global memory directly.
-constexpr int HG_TILE = 4096;
+#ifndef HG_TILE_POINTS
+#define HG_TILE_POINTS 4096
+#endif
+constexpr int HG_TILE = HG_TILE_POINTS;
 #ifndef HG_SLOTS_LOG2
 #define HG_SLOTS_LOG2 13      // 8192 slots = 96 KB: one workgroup per CU, but the middle levels aggregate (iteration 14.9 -> 14.4 ms vs 2048)
 #endif
