@@ -172,7 +172,12 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+        if x.is_cuda and USE_MFMA_CONV3X3 and not (torch.is_grad_enabled() and x.requires_grad):
+            from .. import ops
+            if ops.conv3x3_supported(self.conv, x):            # 1280 @ 32x32 and 640 @ 64x64 in the UNet
+                return ops.conv3x3_plain(x, self.conv)
+        return self.conv(x)
 
 
 # ---------------------------------------------------------------------------------------------- UNet

@@ -593,6 +593,23 @@ class _NormActConv3x3(torch.autograd.Function):
         return dx, d_ca, d_rs, None, None, None
 
 
+def conv3x3_plain(x, conv):
+    """conv(x) (+ bias) for a 3x3 / stride 1 / padding 1 convolution on the split-precision MFMA kernel, without a
+    preceding GroupNorm and without autograd: the UNet's up-sampling convolutions (the UNet runs under no_grad).  The
+    input is scaled by a power of two from its absmax before the fp16 hi/lo split, as the data gradient is."""
+    xc = _f32c(x.detach())
+    N, C, H, W = xc.shape
+    Cout, dev = conv.out_channels, xc.device
+    scale2 = absmax_scale(xc)
+    xs = _split_buffer(N, C, H * W, dev)
+    call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), stream())
+    y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
+    bias = None if conv.bias is None else _f32c(conv.bias.detach())
+    call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(_conv_packed(conv, False), torch.uint8), ptr(bias), ptr(None),
+         ptr(None), ptr(scale2), N, C, Cout, H, W, ptr(y), stream())
+    return y
+
+
 def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None):
     """conv(act(norm(x))) [+ chan_add[:, :, None, None]] [+ residual] on the HIP kernels; the caller checks
     conv3x3_supported first."""

@@ -415,3 +415,27 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
         assert float((x - y).norm() / x.norm()) < 1e-4       # replay vs replay: atomics order only
         assert float((x - z).norm() / z.norm()) < 2e-2       # vs eager: one low-weight draw is ordered differently
         assert 0.5 < float(x.abs().max() / z.abs().max()) < 2.0
+
+
+def test_plain_conv3x3_on_mfma_kernel(cuda):
+    """ops.conv3x3_plain (no GroupNorm in front: the UNet's up-sampling convolutions) vs the same convolution in fp64;
+    inputs of very different magnitude exercise the power-of-two input scale."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import Upsample2D
+    gen = torch.Generator().manual_seed(5)
+    for mag in (1e-4, 1.0, 300.0):
+        up = Upsample2D(64)
+        with torch.no_grad():
+            up.conv.weight.copy_(torch.randn(up.conv.weight.shape, generator=gen) * 0.06)
+            up.conv.bias.copy_(torch.randn(64, generator=gen) * 0.1 * mag)
+        x = torch.randn(2, 64, 8, 16, generator=gen) * mag
+        ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.double(), scale_factor=2.0, mode='nearest'),
+                                         up.conv.weight.double(), up.conv.bias.double(), padding=1)
+        up = up.to(cuda)
+        with torch.no_grad():
+            assert ops.conv3x3_supported(up.conv, torch.empty(2, 64, 16, 32, device=cuda))
+            got = up(x.to(cuda))
+        np.testing.assert_allclose(N(got), ref.detach().float().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    # with autograd enabled on a grad-carrying input the module stays on the differentiable library path
+    xg = torch.randn(1, 64, 8, 16, device=cuda, requires_grad=True)
+    assert up(xg).requires_grad
