@@ -210,8 +210,12 @@ struct ConvArgs {
 
 // MT <= 2: 80 KB of LDS and 256 registers, i.e. TWO workgroups per CU = two waves per SIMD, so one wave's LDS
 // reads, waits and epilogue run under the other wave's MFMAs.
-template <int MT>
+// TW = 32: pixel tile 8 rows x 32 columns, an MFMA column block (32 pixels) = one image row of the tile.
+// TW = 16 (images narrower than 32 pixels: the UNet's 16x16 level): tile 16 x 16, a column block = two rows of 16.
+template <int MT, int TW = CV_TW>
 __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(const ConvArgs a) {
+    constexpr int TH = 256 / TW, HW = TW + 2, PIX = (TH + 2) * HW, RPB = 32 / TW;    // RPB: image rows per column block
+    static_assert(PIX <= CV_PIX, "haloed tile must fit the input buffers");
     constexpr int WB = 3 * MT * 2 * 1024;              // weights of one stage (kernel row, 16 channels)
     __shared__ __attribute__((aligned(16))) char lds[3 * WB + 2 * CV_IN_BYTES];
     char *lds_w = lds, *lds_in = lds + 3 * WB;
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
     const int tx = tile % a.tilesX; tile /= a.tilesX;
     const int ty = tile % a.tilesY;
     const int n = tile / a.tilesY;
-    const int y0 = ty * CV_TH, x0 = tx * CV_TW;
+    const int y0 = ty * TH, x0 = tx * TW;
     const int H = a.H, W = a.W;
     const int64_t plane = (int64_t)H * W * 16;
 
@@ -237,10 +241,10 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
 #pragma unroll
     for (int r = 0; r < CV_IN_ROUNDS; ++r) {
         const int s = r * 256 + tid;
-        in_off[r] = s < 4 * CV_PIX ? -1 : -2;          // -1: halo outside the image (zero page), -2: no slot
-        if (s < 4 * CV_PIX) {
-            const int piece = s / CV_PIX, p = s - piece * CV_PIX;
-            const int row = p / CV_HW, col = p - row * CV_HW;
+        in_off[r] = s < 4 * PIX ? -1 : -2;             // -1: halo outside the image (zero page), -2: no slot
+        if (s < 4 * PIX) {
+            const int piece = s / PIX, p = s - piece * PIX;
+            const int row = p / HW, col = p - row * HW;
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[r] = (int)(piece * plane) + (gy * W + gx) * 16;
         }
@@ -293,13 +297,13 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
     auto load_b = [&](const char *inb, int ky, int kx) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = (jrow0 + j + ky) * CV_HW + l32 + kx;
+            const int p = ((jrow0 + j) * RPB + l32 / TW + ky) * HW + l32 % TW + kx;
             Bh[kx][j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
-            Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + CV_PIX * 16 + p * 16);
+            Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + PIX * 16 + p * 16);
         }
     };
     auto w_base = [&](int t) { return lds_w + (t % 3) * WB + lane * 16; };
-    auto in_base = [&](int t) { return lds_in + ((t / 3) & 1) * CV_IN_BYTES + (kg * 2) * (CV_PIX * 16); };
+    auto in_base = [&](int t) { return lds_in + ((t / 3) & 1) * CV_IN_BYTES + (kg * 2) * (PIX * 16); };
 
     issue_input(0, 0);
     issue_weights(0, 0);
@@ -347,12 +351,12 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
     }
 
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
-    const int gx = x0 + l32;
+    const int gx = x0 + l32 % TW;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int gy = y0 + jrow0 + j;
+            const int gy = y0 + (jrow0 + j) * RPB + l32 / TW;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
@@ -491,7 +495,8 @@ static inline int cv_mt(int64_t Cout, int64_t tiles) {
 using namespace mvip;
 
 extern "C" int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W) {
-    return Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 16 == 0 && H > 0 && W > 0 && H % CV_TH == 0 && W % CV_TW == 0 &&
+    return Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 16 == 0 && H > 0 && W > 0 &&
+           ((H % CV_TH == 0 && W % CV_TW == 0) || (H % 16 == 0 && W % 16 == 0)) &&
            H * W <= (1 << 24);
 }
 
@@ -570,17 +575,20 @@ extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const floa
     if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
-    const int MT = cv_mt(Cout, N * (W / CV_TW) * (H / CV_TH));
+    const int tw = (W % CV_TW == 0 && H % CV_TH == 0) ? CV_TW : 16, th = 256 / tw;      // 16 x 16 tiles for narrow images
+    const int MT = tw == 16 ? 1 : cv_mt(Cout, N * (W / tw) * (H / th));
     ConvArgs a;
     a.xs = (const char *)xs; a.wp = (const char *)packed;
     const char *tail = (const char *)packed + Cout * Cin * 36;
     a.w_scale2 = (const float *)tail; a.zero16 = tail + 128;
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(Cin / 16); a.Cout = (int)Cout; a.H = (int)H; a.W = (int)W;
-    a.tilesX = (int)(W / CV_TW); a.tilesY = (int)(H / CV_TH); a.MB = (int)(Cout / (32 * MT));
+    a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
     const int64_t blocks = N * a.tilesX * a.tilesY * a.MB;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    if (MT == 4)
+    if (tw == 16)
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else if (MT == 4)
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     else if (MT == 2)
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);

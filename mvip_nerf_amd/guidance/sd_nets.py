@@ -40,7 +40,7 @@ class GroupNorm(nn.GroupNorm):
 def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
     """conv(silu(norm(x))) [+ chan_add[:, :, None, None]] [+ residual].  Device fp32 tensors whose shape the
     split-precision MFMA convolution covers (csrc/conv3x3.hip: 3x3/s1/p1, Cout % 32 == 0, Cin % 16 == 0,
-    H % 8 == 0, W % 32 == 0) run statistics -> normalise+SiLU -> convolution (+ the additions) in four HIP
+    H % 8 == 0 and W % 32 == 0, or H % 16 == 0 and W % 16 == 0) run statistics -> normalise+SiLU -> convolution (+ the additions) in four HIP
     launches; every other shape takes the GroupNorm kernel pair followed by the library convolution."""
     if x.is_cuda:
         from .. import ops
