@@ -251,7 +251,8 @@ int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G,
  * scale2 = {s, 1/s, scratch, scratch} (device, 16 bytes): power-of-two scale from the absolute maximum.
  *   y[n,co,h,w] = conv(x, W)[n,co,h,w] / (s_w s_x) + bias[co] + chan_add[n,co] + residual[n,co,h,w]
  * (bias, chan_add, residual, x_scale2 may be NULL).  Supported: Cout % 32 == 0, Cin % 16 == 0,
- * H % 8 == 0, W % 32 == 0 (mvip_conv3x3_supported); anything else returns MVIP_EINVAL. */
+ * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0) (mvip_conv3x3_supported); anything else returns
+ * MVIP_EINVAL. */
 int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W);
 int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
 int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
