@@ -282,6 +282,49 @@ int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const
                     float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a14-a16  transformer blocks of the SD UNet (unet(...) at DS_NeRF/guidance/sd_utils.py:390-403 and :240;
+ * the block structure is the published SD-1.5 one: LayerNorm -> 8-head self-attention -> LayerNorm ->
+ * cross-attention onto the 77 prompt tokens -> LayerNorm -> GEGLU feed-forward).  Activations stay
+ * channel-major [N][C][LP] (LP = tokens padded to a multiple of 256), so every linear layer is
+ * mvip_gemm_f16x3 with the weight as the A operand and no layout transposes; these entry points produce
+ * its operands and run the attention itself, all in split precision (fp16 hi/lo operands, three products,
+ * fp32 accumulation: fp32-grade results).
+ *
+ * mvip_attention_f16x3: flash-style multi-head attention, nothing of size [Lq, Lk] touches memory.
+ *   qs, ks : split planes [N][heads*NCH][2][2][Lq | LkP][8] (mvip_split_planes_strided), NCH = ceil(D/16),
+ *            head h = chunks h*NCH.., channels beyond D zero; scaled by q_scale2[0] / k_scale2[0];
+ *   vp     : mvip_attention_pack_v output (mvip_attention_v_bytes bytes), scaled by v_scale2[0];
+ *   out    : fp32 [N][heads*D][LqP], columns < Lq written;
+ *   out[n, h*D + d, i] = sum_j softmax_j(softmax_scale q_i . k_j)[j < Lk] v_j[d].
+ *   D in {40, 80, 160} (mvip_attention_supported), Lq % 32 == 0, LkP % 64 == 0, LkP >= Lk.
+ *   flags bit 0: 64-key LDS tiles for D = 40 (tuning switch; same results).
+ * mvip_attention_pack_v: v[n*sn + (h*DP + d)*sr + key*sk], d < D <= DP, key < Lk -> A fragments whose k order
+ *   is the accumulator-row order of the score tile (so the probabilities feed the second product from
+ *   registers), zero padded to LkP.
+ * mvip_absmax_scale_sections: x [outer][sections][len] -> scale2[s] = {2^k, 2^-k, bits, -} per section
+ *   (|x|max 2^k in [2^9, 2^10)), sections <= 64; one launch for the q / k / v thirds of a fused projection. */
+int mvip_attention_supported(int64_t D);
+int64_t mvip_attention_v_bytes(int64_t N, int64_t heads, int64_t D, int64_t LkP);
+int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, int64_t D, int64_t DP, int64_t Lk, int64_t LkP,
+                          int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp, void *stream);
+int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, int64_t len, float *scale2,
+                               void *stream);
+int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
+                         const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
+                         int64_t Lk, int64_t LkP, float softmax_scale, int flags, float *out, void *stream);
+/* LayerNorm over the channel axis of x [N][C][LP] for tokens < L, times out_scale (a power of two), written as
+ * split planes [N][C/16][2][2][LP][8] (zero for tokens >= L).  C % 64 == 0, LP % 64 == 0. */
+int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
+                                int64_t L, int64_t LP, float eps, float out_scale, void *xs, void *stream);
+/* GEGLU: y [N][2R][LP] -> out [N][R][LP] = y[:, :R] * gelu(y[:, R:]) (erf form) for tokens < L, zero beyond;
+ * scale2 = {2^k, 2^-k, bits, -} from the result's absolute maximum. */
+int mvip_geglu(const float *y, int64_t N, int64_t R, int64_t L, int64_t LP, float *out, float *scale2, void *stream);
+/* y [NB][M] = act(x [NB][K]) W[M][K]^T + b  (act_in: 0 identity, 1 SiLU), NB <= 8: the timestep-embedding MLP and
+ * the ResNet blocks' time projections (published SD-1.5 UNet), exact fp32, one wavefront per output feature. */
+int mvip_linear_small(const float *x, const float *W, const float *b, int64_t NB, int64_t M, int64_t K, int act_in,
+                      float *y, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * encodings of the reference's second model NeRF_TCNN
  * (DS_NeRF/run_nerf_helpers_tcnn.py:36-46 hash grid, :63-69 spherical harmonics, :91-101 forward), which
  * the reference takes from tiny-cuda-nn (absent from the reference tree; published algorithm restated).

@@ -21,6 +21,8 @@ import torch.nn.functional as F
 USE_MFMA_CONV3X3 = True
 USE_MFMA_CONV1X1 = False      # measured slower than the library at these small K (A/B: +4 ms per step)
 USE_MFMA_VAE_ATTENTION = True
+USE_HIP_TRANSFORMER = True    # UNet transformer blocks on csrc/attention.hip + csrc/transformer.hip (guidance/transformer_cm.py)
+USE_HIP_TIME_LINEARS = True   # timestep-embedding MLP and the ResNet blocks' time projections on mvip_linear_small
 
 
 # ---------------------------------------------------------------------------------------------- blocks
@@ -63,7 +65,14 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
-        t = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+        if self.time_emb_proj is None:
+            t = None
+        elif (USE_HIP_TIME_LINEARS and temb.is_cuda and temb.dtype == torch.float32 and temb.shape[0] <= 8
+              and not (torch.is_grad_enabled() and temb.requires_grad)):
+            from .. import ops
+            t = ops.linear_small(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, act_in=1)     # proj(silu(temb))
+        else:
+            t = self.time_emb_proj(F.silu(temb))
         h = norm_act_conv(self.norm1, self.conv1, x, chan_add=t)
         if self.conv_shortcut is None:
             sc = x
@@ -142,6 +151,10 @@ class Transformer2DModel(nn.Module):
         fast = False
         if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
             from .. import ops
+            if USE_HIP_TRANSFORMER:
+                from . import transformer_cm
+                if transformer_cm.supported(self, x):
+                    return transformer_cm.transformer2d_forward(self, x, ctx)
             fast = USE_MFMA_CONV1X1 and ops.conv1x1_supported(self.proj_in, x)       # 1x1 projections on the split-precision GEMM
         if fast:
             h = ops.norm_conv1x1(x, self.norm, self.proj_in).permute(0, 2, 1)
@@ -235,6 +248,11 @@ class TimestepEmbedding(nn.Module):
         self.linear_1, self.linear_2 = nn.Linear(cin, cout), nn.Linear(cout, cout)
 
     def forward(self, x):
+        if (USE_HIP_TIME_LINEARS and x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= 8
+                and not (torch.is_grad_enabled() and x.requires_grad)):
+            from .. import ops
+            h = ops.linear_small(x, self.linear_1.weight, self.linear_1.bias)
+            return ops.linear_small(h, self.linear_2.weight, self.linear_2.bias, act_in=1)
         return self.linear_2(F.silu(self.linear_1(x)))
 
 

@@ -1,0 +1,189 @@
+"""The SD UNet's Transformer2DModel (GroupNorm -> 1x1 proj_in -> BasicTransformerBlock -> 1x1 proj_out + residual;
+the unet(...) call of DS_NeRF/guidance/sd_utils.py:390-403, block structure from the published SD-1.5
+architecture) executed entirely by the hand-written split-precision kernels, forward only (the UNet runs under
+no_grad in every SDS step: no UNet backward ever).
+
+Activations stay CHANNEL-MAJOR [N, C, LP] from proj_in to proj_out (LP = tokens, padded to 256 for the 8x8 level), so
+  * every linear layer is `ops.gemm_f16x3` (weights = the packed A operand, tokens = columns): no NCHW <-> NHWC
+    transposes and no library GEMM;
+  * LayerNorm writes the GEMM's fp16 hi/lo operand planes directly (`ops.layernorm_split`);
+  * the q / k / v projections are one GEMM with the heads' rows padded to a multiple of 16 channels (40 -> 48,
+    zero rows), whose three thirds get their power-of-two scales in one launch;
+  * attention is the flash-style kernel of csrc/attention.hip (nothing of size [Lq, Lk] in memory);
+  * the prompt's key / value projections depend only on the (cached) prompt embedding: computed once per prompt.
+Stock torch ops left in here: tensor allocation, the zero-padding copy of the 8x8 level, and nothing else.
+"""
+import math
+
+import torch
+
+from .. import ops
+
+
+def _pad_head_rows(W, heads, D, DP):
+    """[heads*D, K] -> [heads*DP, K] with each head's rows at h*DP .. h*DP + D - 1 (zero rows between)."""
+    if DP == D:
+        return W.detach().contiguous()
+    out = torch.zeros((heads * DP, W.shape[1]), device=W.device, dtype=W.dtype)
+    out.view(heads, DP, -1)[:, :D] = W.detach().view(heads, D, -1)
+    return out
+
+
+def _ln_scale(ln, C):
+    """Power of two s with |LayerNorm(x)| * s < 2^15 for every input (|y| <= sqrt(C) max|gamma| + max|beta|)."""
+    bound = math.sqrt(C) * float(ln.weight.detach().abs().max()) + float(ln.bias.detach().abs().max())
+    k = int(math.floor(math.log2(30000.0 / max(bound, 1e-30))))
+    return float(2.0 ** max(-20, min(4, k)))
+
+
+def _scale_tensor(s, device):
+    return torch.tensor([s, 1.0 / s, 0.0, 0.0], device=device, dtype=torch.float32)
+
+
+class _Packed:
+    """Packed weight images of one Transformer2DModel (frozen network: rebuilt only if a weight's version moves)."""
+
+    def __init__(self, mod):
+        blk = mod.transformer_blocks[0]
+        a1, a2, ff = blk.attn1, blk.attn2, blk.ff
+        C = mod.proj_in.in_channels
+        heads = a1.heads
+        D = C // heads
+        DP = (D + 15) // 16 * 16
+        R = heads * DP
+        dev = mod.proj_in.weight.device
+        self.C, self.heads, self.D, self.DP, self.R = C, heads, D, DP, R
+        self.key = self.version_key(mod)
+        pack = ops.gemm_pack_a
+        wqkv = torch.cat([_pad_head_rows(w.weight, heads, D, DP) for w in (a1.to_q, a1.to_k, a1.to_v)], 0).contiguous()
+        self.qkv1 = pack(wqkv, 3 * R, C, C, 1)
+        self.o1 = pack(a1.to_out[0].weight.detach().contiguous(), C, C, C, 1)
+        self.bo1 = a1.to_out[0].bias.detach().contiguous()
+        self.q2 = pack(_pad_head_rows(a2.to_q.weight, heads, D, DP), R, C, C, 1)
+        ctx_dim = a2.to_k.weight.shape[1]
+        wkv = torch.cat([_pad_head_rows(a2.to_k.weight, heads, D, DP), _pad_head_rows(a2.to_v.weight, heads, D, DP)], 0)
+        self.kv2 = pack(wkv.contiguous(), 2 * R, ctx_dim, ctx_dim, 1)
+        self.ctx_dim = ctx_dim
+        self.o2 = pack(a2.to_out[0].weight.detach().contiguous(), C, C, C, 1)
+        self.bo2 = a2.to_out[0].bias.detach().contiguous()
+        w1 = ff.net[0].proj
+        self.ff1 = pack(w1.weight.detach().contiguous(), 8 * C, C, C, 1)
+        self.b1 = w1.bias.detach().contiguous()
+        self.ff2 = pack(ff.net[2].weight.detach().contiguous(), C, 4 * C, 4 * C, 1)
+        self.b2 = ff.net[2].bias.detach().contiguous()
+        self.pin = pack(mod.proj_in.weight.detach().reshape(C, C).contiguous(), C, C, C, 1)
+        self.bin = mod.proj_in.bias.detach().contiguous()
+        self.pout = pack(mod.proj_out.weight.detach().reshape(C, C).contiguous(), C, C, C, 1)
+        self.bout = mod.proj_out.bias.detach().contiguous()
+        self.ln = []
+        for ln in (blk.norm1, blk.norm2, blk.norm3):
+            s = _ln_scale(ln, C)
+            self.ln.append((ln.weight.detach().contiguous(), ln.bias.detach().contiguous(), float(ln.eps), s,
+                            _scale_tensor(s, dev)))
+        self.ctx_cache = {}
+
+    @staticmethod
+    def version_key(mod):
+        return tuple((p.data_ptr(), p._version) for p in mod.parameters())
+
+
+def supported(mod, x):
+    """fp32 device tensors, one transformer block, a head size the attention kernel is built for."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and len(mod.transformer_blocks) == 1):
+        return False
+    C = mod.proj_in.in_channels
+    heads = mod.transformer_blocks[0].attn1.heads
+    L = x.shape[2] * x.shape[3]
+    return (C % 64 == 0 and C % heads == 0 and bool(ops._lib.load().mvip_attention_supported(C // heads))
+            and L % 64 == 0 and mod.proj_in.weight.dtype == torch.float32)
+
+
+def _packed(mod):
+    pk = mod.__dict__.get('_mvip_cm')
+    if pk is None or pk.key != _Packed.version_key(mod):
+        pk = _Packed(mod)
+        mod.__dict__['_mvip_cm'] = pk
+    return pk
+
+
+def _prompt_kv(pk, ctx):
+    """Key planes / value fragments of the prompt tokens for the cross-attention (constant per prompt)."""
+    key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+    hit = pk.ctx_cache.get(key)
+    if hit is not None:
+        return hit
+    N, T, E = ctx.shape
+    TP, GP = 128, 256                          # key padding of the attention kernel / column padding of the GEMM
+    assert T <= TP and E == pk.ctx_dim
+    cpad = torch.zeros((N, GP, E), device=ctx.device, dtype=torch.float32)
+    cpad[:, :T] = ctx.detach().float()
+    xs, s2 = ops._scaled_planes(cpad, N, E, GP, GP * E, 1, E)                       # X[n][k][p] = ctx[n][p][k]
+    kv = ops.gemm_f16x3(xs, pk.kv2, N, E, 2 * pk.R, GP, x_scale2=s2)                # [N, 2R, GP]
+    sc = ops.absmax_scale_sections(kv, N, 2, pk.R * GP)
+    flat = kv.reshape(-1)
+    ks = ops.split_planes_strided(flat, N, pk.R, TP, 2 * pk.R * GP, GP, 1, sc[0:4])
+    vp = ops.attention_pack_v(flat[pk.R * GP:], N, pk.heads, pk.D, pk.DP, T, TP, 2 * pk.R * GP, GP, 1, sc[4:8])
+    hit = (ks, vp, sc[0:4], sc[4:8], T, TP)
+    pk.ctx_cache.clear()                                                             # one prompt set at a time
+    pk.ctx_cache[key] = hit
+    return hit
+
+
+def _block(h, pk, ctx, N, L, LP):
+    C, R, heads, D, DP = pk.C, pk.R, pk.heads, pk.D, pk.DP
+    # ---- self-attention ----
+    g, b, eps, s, st = pk.ln[0]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    qkv = ops.gemm_f16x3(xs, pk.qkv1, N, C, 3 * R, LP, x_scale2=st)                  # [N, 3R, LP]
+    sc = ops.absmax_scale_sections(qkv, N, 3, R * LP)
+    flat = qkv.reshape(-1)
+    qs = ops.split_planes_strided(flat, N, R, L, 3 * R * LP, LP, 1, sc[0:4])
+    ks = ops.split_planes_strided(flat[R * LP:], N, R, L, 3 * R * LP, LP, 1, sc[4:8])
+    vp = ops.attention_pack_v(flat[2 * R * LP:], N, heads, D, DP, L, L, 3 * R * LP, LP, 1, sc[8:12])
+    o = ops.attention_f16x3(qs, ks, vp, sc[0:4], sc[4:8], sc[8:12], N, heads, D, L, LP, L, L)
+    os_ = ops.split_planes_strided(o, N, C, LP, C * LP, LP, 1, sc[8:12])            # |o| <= max|v|: v's scale fits
+    h = ops.gemm_f16x3(os_, pk.o1, N, C, C, LP, bias=pk.bo1, residual=h, x_scale2=sc[8:12])
+    # ---- cross-attention onto the prompt tokens ----
+    g, b, eps, s, st = pk.ln[1]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    q = ops.gemm_f16x3(xs, pk.q2, N, C, R, LP, x_scale2=st)
+    sq = ops.absmax_scale_sections(q, 1, 1, N * R * LP)
+    qs = ops.split_planes_strided(q, N, R, L, R * LP, LP, 1, sq)
+    ks2, vp2, sk2, sv2, T, TP = _prompt_kv(pk, ctx)
+    o = ops.attention_f16x3(qs, ks2, vp2, sq, sk2, sv2, N, heads, D, L, LP, T, TP)
+    os_ = ops.split_planes_strided(o, N, C, LP, C * LP, LP, 1, sv2)
+    h = ops.gemm_f16x3(os_, pk.o2, N, C, C, LP, bias=pk.bo2, residual=h, x_scale2=sv2)
+    # ---- GEGLU feed-forward ----
+    g, b, eps, s, st = pk.ln[2]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    y = ops.gemm_f16x3(xs, pk.ff1, N, C, 8 * C, LP, bias=pk.b1, x_scale2=st)
+    act, sa = ops.geglu(y, N, 4 * C, L, LP)
+    as_ = ops.split_planes_strided(act, N, 4 * C, LP, 4 * C * LP, LP, 1, sa)
+    return ops.gemm_f16x3(as_, pk.ff2, N, 4 * C, C, LP, bias=pk.b2, residual=h, x_scale2=sa)
+
+
+def transformer2d_forward(mod, x, ctx):
+    """Transformer2DModel.forward(x [N, C, H, W], ctx [N, 77, 768]) -> [N, C, H, W]; caller checks `supported`."""
+    pk = _packed(mod)
+    N, C, H, W = x.shape
+    L = H * W
+    xc = x.detach().contiguous()
+    if L % 256 == 0:
+        LP = L
+        h = ops.norm_conv1x1(xc, mod.norm, mod.proj_in)                              # GroupNorm + 1x1 conv: [N, C, L]
+        res = xc.reshape(N, C, L)
+    else:                                                                            # the 8x8 level: pad the token axis
+        LP = (L + 255) // 256 * 256
+        hn = ops.group_norm(xc, mod.norm.weight, mod.norm.bias, mod.norm.num_groups, mod.norm.eps, False)
+        hp = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
+        hp[:, :, :L] = hn.reshape(N, C, L)
+        xs, s2 = ops._scaled_planes(hp, N, C, LP, C * LP, LP, 1)
+        h = ops.gemm_f16x3(xs, pk.pin, N, C, C, LP, bias=pk.bin, x_scale2=s2)
+        res = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
+        res[:, :, :L] = xc.reshape(N, C, L)
+    h = _block(h, pk, ctx, N, L, LP)
+    xs, s2 = ops._scaled_planes(h, N, C, LP, C * LP, LP, 1)
+    y = ops.gemm_f16x3(xs, pk.pout, N, C, C, LP, bias=pk.bout, residual=res, x_scale2=s2)
+    if LP != L:
+        y = y[:, :, :L].contiguous()
+    return y.reshape(N, C, H, W)

@@ -1,7 +1,10 @@
 """Thin tensor-level wrappers over the C ABI (allocation + autograd plumbing only).
 
-Every function here launches HIP kernels from libmvipnerf.so on the current torch stream.
-Nothing falls back to torch ops or the CPU: inputs must be dense fp32 tensors on the GPU.
+Every function of the NeRF render / training path here launches HIP kernels from libmvipnerf.so on the
+current torch stream; inputs must be dense fp32 tensors on the GPU and nothing computes on the CPU.
+Two places still call stock torch GPU ops and say so where they do: the hash-grid model's training
+forward / data-gradient products (`_LinearCM`: plain `W @ X`; only its weight gradient is a HIP kernel)
+and a few reductions / softmaxes inside the VAE mid-block attention (`_VAEAttention`).
 """
 import weakref
 
@@ -953,3 +956,64 @@ def tokens_conv1x1(h, conv, residual):
     rs = residual.detach().contiguous()
     return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias, residual=rs,
                       x_scale2=s2).reshape(rs.shape)
+
+
+# Transformer blocks of the SDS UNet: attention and token-side kernels (csrc/attention.hip, csrc/transformer.hip) -----
+
+def absmax_scale_sections(x, outer, sections, length):
+    """x viewed as [outer][sections][length] -> flat [sections * 4] device floats: {2^k, 2^-k, bits, -} per section."""
+    sc = torch.empty(sections * 4, device=x.device, dtype=_F32)
+    call('mvip_absmax_scale_sections', ptr(x), int(outer), int(sections), int(length), ptr(sc), stream())
+    return sc
+
+
+def layernorm_split(x, weight, bias, eps, N, C, L, LP, out_scale):
+    """LayerNorm over the channel axis of channel-major x [N, C, LP] (tokens < L), times the power of two
+    `out_scale`, as fp16 hi/lo split planes (the B operand of gemm_f16x3 with P = LP)."""
+    xs = _split_buffer(N, C, LP, x.device)
+    call('mvip_layernorm_split_planes', ptr(x), ptr(weight), ptr(bias), int(N), int(C), int(L), int(LP), float(eps),
+         float(out_scale), ptr(xs, torch.float16), stream())
+    return xs
+
+
+def attention_pack_v(v, N, heads, D, DP, Lk, LkP, sn, sr, sk, scale2):
+    """v.flatten()[n*sn + (h*DP + d)*sr + key*sk] -> the attention kernel's V operand (A fragments, fp16 hi/lo)."""
+    nbytes = int(_lib.load().mvip_attention_v_bytes(N, heads, D, LkP))
+    vp = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
+    call('mvip_attention_pack_v', ptr(v), int(N), int(heads), int(D), int(DP), int(Lk), int(LkP), int(sn), int(sr),
+         int(sk), ptr(scale2), ptr(vp, torch.uint8), stream())
+    return vp
+
+
+ATTENTION_FLAGS = 0      # bit 0: 64-key LDS tiles for 40-channel heads (A/B timing switch)
+
+
+def attention_f16x3(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, out=None):
+    """softmax(q k^T / sqrt(D)) v per head on the split-precision flash kernel -> fp32 [N, heads*D, LqP]
+    (columns < Lq written; allocate `out` zeroed when LqP > Lq)."""
+    if out is None:
+        mk = torch.empty if LqP == Lq else torch.zeros
+        out = mk((N, heads * D, LqP), device=qs.device, dtype=_F32)
+    call('mvip_attention_f16x3', ptr(qs, torch.float16), ptr(ks, torch.float16), ptr(vp, torch.uint8), ptr(q_scale2),
+         ptr(k_scale2), ptr(v_scale2), int(N), int(heads), int(D), int(Lq), int(LqP), int(Lk), int(LkP),
+         float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out), stream())
+    return out
+
+
+def geglu(y, N, R, L, LP):
+    """y [N, 2R, LP] -> (y[:, :R] * gelu(y[:, R:]) [N, R, LP] zero beyond L, its power-of-two scale2)."""
+    out = torch.empty((N, R, LP), device=y.device, dtype=_F32)
+    scale2 = torch.empty(4, device=y.device, dtype=_F32)
+    call('mvip_geglu', ptr(y), int(N), int(R), int(L), int(LP), ptr(out), ptr(scale2), stream())
+    return out, scale2
+
+
+def linear_small(x, W, b, act_in=0):
+    """act(x) @ W^T + b for x [NB <= 8, K] in exact fp32 (act_in: 0 identity, 1 SiLU)."""
+    xc, Wc = _f32c(x), _f32c(W)
+    NB, K = xc.shape
+    M = Wc.shape[0]
+    y = torch.empty((NB, M), device=xc.device, dtype=_F32)
+    call('mvip_linear_small', ptr(xc), ptr(Wc), ptr(None if b is None else _f32c(b)), NB, M, K, int(act_in), ptr(y),
+         stream())
+    return y

@@ -1,0 +1,212 @@
+"""The SD UNet's transformer-block kernels (csrc/attention.hip, csrc/transformer.hip, guidance/transformer_cm.py)
+against the fp64 statement of the same expressions on the host.  Tolerances are fractions of the output scale:
+split-precision MFMA products (fp16 hi+lo operands, three products, fp32 accumulation) are fp32-grade, ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _attention_case(cuda, Nb, heads, D, Lq, Lk, LqP=None, seed=0, q_gain=1.0, flags=0):
+    """q, k, v channel-major [Nb, heads*D, L] fp32 -> HIP attention vs fp64 softmax(q^T k / sqrt(D)) v."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(seed)
+    DP = (D + 15) // 16 * 16
+    LqP = LqP or Lq
+    LkP = (Lk + 63) // 64 * 64
+    q = torch.randn(Nb, heads, D, Lq, generator=gen) * q_gain
+    k = torch.randn(Nb, heads, D, Lk, generator=gen) * 1.3
+    v = torch.randn(Nb, heads, D, Lk, generator=gen) * 0.7 + 0.1
+    s = torch.einsum('nhdi,nhdj->nhij', q.double(), k.double()) * D ** -0.5
+    ref = torch.einsum('nhij,nhdj->nhdi', torch.softmax(s, -1), v.double()).reshape(Nb, heads * D, Lq)
+
+    def padded(t, L, LP):                      # [Nb, heads*DP, LP] with zero channels D..DP-1 and zero tokens >= L
+        out = torch.zeros(Nb, heads, DP, LP)
+        out[:, :, :D, :L] = t
+        return out.reshape(Nb, heads * DP, LP).to(cuda)
+    R = heads * DP
+    qd, kd, vd = padded(q, Lq, LqP), padded(k, Lk, LkP), padded(v, Lk, LkP)
+    sq, sk, sv = (ops.absmax_scale(t) for t in (qd, kd, vd))
+    qs = ops.split_planes_strided(qd, Nb, R, Lq, R * LqP, LqP, 1, sq)
+    ks = ops.split_planes_strided(kd, Nb, R, LkP, R * LkP, LkP, 1, sk)
+    vp = ops.attention_pack_v(vd, Nb, heads, D, DP, Lk, LkP, R * LkP, LkP, 1, sv)
+    old = ops.ATTENTION_FLAGS
+    ops.ATTENTION_FLAGS = flags
+    try:
+        out = ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, Lq, LqP, Lk, LkP)
+    finally:
+        ops.ATTENTION_FLAGS = old
+    assert out.shape == (Nb, heads * D, LqP)
+    got = N(out)[:, :, :Lq]
+    scale = float(ref.abs().max())
+    err = np.abs(got - ref.numpy()).max() / scale
+    return err, got, ref.numpy()
+
+
+@pytest.mark.parametrize('heads,D,Lq,Lk,LqP,flags', [
+    (8, 40, 256, 256, None, 0), (8, 40, 256, 256, None, 1), (2, 40, 1024, 1024, None, 0),   # 64x64-level heads
+    (8, 80, 256, 256, None, 0), (3, 80, 128, 1024, None, 0),                                 # 32x32 level
+    (8, 160, 256, 256, None, 0), (8, 160, 64, 64, 256, 0),                                   # 16x16 and (padded) 8x8
+    (8, 40, 256, 77, None, 0), (8, 40, 128, 77, None, 1), (8, 80, 64, 77, None, 0), (8, 160, 64, 77, 256, 0),  # prompt
+    (1, 40, 32, 1, None, 0), (1, 80, 96, 33, None, 0)])                                      # ragged key counts
+def test_attention_vs_fp64(cuda, heads, D, Lq, Lk, LqP, flags):
+    err, got, ref = _attention_case(cuda, 2, heads, D, Lq, Lk, LqP, seed=heads + D + Lq + Lk, flags=flags)
+    assert err < 3e-6, err
+
+
+def test_attention_peaked_and_uniform_scores(cuda):
+    """Peaked softmax (large logits: one key dominates) and exactly uniform scores (q = 0: every probability is
+    1/Lk, the case where the fp16 lo terms of the probabilities matter most)."""
+    err, _, _ = _attention_case(cuda, 1, 8, 40, 256, 4096, seed=5, q_gain=6.0)
+    assert err < 3e-6, err
+    err, got, ref = _attention_case(cuda, 1, 8, 40, 128, 4096, seed=6, q_gain=0.0)
+    assert err < 2e-6, err
+    err, _, _ = _attention_case(cuda, 1, 8, 80, 128, 1024, seed=7, q_gain=0.0)
+    assert err < 2e-6, err
+
+
+def test_attention_full_size_level(cuda):
+    """The UNet's largest attention (2 x 8 heads x 4096 x 4096 x 40) on a strided sample of rows vs fp64."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    Nb, heads, D, L = 2, 8, 40, 4096
+    DP, R = 48, 8 * 48
+    q = torch.randn(Nb, heads, D, L, generator=gen)
+    k = torch.randn(Nb, heads, D, L, generator=gen)
+    v = torch.randn(Nb, heads, D, L, generator=gen)
+
+    def padded(t):
+        out = torch.zeros(Nb, heads, DP, L)
+        out[:, :, :D] = t
+        return out.reshape(Nb, R, L).to(cuda)
+    qd, kd, vd = padded(q), padded(k), padded(v)
+    sq, sk, sv = (ops.absmax_scale(t) for t in (qd, kd, vd))
+    qs = ops.split_planes_strided(qd, Nb, R, L, R * L, L, 1, sq)
+    ks = ops.split_planes_strided(kd, Nb, R, L, R * L, L, 1, sk)
+    vp = ops.attention_pack_v(vd, Nb, heads, D, DP, L, L, R * L, L, 1, sv)
+    out = ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, L, L, L, L)
+    rows = torch.arange(0, L, 37)
+    s = torch.einsum('nhdi,nhdj->nhij', q[..., rows].double(), k.double()) * D ** -0.5
+    ref = torch.einsum('nhij,nhdj->nhdi', torch.softmax(s, -1), v.double()).reshape(Nb, heads * D, -1)
+    got = N(out)[:, :, rows.numpy()]
+    assert np.abs(got - ref.numpy()).max() / float(ref.abs().max()) < 3e-6
+
+
+def test_layernorm_split_feeds_gemm(cuda):
+    """LayerNorm over the (strided) channel axis written as split planes, consumed by the GEMM: W LN(x) vs fp64;
+    the padded-token variant (L = 64 inside LP = 256) leaves zero columns."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for Nb, C, L, LP, M in ((2, 320, 256, 256, 64), (2, 1280, 64, 256, 96), (1, 640, 1024, 1024, 32)):
+        x = torch.randn(Nb, C, LP, generator=gen) * 2.0 + 0.5
+        g = torch.randn(C, generator=gen) * 0.3 + 1.0
+        b = torch.randn(C, generator=gen) * 0.2
+        W = torch.randn(M, C, generator=gen) / C ** 0.5
+        ln = torch.nn.functional.layer_norm(x.double().transpose(1, 2), (C,), g.double(), b.double(), 1e-5)   # [Nb, LP, C]
+        ref = torch.einsum('mc,nlc->nml', W.double(), ln)
+        ref[:, :, L:] = 0
+        xs = ops.layernorm_split(x.to(cuda), g.to(cuda), b.to(cuda), 1e-5, Nb, C, L, LP, 16.0)
+        s2 = torch.tensor([16.0, 1 / 16.0, 0, 0], device=cuda)
+        y = ops.gemm_f16x3(xs, ops.gemm_pack_a(W.to(cuda), M, C, C, 1), Nb, C, M, LP, x_scale2=s2)
+        np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+
+
+def test_geglu_and_linear_small(cuda):
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    Nb, R, L, LP = 2, 96, 200, 256
+    y = torch.randn(Nb, 2 * R, LP, generator=gen) * 2.0
+    ref = y[:, :R].double() * torch.nn.functional.gelu(y[:, R:].double())
+    ref[:, :, L:] = 0
+    out, s2 = ops.geglu(y.to(cuda), Nb, R, L, LP)
+    np.testing.assert_allclose(N(out), ref.float().numpy(), rtol=2e-6, atol=2e-6)
+    s = float(s2[0])
+    assert 512.0 <= float(ref.abs().max()) * s < 1024.0 and abs(float(s2[1]) * s - 1.0) < 1e-7
+    for NB, M, K, act in ((2, 1280, 320, 0), (2, 321, 1280, 1), (8, 7, 50, 1), (1, 64, 64, 0)):
+        x = torch.randn(NB, K, generator=gen)
+        W = torch.randn(M, K, generator=gen) / K ** 0.5
+        b = torch.randn(M, generator=gen)
+        xin = torch.nn.functional.silu(x.double()) if act else x.double()
+        ref = xin @ W.double().t() + b.double()
+        got = ops.linear_small(x.to(cuda), W.to(cuda), b.to(cuda), act_in=act)
+        np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+
+
+def test_absmax_scale_sections(cuda):
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 4, 1001, generator=gen)
+    x[:, 1] *= 100.0
+    x[:, 2] *= 1e-3
+    x[1, 3, 5] = float('nan')
+    sc = N(ops.absmax_scale_sections(x.to(cuda), 3, 4, 1001)).reshape(4, 4)
+    for s in range(4):
+        m = float(torch.nan_to_num(x[:, s], nan=0.0).abs().max())
+        assert 512.0 <= m * sc[s, 0] < 1024.0 and sc[s, 0] * sc[s, 1] == 1.0
+
+
+@pytest.mark.parametrize('C,heads,H,W', [(320, 8, 16, 16), (640, 8, 16, 16), (1280, 8, 16, 16), (1280, 8, 8, 8)])
+def test_transformer2d_hip_path_vs_fp64_module(cuda, C, heads, H, W):
+    """Transformer2DModel (GroupNorm, proj_in, self-attention, cross-attention, GEGLU, proj_out, residual) on the
+    HIP kernels vs the SAME module evaluated in fp64 by torch on the host."""
+    from mvip_nerf_amd.guidance import sd_nets, transformer_cm
+    torch.manual_seed(C + H)
+    mod = sd_nets.Transformer2DModel(C, heads, 768).eval()
+    with torch.no_grad():
+        for name, p in mod.named_parameters():                     # non-trivial norms and biases
+            if 'norm' in name:
+                p.add_(torch.randn_like(p) * 0.2)
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, C, H, W) * 1.5
+    ctx = torch.randn(2, 77, 768)
+    with torch.no_grad():
+        ref = mod.double()(x.double(), ctx.double())
+    mod = mod.float().to(cuda)
+    xd, cd = x.to(cuda), ctx.to(cuda)
+    assert transformer_cm.supported(mod, xd)
+    with torch.no_grad():
+        got = mod(xd, cd)
+        again = mod(xd, cd)                                        # cached prompt projections
+    assert torch.equal(got, again)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=1e-5 * scale)
+    # a changed weight invalidates the packed images
+    with torch.no_grad():
+        mod.proj_out.bias.add_(1.0)
+        moved = mod(xd, cd)
+    np.testing.assert_allclose(N(moved), N(got) + 1.0, rtol=0, atol=1e-5 * scale)
+
+
+def test_unet_forward_has_no_library_attention_or_gemm(cuda):
+    """The whole UNet forward at a reduced spatial size: HIP transformer path == library path (fp32 both), and the
+    profiler of the HIP run lists no library attention / GEMM kernel (names `attn_fwd`, `Cijk_`)."""
+    from mvip_nerf_amd.guidance import sd_nets
+    torch.manual_seed(0)
+    unet = sd_nets.UNet2DConditionModel().to(cuda).eval()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 9, 64, 64, device=cuda)
+    ctx = torch.randn(2, 77, 768, device=cuda)
+    t = torch.tensor(417, device=cuda)
+    old1x1 = sd_nets.USE_MFMA_CONV1X1
+    with torch.no_grad():
+        sd_nets.USE_HIP_TRANSFORMER = sd_nets.USE_HIP_TIME_LINEARS = sd_nets.USE_MFMA_CONV1X1 = False
+        try:
+            ref = unet(x, t, encoder_hidden_states=ctx)[0]
+        finally:
+            sd_nets.USE_HIP_TRANSFORMER = sd_nets.USE_HIP_TIME_LINEARS = True
+            sd_nets.USE_MFMA_CONV1X1 = old1x1
+        unet(x, t, encoder_hidden_states=ctx)                      # warm-up: packs weights, caches prompt k/v
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            got = unet(x, t, encoder_hidden_states=ctx)[0]
+            torch.cuda.synchronize()
+    np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-4 * float(ref.abs().max()))
+    names = [e.key for e in prof.key_averages()]
+    assert any('attn_f16x3_kernel' in n for n in names)
+    assert not [n for n in names if 'attn_fwd' in n or 'Cijk_Alik' in n], names        # no library attention, no hipBLASLt linear
