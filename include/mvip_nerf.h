@@ -280,6 +280,12 @@ int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, 
 int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                     const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                     float *y, void *stream);
+/* the same with the workgroup tile forced (timing switch; identical arithmetic per output element up to the k order
+ * inside a stage, which is the same): cfg 0 = by shape (what mvip_gemm_f16x3 does), 1 = 32/64 rows x 256 columns,
+ * 2 = 128 x 256 (M % 128 == 0), 3 = 128 x 128 (M % 128 == 0), 4 = 64 x 128 (M % 64 == 0). */
+int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                        float *y, int cfg, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a14-a16  transformer blocks of the SD UNet (unet(...) at DS_NeRF/guidance/sd_utils.py:390-403 and :240;
@@ -301,24 +307,31 @@ int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const
  * mvip_attention_pack_v: v[n*sn + (h*DP + d)*sr + key*sk], d < D <= DP, key < Lk -> A fragments whose k order
  *   is the accumulator-row order of the score tile (so the probabilities feed the second product from
  *   registers), zero padded to LkP.
- * mvip_absmax_scale_sections: x [outer][sections][len] -> scale2[s] = {2^k, 2^-k, bits, -} per section
- *   (|x|max 2^k in [2^9, 2^10)), sections <= 64; one launch for the q / k / v thirds of a fused projection. */
+ * mvip_absmax_scale_sections: x [outer][sections][len] -> scale2[s] = {2^k, 2^-k, -, -} per section
+ *   (|x|max 2^k in [2^9, 2^10)), sections <= 64; one launch for the q / k / v thirds of a fused projection.
+ *   zero_words64: 64 caller-owned 32-bit scratch words that are ZERO on entry and left zero on exit (allocate
+ *   zeroed once per stream; the maxima are collected there with atomics, which saves a zeroing launch per use). */
 int mvip_attention_supported(int64_t D);
 int64_t mvip_attention_v_bytes(int64_t N, int64_t heads, int64_t D, int64_t LkP);
 int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, int64_t D, int64_t DP, int64_t Lk, int64_t LkP,
                           int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp, void *stream);
 int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, int64_t len, float *scale2,
-                               void *stream);
+                               void *zero_words64, void *stream);
 int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
                          const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
                          int64_t Lk, int64_t LkP, float softmax_scale, int flags, float *out, void *stream);
 /* LayerNorm over the channel axis of x [N][C][LP] for tokens < L, times out_scale (a power of two), written as
- * split planes [N][C/16][2][2][LP][8] (zero for tokens >= L).  C % 64 == 0, LP % 64 == 0. */
+ * split planes [N][C/16][2][2][LP][8] (zero for tokens >= L).  C % 64 == 0, LP % 256 == 0; workspace of
+ * mvip_layernorm_workspace_bytes(N, C, LP) bytes (fp64 partial moments), 8-byte aligned. */
+int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t LP);
 int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
-                                int64_t L, int64_t LP, float eps, float out_scale, void *xs, void *stream);
+                                int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
+                                void *stream);
 /* GEGLU: y [N][2R][LP] -> out [N][R][LP] = y[:, :R] * gelu(y[:, R:]) (erf form) for tokens < L, zero beyond;
- * scale2 = {2^k, 2^-k, bits, -} from the result's absolute maximum. */
-int mvip_geglu(const float *y, int64_t N, int64_t R, int64_t L, int64_t LP, float *out, float *scale2, void *stream);
+ * scale2 = {2^k, 2^-k, -, -} from the result's absolute maximum; zero_word: one scratch word as in
+ * mvip_absmax_scale_sections (zero on entry, zero on exit). */
+int mvip_geglu(const float *y, int64_t N, int64_t R, int64_t L, int64_t LP, float *out, float *scale2, void *zero_word,
+               void *stream);
 /* y [NB][M] = act(x [NB][K]) W[M][K]^T + b  (act_in: 0 identity, 1 SiLU), NB <= 8: the timestep-embedding MLP and
  * the ResNet blocks' time projections (published SD-1.5 UNet), exact fp32, one wavefront per output feature. */
 int mvip_linear_small(const float *x, const float *W, const float *b, int64_t NB, int64_t M, int64_t K, int act_in,

@@ -85,14 +85,16 @@ _SIGNATURES = {
     'mvip_gemm_pack_a': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
     'mvip_attention_supported': (_int, [_i64]),
     'mvip_attention_v_bytes': (_i64, [_i64, _i64, _i64, _i64]),
     'mvip_attention_pack_v': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
-    'mvip_absmax_scale_sections': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_absmax_scale_sections': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_attention_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _flt, _int,
                                     _c_f, _c_f]),
-    'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f]),
-    'mvip_geglu': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
+    'mvip_layernorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f, _c_f]),
+    'mvip_geglu': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
     'mvip_linear_small': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _c_f, _c_f]),
     'mvip_groupnorm_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _int, _c_f, _c_f,
                                        _c_f]),

@@ -268,14 +268,16 @@ absmax_sections_kernel(const float *__restrict__ x, int64_t outer, int sections,
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(bits + 4 * s + 2, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    if (threadIdx.x == 0) atomicMax(bits + s, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
-// scale2[s] = {2^k, 2^-k, bits, -} with |x|max 2^k in [2^9, 2^10)  (same rule as csrc/conv3x3.hip)
-__global__ void scale_sections_kernel(float *__restrict__ scale2, int sections) {
+// scale2[s] = {2^k, 2^-k, -, -} with |x|max 2^k in [2^9, 2^10)  (same rule as csrc/conv3x3.hip); the maxima were
+// collected in bits[s], which is left ZERO for the next user (caller-owned scratch that travels zero between calls)
+__global__ void scale_sections_kernel(float *__restrict__ scale2, unsigned *__restrict__ bits, int sections) {
     const int s = threadIdx.x;
     if (s >= sections) return;
-    const float m = __uint_as_float(reinterpret_cast<const unsigned *>(scale2)[4 * s + 2]);
+    const float m = __uint_as_float(bits[s]);
+    bits[s] = 0u;
     float sc = 1.f;
     if (m > 0.f && m < 3.0e38f) {
         int e;
@@ -316,18 +318,17 @@ extern "C" int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, i
 }
 
 extern "C" int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, int64_t len, float *scale2,
-                                          void *stream) {
-    if (outer < 0 || sections <= 0 || sections > 64 || len < 0 || !scale2) return MVIP_EINVAL;
+                                          void *zero_words64, void *stream) {
+    if (outer < 0 || sections <= 0 || sections > 64 || len < 0 || !scale2 || !zero_words64) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    zero_words(scale2, (int)(4 * sections), st);
     if (outer > 0 && len > 0) {
         if (!x) return MVIP_EINVAL;
         int64_t b = (len + 256 * 32 - 1) / (256 * 32);
         b = b < 1 ? 1 : (b > 256 ? 256 : b);
         hipLaunchKernelGGL(absmax_sections_kernel, dim3((unsigned)b, (unsigned)sections), dim3(256), 0, st, x, outer,
-                           (int)sections, len, (unsigned *)scale2);
+                           (int)sections, len, (unsigned *)zero_words64);
     }
-    hipLaunchKernelGGL(scale_sections_kernel, dim3(1), dim3(64), 0, st, scale2, (int)sections);
+    hipLaunchKernelGGL(scale_sections_kernel, dim3(1), dim3(64), 0, st, scale2, (unsigned *)zero_words64, (int)sections);
     return check_launch();
 }
 

@@ -481,6 +481,119 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
         }
 }
 
+// ---- the same GEMM with a square-ish workgroup tile ---------------------------------------------------------
+// At split-precision MFMA rates the kernel above is bound by L2 -> LDS operand traffic, not by the matrix pipe: a
+// workgroup tile of Tm x Tp needs (Tm + Tp) / (Tm Tp) x 2731 B/clk/CU of operands to keep the pipe busy, i.e. 96
+// B/clk for 32 x 256 and 53 B/clk for 64 x 256 against ~55 B/clk/CU of L2 bandwidth.  Here a workgroup owns
+// (WGM*64) x (WGP*64) outputs (128 x 256: 32 B/clk), every wave a 64 x 64 block (2 x 2 MFMA tiles, 12 MFMAs per
+// eight fragment reads), operands of one 32-deep k-stage land by DMA NST-1 stages ahead of their use and the wave
+// waits with a COUNTED vmcnt for exactly the stage it is about to read.
+template <int WGM, int WGP, int NST>
+__global__ void __launch_bounds__(WGM * WGP * 64) gemm2_f16x3_kernel(const GemmArgs a) {
+    constexpr int NW = WGM * WGP;
+    constexpr int TP = WGP * 64;
+    constexpr int AB = WGM * 2 * GM_KC * 2 * 1024;          // A stage: [m-tile][kc][hl][lane][16 B]
+    constexpr int BB = GM_KC * 4 * TP * 16;                 // B stage: [kc][kg*2+hl][column][16 B]
+    constexpr int NAP = AB / 1024, NBP = BB / 1024;
+    constexpr int PPW = (NAP + NBP) / NW;                   // DMA pieces per wave per stage
+    static_assert((NAP + NBP) % NW == 0, "pieces must divide evenly over the waves (counted vmcnt)");
+    constexpr int AHEAD = NST - 1;
+    constexpr int WAITN = PPW * (AHEAD - 1);                // pieces that may still be in flight when a stage is read
+    static_assert(WAITN < 64, "vmcnt field");
+    __shared__ __attribute__((aligned(16))) char lds[NST * (AB + BB)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, kg = lane >> 5;
+    const int wm = wave % WGM, wp = wave / WGM;
+    int id = blockIdx.x;
+    const int total = gridDim.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int mb = id % a.MB;
+    const int tile = id / a.MB;
+    const int tp = tile % a.tiles;
+    const int n = tile / a.tiles;
+    const int64_t p0 = (int64_t)tp * TP;
+    const int64_t plane = a.P * 16;
+    const char *xs_n = a.xs + (int64_t)n * a.CK * 4 * plane + (p0 + lane) * 16;
+    const char *wp_b = a.wp + (int64_t)mb * (WGM * 2) * a.CK * 2048 + lane * 16;
+
+    auto issue = [&](int s, int buf) {
+        char *ad = lds + buf * (AB + BB), *bd = ad + AB;
+#pragma unroll
+        for (int q0 = 0; q0 < NAP + NBP; q0 += NW) {
+            const int q = q0 + wave;
+            if (q < NAP) {                                  // q = (mt * GM_KC + kc) * 2 + hl
+                const int hl = q & 1, kc = (q >> 1) % GM_KC, mt = (q >> 1) / GM_KC;
+                glds16b(wp_b + (((int64_t)mt * a.CK + s * GM_KC + kc) * 2 + hl) * 1024, ad + q * 1024);
+            } else {                                        // r = (kc * 4 + piece) * WGP + column block
+                const int r = q - NAP;
+                const int cb = r % WGP, pl = r / WGP;       // pl = kc * 4 + (kg * 2 + hl)
+                glds16b(xs_n + ((int64_t)(s * GM_KC * 4 + pl)) * plane + cb * 1024, bd + (pl * TP + cb * 64) * 16);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    const int nstage = a.CK / GM_KC;
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s)
+        if (s < nstage) issue(s, s);
+    for (int s = 0; s < nstage; ++s) {
+        // stage s has landed once at most the pieces of the AHEAD-1 younger stages are outstanding
+        if (s + AHEAD - 1 < nstage) __builtin_amdgcn_s_waitcnt(0x0f70 | (WAITN & 15) | ((WAITN >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();                                   // everyone's pieces; everyone is done with stage s-1
+        if (s + AHEAD < nstage) issue(s + AHEAD, (s + AHEAD) % NST);
+        const char *ab = lds + (s % NST) * (AB + BB) + lane * 16, *bb = lds + (s % NST) * (AB + BB) + AB;
+#pragma unroll
+        for (int kc = 0; kc < GM_KC; ++kc) {
+            h16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (wp * 2 + j) * 32 + l32;
+                bh[j] = *reinterpret_cast<const h16x8 *>(bb + ((kc * 4 + kg * 2 + 0) * TP + col) * 16);
+                bl[j] = *reinterpret_cast<const h16x8 *>(bb + ((kc * 4 + kg * 2 + 1) * TP + col) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const h16x8 *>(ab + (((wm * 2 + m) * GM_KC + kc) * 2 + 0) * 1024);
+                al[m] = *reinterpret_cast<const h16x8 *>(ab + (((wm * 2 + m) * GM_KC + kc) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[j], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[j], acc[m][j], 0, 0, 0);
+                }
+        }
+    }
+    const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t px = p0 + (wp * 2 + j) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ((mb * WGM + wm) * 2 + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                float v = acc[m][j][r] * inv;
+                if (a.bias) v += a.bias[row];
+                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
+                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
+                if (a.residual) v += a.residual[o];
+                a.y[o] = v;
+            }
+        }
+}
+
 // largest MT in {4, 2, 1} dividing Cout/32 whose grid still has >= 256 workgroups (else the smallest)
 static inline int cv_mt(int64_t Cout, int64_t tiles) {
     if (Cout % 32 != 0) return 0;
@@ -617,9 +730,10 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     return check_launch();
 }
 
-extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
-                               const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                               float *y, void *stream) {
+// cfg: 0 = choose by shape, 1 = 32/64-row kernel, 2 = 128 x 256 tile, 3 = 128 x 128, 4 = 64 x 128 (timing switch)
+extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                   const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                                   float *y, int cfg, void *stream) {
     if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
@@ -627,16 +741,44 @@ extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *
     a.xs = (const char *)xs; a.wp = (const char *)packed;
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
-    a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P; a.tiles = (int)(P / GM_PIX);
-    const int MT = cv_mt(M, N * a.tiles);
-    a.MB = (int)(M / (32 * MT));
-    const int64_t blocks = N * a.tiles * a.MB;
-    if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    if (MT == 4)
-        hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
-    else if (MT == 2)
-        hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
+    hipStream_t st = as_stream(stream);
+    if (cfg == 0) {
+        // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
+        // (10..40 stages) every tile shape lands within ~10 % of the 32/64-row kernel -- these launches are bound by
+        // the per-workgroup prologue / epilogue and by grid quantisation, not by operand traffic -- and the square
+        // tile only wins once M is large enough for several full waves of workgroups (the 1280-wide GEGLU projection).
+        cfg = (M % 128 == 0 && M >= 8192 && (M / 128) * N * (P / 256) >= 128) ? 2 : 1;
+    }
+    if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
+    if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
+    if (cfg == 2) {
+        a.tiles = (int)(P / 256); a.MB = (int)(M / 128);
+        hipLaunchKernelGGL((gemm2_f16x3_kernel<2, 4, 3>), dim3((unsigned)(N * a.tiles * a.MB)), dim3(512), 0, st, a);
+    } else if (cfg == 3) {
+        a.tiles = (int)(P / 128); a.MB = (int)(M / 128);
+        hipLaunchKernelGGL((gemm2_f16x3_kernel<2, 2, 2>), dim3((unsigned)(N * a.tiles * a.MB)), dim3(256), 0, st, a);
+    } else if (cfg == 4) {
+        a.tiles = (int)(P / 128); a.MB = (int)(M / 64);
+        hipLaunchKernelGGL((gemm2_f16x3_kernel<1, 2, 3>), dim3((unsigned)(N * a.tiles * a.MB)), dim3(128), 0, st, a);
+    } else {
+        a.tiles = (int)(P / GM_PIX);
+        const int MT = cv_mt(M, N * a.tiles);
+        a.MB = (int)(M / (32 * MT));
+        const int64_t blocks = N * a.tiles * a.MB;
+        if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+        if (MT == 4)
+            hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (MT == 2)
+            hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     return check_launch();
+}
+
+extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                               const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                               float *y, void *stream) {
+    return mvip_gemm_f16x3_cfg(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, stream);
 }

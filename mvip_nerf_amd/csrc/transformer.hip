@@ -5,7 +5,8 @@
 // layer is then Y = W X on the split-precision GEMM of csrc/conv3x3.hip with no layout transposes, and these
 // kernels produce its operands:
 //   layernorm_split : per-token LayerNorm over the channel (strided) axis, written straight as fp16 hi/lo
-//                     split planes [N][C/16][2][2][LP][8] (the GEMM's B operand);
+//                     split planes [N][C/16][2][2][LP][8] (the GEMM's B operand); two launches, both parallel over
+//                     (token, channel segment): fp64 partial moments, then normalise + split;
 //   geglu           : a * gelu(g) of the feed-forward's first projection + the absolute maximum that sizes the
 //                     power-of-two scale of its split;
 //   linear_small    : y = W act(x) + b for a handful of rows (the timestep embedding MLP and the per-ResNet-block
@@ -30,56 +31,75 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// grid (LP / 64, N), 256 threads: lane = token, wave = channel group (chunks wave, wave + 4, ... of 16 channels).
-// Two-pass statistics in fp32 (mean, then centred second moment), the three passes re-read x from L2.
+// LayerNorm statistics, pass 1: grid (LP / 64, C / 64, N), 256 threads: lane = token, wave = one 16-channel chunk of
+// the workgroup's 64-channel segment.  Per (sample, segment, token): sum and sum of squares in fp64 (exact enough
+// that var = E[x^2] - mean^2 carries no cancellation error at fp32 output precision).
 __global__ void __launch_bounds__(256)
-layernorm_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                       int C, int L, int LP, float eps, float out_scale, uint4 *__restrict__ xs) {
-    __shared__ float red[4][64];
+ln_stats_kernel(const float *__restrict__ x, int C, int L, int LP, double *__restrict__ part) {
+    __shared__ double red[2][4][64];
     const int tok = threadIdx.x & 63;
-    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.y;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = blockIdx.y, n = blockIdx.z, S = C / 64;
     const int p = blockIdx.x * 64 + tok;
-    const int CK = C / 16;
-    const bool live = p < L;
-    const float *xp = x + (int64_t)n * C * LP + p;
-    float s = 0.f;
-    if (live)
-        for (int ck = cg; ck < CK; ck += 4)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) s += xp[(int64_t)(ck * 16 + c) * LP];
-    red[cg][tok] = s;
-    __syncthreads();
-    const float mean = (red[0][tok] + red[1][tok] + red[2][tok] + red[3][tok]) / (float)C;
-    __syncthreads();
-    float q = 0.f;
-    if (live)
-        for (int ck = cg; ck < CK; ck += 4)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { const float d = xp[(int64_t)(ck * 16 + c) * LP] - mean; q += d * d; }
-    red[cg][tok] = q;
-    __syncthreads();
-    const float var = (red[0][tok] + red[1][tok] + red[2][tok] + red[3][tok]) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    for (int ck = cg; ck < CK; ck += 4) {
+    double s = 0.0, q = 0.0;
+    if (p < L) {
+        const float *xp = x + ((int64_t)n * C + seg * 64 + w * 16) * LP + p;
         float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = xp[(int64_t)c * LP];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s += (double)v[c]; q += (double)v[c] * (double)v[c]; }
+    }
+    red[0][w][tok] = s;
+    red[1][w][tok] = q;
+    __syncthreads();
+    if (w < 2) {                         // wave 0 writes the sums, wave 1 the squares
+        const double t = red[w][0][tok] + red[w][1][tok] + red[w][2][tok] + red[w][3][tok];
+        part[(((int64_t)n * S + seg) * 2 + w) * LP + p] = t;
+    }
+}
+
+// pass 2: grid (LP / 256, N * C / 16): thread = (token, 16-channel chunk) -> normalise, scale, split, write planes.
+__global__ void __launch_bounds__(256)
+ln_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                const double *__restrict__ part, int C, int L, int LP, float eps, float out_scale,
+                uint4 *__restrict__ xs) {
+    const int CK = C / 16, S = C / 64;
+    const int ck = blockIdx.y % CK, n = blockIdx.y / CK;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= LP) return;
+    float v[16];
+    if (p < L) {
+        double s = 0.0, q = 0.0;
+        for (int g = 0; g < S; ++g) {
+            s += part[(((int64_t)n * S + g) * 2 + 0) * LP + p];
+            q += part[(((int64_t)n * S + g) * 2 + 1) * LP + p];
+        }
+        const double mean = s / C;
+        double var = q / C - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float *xp = x + ((int64_t)n * C + ck * 16) * LP + p;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int ch = ck * 16 + c;
             const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
-            v[c] = live ? ((xp[(int64_t)ch * LP] - mean) * rstd * g + b) * out_scale : 0.f;
+            v[c] = ((xp[(int64_t)c * LP] - mf) * rstd * g + b) * out_scale;
         }
-        uint4 *dst = xs + ((int64_t)(n * CK + ck) * 4) * LP + p;
+    } else {
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            float t[8];
+        for (int c = 0; c < 16; ++c) v[c] = 0.f;
+    }
+    uint4 *dst = xs + ((int64_t)(n * CK + ck) * 4) * LP + p;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = v[kg * 8 + j];
-            uint4 hi, lo;
-            split8(t, hi, lo);
-            dst[(int64_t)(kg * 2 + 0) * LP] = hi;
-            dst[(int64_t)(kg * 2 + 1) * LP] = lo;
-        }
+    for (int kg = 0; kg < 2; ++kg) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[kg * 8 + j];
+        uint4 hi, lo;
+        split8(t, hi, lo);
+        dst[(int64_t)(kg * 2 + 0) * LP] = hi;
+        dst[(int64_t)(kg * 2 + 1) * LP] = lo;
     }
 }
 
@@ -114,8 +134,11 @@ geglu_kernel(const float *__restrict__ y, int64_t R, int L, int LP, float *__res
     if (threadIdx.x == 0) atomicMax(bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
-__global__ void scale_from_bits_kernel(float *__restrict__ scale2) {
-    const float m = __uint_as_float(reinterpret_cast<const unsigned *>(scale2)[2]);
+// scale2 = {2^k, 2^-k} from the maximum collected in *bits; *bits is left ZERO for its next user (the scratch word is
+// owned by the caller and travels zero between calls, which saves a zeroing launch per use)
+__global__ void scale_from_bits_kernel(float *__restrict__ scale2, unsigned *__restrict__ bits) {
+    const float m = __uint_as_float(*bits);
+    *bits = 0u;
     float sc = 1.f;
     if (m > 0.f && m < 3.0e38f) {
         int e;
@@ -164,30 +187,37 @@ linear_small_kernel(const float *__restrict__ x, const float *__restrict__ W, co
 using namespace mvip;
 using namespace mvip::tok;
 
+extern "C" int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t LP) {
+    return (N <= 0 || C <= 0 || LP <= 0) ? 0 : N * (C / 64) * 2 * LP * (int64_t)sizeof(double);
+}
+
 extern "C" int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
-                                           int64_t L, int64_t LP, float eps, float out_scale, void *xs, void *stream) {
-    if (N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 64 != 0 || N > 65535) return MVIP_EINVAL;
+                                           int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
+                                           void *stream) {
+    if (N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
-    if (!x || !xs) return MVIP_EINVAL;
-    hipLaunchKernelGGL(layernorm_split_kernel, dim3((unsigned)(LP / 64), (unsigned)N), dim3(256), 0, as_stream(stream), x,
-                       gamma, beta, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs);
+    if (!x || !xs || !workspace) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(LP / 64), (unsigned)(C / 64), (unsigned)N), dim3(256), 0, st, x,
+                       (int)C, (int)L, (int)LP, (double *)workspace);
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)(LP / 256), (unsigned)(N * (C / 16))), dim3(256), 0, st, x, gamma,
+                       beta, (const double *)workspace, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs);
     return check_launch();
 }
 
 extern "C" int mvip_geglu(const float *y, int64_t N, int64_t R, int64_t L, int64_t LP, float *out, float *scale2,
-                          void *stream) {
-    if (N < 0 || R <= 0 || L <= 0 || LP < L || LP % 4 != 0 || !scale2) return MVIP_EINVAL;
+                          void *zero_word, void *stream) {
+    if (N < 0 || R <= 0 || L <= 0 || LP < L || LP % 4 != 0 || !scale2 || !zero_word) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    zero_words(scale2, 4, st);
     if (N > 0) {
         if (!y || !out) return MVIP_EINVAL;
         const int64_t total4 = N * R * (LP / 4);
         int64_t blocks = (total4 + 255) / 256;
         blocks = blocks > 4096 ? 4096 : blocks;
         hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, R, (int)L, (int)LP, out,
-                           (unsigned *)(scale2 + 2), total4);
+                           (unsigned *)zero_word, total4);
     }
-    hipLaunchKernelGGL(scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2);
+    hipLaunchKernelGGL(scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2, (unsigned *)zero_word);
     return check_launch();
 }
 

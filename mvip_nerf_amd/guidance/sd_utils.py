@@ -135,6 +135,12 @@ class _GraphedStep:
                 self._body()
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        self.generator = sd.generator
+        if sd.generator is not None:
+            # a private generator is invisible to the capture unless registered: its draws would be baked in
+            if not hasattr(self.graph, 'register_generator_state'):
+                raise RuntimeError('use_graphs with a private generator needs CUDAGraph.register_generator_state')
+            self.graph.register_generator_state(sd.generator)
         with torch.cuda.graph(self.graph):
             self.d_pred = self._body()
 
@@ -199,7 +205,17 @@ class StableDiffusion(nn.Module):
         self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
 
     # -- hooks (tests replay recorded draws through _randn) --------------------------------------
-    generator = None      # optional torch.Generator: multi-GPU runs seed it identically on every rank
+    generator = None      # optional torch.Generator (default: the device's global generator, like the reference)
+
+    def seed_generator(self, seed):
+        """Draw this object's noise from ONE persistent private generator, re-seeded in place.  Multi-GPU runs seed it
+        per (iteration, term) so a term's noise does not depend on which rank evaluates it; a captured hipGraph
+        registers this generator (`_GraphedStep`), so re-seeding between replays is honoured."""
+        if self.__dict__.get('_private_gen') is None:
+            self._private_gen = torch.Generator(device=self.device)
+        self._private_gen.manual_seed(int(seed))
+        self.generator = self._private_gen
+        return self._private_gen
 
     def _randn(self, shape, dtype=torch.float32):
         return torch.randn(tuple(shape), device=self.device, dtype=dtype, generator=self.generator)
@@ -249,7 +265,7 @@ class StableDiffusion(nn.Module):
         return latents, grad
 
     def _graphed(self, t, mask, prompt, pred, guidance_scale):
-        key = (tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale))
+        key = (tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale), id(self.generator))
         if key not in self._graphs:
             self._graphs[key] = _GraphedStep(self, pred.shape, mask.shape, prompt, guidance_scale)
         d_pred = self._graphs[key].run(pred, mask, t)
@@ -295,3 +311,49 @@ class StableDiffusion(nn.Module):
 
     # `train_step` exists by name only in the reference's unused guidance/sd.py (:162, :988)
     train_step = train_step_sd
+
+    # -- per-term entry points of the view-sharded multi-GPU path (mvip_nerf_amd/sds_shard.py) ---------------------
+    # The reference runs every term on one device (DS_NeRF/nerf/utils.py:280-302); these expose the same arithmetic
+    # term by term so that different ranks can own different terms.  `seed` re-seeds the private generator, making a
+    # term's noise a function of (iteration, term) instead of the evaluation order.
+    def image_grad(self, kind, i, mask, prompt, pred, guidance_scale, weight=1.0, normal_start=0, seed=None):
+        """weight * d train_step_sd{,_normal}(...) / d pred for kind in {'rgb', 'normal'}; pred is not touched."""
+        if seed is not None:
+            self.seed_generator(seed)
+        x = pred.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            if kind == 'rgb':
+                loss = self.train_step_sd(i, mask, prompt, x, guidance_scale=guidance_scale)
+            elif kind == 'normal':
+                loss = self.train_step_sd_normal(i, mask, prompt, x, guidance_scale=guidance_scale,
+                                                 normal_start=normal_start)
+            else:
+                raise ValueError(kind)
+            (weight * loss).sum().backward()
+        return x.grad
+
+    def colla_view_share(self, k, mask_k, prompt, pred_k, guidance_scale, seed=None):
+        """Neighbour view k's share nan_to_num(w_k (eps_hat - eps)) of train_step_colla_sds' accumulated latent
+        gradient (DS_NeRF/guidance/sd_utils.py:575), forward only; t comes from the VIEW index as in the reference."""
+        if seed is not None:
+            self.seed_generator(seed)
+        with torch.no_grad():
+            prep = self._prepare(pred_k.detach(), mask_k, prompt, guidance_scale)
+            _, grad = self._noise_and_predict(*prep, self._timestep(k / 10000), guidance_scale)
+        return grad
+
+    def colla_last_view_image_grad(self, k, mask_k, prompt, pred_k, guidance_scale, share_sum, weight=1.0, seed=None):
+        """The LAST neighbour view of train_step_colla_sds: its own share is added to `share_sum` (the other views'
+        shares), and the accumulated gradient is injected through SpecifyGradient with the CFG-duplicated mask, as
+        the reference does (sd_utils.py:597-599); returns weight * d term / d pred_k."""
+        if seed is not None:
+            self.seed_generator(seed)
+        x = pred_k.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            prep = self._prepare(x, mask_k, prompt, guidance_scale)
+            acc = share_sum.detach().clone().float().reshape(1, 4, 64, 64).contiguous()
+            latents, grad = self._noise_and_predict(*prep, self._timestep(k / 10000), guidance_scale,
+                                                    accumulate_into=acc)
+            loss = SpecifyGradient.apply(latents, grad.clone(), prep[1])
+            (weight * loss).sum().backward()
+        return x.grad

@@ -754,11 +754,14 @@ def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
     return xs
 
 
+GEMM_CFG = 0       # 0: tile chosen by shape; 1..4 force a workgroup tile (A/B timing switch, see include/mvip_nerf.h)
+
+
 def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None):
     """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P]."""
     y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
-    call('mvip_gemm_f16x3', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
-         ptr(x_scale2), N, K, M, P, ptr(y), stream())
+    call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
+         ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), stream())
     return y
 
 
@@ -960,10 +963,23 @@ def tokens_conv1x1(h, conv, residual):
 
 # Transformer blocks of the SDS UNet: attention and token-side kernels (csrc/attention.hip, csrc/transformer.hip) -----
 
+_ZERO_WORDS = {}
+
+
+def _zero_words(device):
+    """64 scratch words per (device, stream) that are zero between kernel launches: the absmax collectors use them
+    with atomics and the kernel that reads the maximum re-zeroes them (saves a zeroing launch per use)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _ZERO_WORDS:
+        _ZERO_WORDS[key] = torch.zeros(64, device=device, dtype=torch.int32)
+    return _ZERO_WORDS[key]
+
+
 def absmax_scale_sections(x, outer, sections, length):
-    """x viewed as [outer][sections][length] -> flat [sections * 4] device floats: {2^k, 2^-k, bits, -} per section."""
+    """x viewed as [outer][sections][length] -> flat [sections * 4] device floats: {2^k, 2^-k, -, -} per section."""
     sc = torch.empty(sections * 4, device=x.device, dtype=_F32)
-    call('mvip_absmax_scale_sections', ptr(x), int(outer), int(sections), int(length), ptr(sc), stream())
+    call('mvip_absmax_scale_sections', ptr(x), int(outer), int(sections), int(length), ptr(sc),
+         ptr(_zero_words(x.device), torch.int32), stream())
     return sc
 
 
@@ -971,8 +987,9 @@ def layernorm_split(x, weight, bias, eps, N, C, L, LP, out_scale):
     """LayerNorm over the channel axis of channel-major x [N, C, LP] (tokens < L), times the power of two
     `out_scale`, as fp16 hi/lo split planes (the B operand of gemm_f16x3 with P = LP)."""
     xs = _split_buffer(N, C, LP, x.device)
+    ws = torch.empty(int(_lib.load().mvip_layernorm_workspace_bytes(N, C, LP)) // 8, device=x.device, dtype=torch.float64)
     call('mvip_layernorm_split_planes', ptr(x), ptr(weight), ptr(bias), int(N), int(C), int(L), int(LP), float(eps),
-         float(out_scale), ptr(xs, torch.float16), stream())
+         float(out_scale), ptr(ws, torch.float64), ptr(xs, torch.float16), stream())
     return xs
 
 
@@ -1004,7 +1021,8 @@ def geglu(y, N, R, L, LP):
     """y [N, 2R, LP] -> (y[:, :R] * gelu(y[:, R:]) [N, R, LP] zero beyond L, its power-of-two scale2)."""
     out = torch.empty((N, R, LP), device=y.device, dtype=_F32)
     scale2 = torch.empty(4, device=y.device, dtype=_F32)
-    call('mvip_geglu', ptr(y), int(N), int(R), int(L), int(LP), ptr(out), ptr(scale2), stream())
+    call('mvip_geglu', ptr(y), int(N), int(R), int(L), int(LP), ptr(out), ptr(scale2),
+         ptr(_zero_words(y.device), torch.int32), stream())
     return out, scale2
 
 

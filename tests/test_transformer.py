@@ -210,3 +210,27 @@ def test_unet_forward_has_no_library_attention_or_gemm(cuda):
     names = [e.key for e in prof.key_averages()]
     assert any('attn_f16x3_kernel' in n for n in names)
     assert not [n for n in names if 'attn_fwd' in n or 'Cijk_Alik' in n], names        # no library attention, no hipBLASLt linear
+
+
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4])
+def test_gemm_tile_configs_vs_fp64(cuda, cfg):
+    """Every workgroup-tile variant of the split-precision GEMM (csrc/conv3x3.hip) against W X in fp64, with bias,
+    per-sample channel addend and residual, K from one to many 32-deep stages (pipeline prologue / tail)."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(20 + cfg)
+    old = ops.GEMM_CFG
+    ops.GEMM_CFG = cfg
+    try:
+        for Nb, M, K, P in ((2, 128, 32, 256), (1, 256, 64, 512), (2, 384, 320, 256), (1, 128, 96, 1024), (1, 1152, 320, 512)):
+            W = torch.randn(M, K, generator=gen) / K ** 0.5
+            x = torch.randn(Nb, K, P, generator=gen) * 1.5
+            b, ca, rs = torch.randn(M, generator=gen), torch.randn(Nb, M, generator=gen), torch.randn(Nb, M, P, generator=gen)
+            ref = torch.einsum('mk,nkp->nmp', W.double(), x.double()) + b.double()[None, :, None] + ca.double()[:, :, None] + rs.double()
+            xd = x.to(cuda)
+            xs, s2 = ops._scaled_planes(xd, Nb, K, P, K * P, P, 1)
+            y = ops.gemm_f16x3(xs, ops.gemm_pack_a(W.to(cuda), M, K, K, 1), Nb, K, M, P, bias=b.to(cuda),
+                               chan_add=ca.to(cuda), residual=rs.to(cuda), x_scale2=s2)
+            np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()),
+                                       err_msg=f'cfg {cfg} shape {(Nb, M, K, P)}')
+    finally:
+        ops.GEMM_CFG = old
