@@ -47,7 +47,11 @@ def all_gather_ragged(local, n_total, rank, world, dist):
 
 class FlatGradBucket:
     """One contiguous fp32 bucket for all parameters: grads are copied in, all-reduced once, and
-    handed back as views (so the optimizer reads the reduced values without another copy)."""
+    handed back as views (so the optimizer reads the reduced values without another copy).
+    A parameter whose gradient is None on this rank contributes zeros and receives the reduced value (it may be
+    non-None on another rank); a parameter that is None on EVERY rank therefore gets a zero gradient here where
+    single-process training would skip it in Adam.  The trainer always back-propagates through both MLPs, so this
+    does not occur on the hot path."""
 
     def __init__(self, params):
         self.params = list(params)

@@ -2,9 +2,16 @@
 sums the RGB / collaborative / normal SDS terms (DS_NeRF/nerf/utils.py:174-311).
 
 The reference also draws `rand_poses` each call and uses only `phis` to compute a value that is
-never read (utils.py:239-254); that dead code -- and the Perp-Neg / text-direction helpers nothing
-calls (utils.py:8-98) -- is not restated.  `global_step` is still counted.
+never read (utils.py:239-254).  The pose algebra is dead code and is not restated, but its RANDOM DRAWS are
+consumed in the same order and shapes when `reference_rng` is on (the default: `guidance['SD'].reference_rng`),
+so that a seeded run sees the same device random stream as the reference: torch.rand(B) for the radius, one
+python `random.random()` for the branch, then either three torch.randn(B) (uniform-sphere branch) or two
+torch.rand(B) (utils.py:119-135).  The Perp-Neg / text-direction helpers nothing calls (utils.py:8-98) are not
+restated.  `global_step` is counted as in the reference.
 """
+import random
+
+import torch
 
 
 class Pretrain_Model(object):
@@ -20,12 +27,29 @@ class Pretrain_Model(object):
                     p.requires_grad = False
                 self.embeddings[key] = {}
 
+    def _reference_rng(self):
+        sd = self.guidance.get('SD') if isinstance(self.guidance, dict) or hasattr(self.guidance, 'get') else None
+        return bool(getattr(sd, 'reference_rng', True))
+
+    def _consume_rand_poses_draws(self, B):
+        """The draws of rand_poses(B, ...) (DS_NeRF/nerf/utils.py:119-135), values discarded."""
+        dev = self.device
+        torch.rand(B, device=dev)
+        if random.random() < float(getattr(self.opt, 'uniform_sphere_rate', 0)):
+            for _ in range(3):
+                torch.randn(B, device=dev)
+        else:
+            torch.rand(B, device=dev)
+            torch.rand(B, device=dev)
+
     def cal_loss(self, i, rgbs4_tensor, pre_normal_map, pred_depth, pred_rgb, rgb, masks, mask4, B=1):
         """Signature and term order of DS_NeRF/nerf/utils.py:222-311."""
         opt = self.opt
         self.rgb, self.pred_rgb, self.pred_depth = rgb, pred_rgb, pred_depth
         self.pre_normal_map, self.rgbs4_tensor = pre_normal_map, rgbs4_tensor
         self.B, self.masks = B, masks
+        if self._reference_rng():
+            self._consume_rand_poses_draws(B)
         self.global_step += 1
         loss = 0
         if 'SD' in self.guidance:

@@ -64,6 +64,10 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     """DS_NeRF/run.py:1143-1219.  Returns [rgb_map, disp_map, acc_map, depth_map, extras]."""
     scalar_bounds = not torch.is_tensor(near) and not torch.is_tensor(far)
     fast = use_viewdirs and not ndc and depths is None and c2w_staticcam is None and scalar_bounds
+    if rays is not None and c2w is None and torch.is_tensor(rays[1]) and rays[1].dtype != torch.float32:
+        # the reference's pre-baked fp16 ray batches (run.py:639, :978): view directions are normalised in the
+        # rays' own precision before the cast to float (run.py:1186-1187) -- the general assembly does exactly that
+        fast = False
     if c2w is not None:
         c2w = torch.as_tensor(c2w)
         if fast and patch is None:

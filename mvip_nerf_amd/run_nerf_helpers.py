@@ -85,6 +85,19 @@ class NeRF(nn.Module):
                 'the fused HIP kernel is built for the north-star model: D=8, W=256, skips=[4], '
                 'multires=10, multires_views=4, use_viewdirs=True')
 
+    def invalidate_packed(self):
+        """Drop the packed weight images.  They are keyed on (data_ptr, tensor version), which in-place writes through
+        `.data` do NOT bump (p.data.copy_(), an all-reduce or broadcast on p.data): call this after any such write.
+        load_state_dict() and the trainer's initial weight broadcast do."""
+        self._packed = self._packed_key = None
+        self._packed16 = self._packed16_key = None
+        self._packed_w16 = self._packed_w16_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
     def param_list(self):
         """The 24 tensors in state-dict order (what mvip_mlp_pack expects)."""
         sd = dict(self.named_parameters())

@@ -11,22 +11,29 @@ Per iteration, as in the reference:
   4. loss = mse(rgb2) + depth_lambda*mse(disp2) + mse(rgb0) + sds_loss_weight*SDS  (run.py:1000-1027);
   5. backward, Adam step, lr = lrate * 0.1^(step / (lrate_decay*1000))  (run.py:1030-1039).
 
-Differences that are deliberate and documented in DESIGN.md: rays are generated on the GPU from
-(pose, pixel index) in fp32 instead of being pre-baked on the host in fp16 (run.py:639, :658); the
-full-frame get_rays + 94 % discard (run.py:869-883) is replaced by generating only the masked
-rays; the Tk GUI thread, PNG dumps and host syncs are gone.
+Two kinds of scene feed it:
+  * `scene.LLFFScene` (real data, or arrays shaped like `load_llff_data`'s return values): per-view masks, and the
+    supervision batches are the reference's pre-baked fp16 ray records drawn ACROSS views (run.py:613-717, :887-908)
+    -- with it two iterations reproduce the reference's own loop (tests/golden/trainer_two_steps.npz);
+  * `SyntheticScene` (SURVEY.md 8(d) bench inputs): one shared mask, supervision pixels of the chosen view with
+    rays generated on the GPU in fp32.
+Deliberate differences: the masked rays come from (pose, pixel index) on the GPU instead of a full-frame
+get_rays + 94 % discard (run.py:869-883); the neighbour views that receive no gradient in the reference's
+collaborative term are rendered without autograd; the Tk GUI thread, PNG dumps and host syncs are gone.
 
 Multi-GPU (world > 1, torch.distributed over RCCL): every per-step ray set is sharded by index
-across ranks (rank r takes rays r::world), the SDS image is assembled with one all_gather of the
-rendered masked colours, and the two MLPs' gradients are summed with ONE all_reduce of a flat
-1,191,688-float bucket (4.77 MB), after which every rank applies the identical Adam update.
+across ranks (rank r takes rays r::world), frames are assembled with all_gather (the local shard keeps its autograd
+history), the <= 7 SDS terms are evaluated by different ranks (`sds_shard`: one async 64 KB all_reduce + <= 3 frame
+broadcasts), and the two MLPs' gradients are summed with ONE all_reduce of a flat 1,191,688-float bucket (4.77 MB),
+after which every rank applies the identical Adam update.  Shard losses are weighted n_local / n_global so the
+reduced gradient is the single-process one for any shard sizes.
 """
 import math
 
 import numpy as np
 import torch
 
-from . import ops, run
+from . import ops, run, sds_shard
 from .dist_utils import shard, all_gather_ragged, FlatGradBucket
 from .run_nerf_helpers import img2mse
 
@@ -34,6 +41,7 @@ from .run_nerf_helpers import img2mse
 class SyntheticScene:
     """SURVEY.md §8(d) synthetic stand-in for SPIn-NeRF scene 1: 60 orbit poses, random target
     images, a centred rectangular inpainting mask (~6 % of the frame), constant near/far."""
+    sets = None                                     # no pre-baked ray records: supervision pixels of the chosen view
 
     def __init__(self, H=378, W=504, focal=383.65, near=1.2, far=7.74, n_views=60, mask_hw=(104, 111),
                  device='cuda', seed=0):
@@ -53,6 +61,12 @@ class SyntheticScene:
         self.unmasked_idx = torch.nonzero(~flat, as_tuple=False).reshape(-1).to(device)
         self.i_train = np.arange(n_views)
 
+    def masked_idx_of(self, view):
+        return self.masked_idx
+
+    def mask_of(self, view):
+        return self.mask
+
     @staticmethod
     def _pose(k):
         th = math.radians(6.0 * k)
@@ -61,7 +75,7 @@ class SyntheticScene:
 
 
 class SecondStageTrainer:
-    def __init__(self, args, scene, device, guidance=None, world=1, rank=0, dist=None):
+    def __init__(self, args, scene, device, guidance=None, world=1, rank=0, dist=None, view_shard=None):
         self.args, self.scene, self.device = args, scene, device
         self.world, self.rank, self.dist = world, rank, dist
         make = run.create_nerf if getattr(args, 'no_tcnn', True) else run.create_nerf_tcnn      # run.py:541-546
@@ -71,21 +85,36 @@ class SecondStageTrainer:
         self.rng = np.random.RandomState(1234)         # same draw on every rank (view choice must agree)
         self.N_rand = args.N_rand
         self.bucket = FlatGradBucket(self.grad_vars)
+        # SDS terms owned by different ranks (sds_shard); None = whenever there is more than one rank
+        self.view_shard = (world > 1) if view_shard is None else bool(view_shard)
         if world > 1:                                  # identical initial weights on every rank
-            for p in self.grad_vars:
-                dist.broadcast(p.data, src=0)
+            with torch.no_grad():
+                for p in self.grad_vars:
+                    dist.broadcast(p.detach(), src=0)  # shares p's version counter: the packed images are rebuilt
+            for key in ('network_fn', 'network_fine'):
+                net = self.kw_train.get(key)
+                if net is not None and hasattr(net, 'invalidate_packed'):
+                    net.invalidate_packed()
 
     # -- helpers ---------------------------------------------------------------------------------
     def _shard(self, idx):
         return shard(idx, self.rank, self.world)
 
+    def _kw(self, kw):
+        return {k: v for k, v in kw.items() if k not in ('ndc', 'use_viewdirs', 'near', 'far')}
+
     def _render_pixels(self, pose, sel, hwf=None, **kw):
         sc = self.scene
         H, W, focal = hwf if hwf is not None else (sc.H, sc.W, sc.focal)
         rows = ops.ray_rows_from_pose(pose, H, W, focal, sc.near, sc.far, sel=sel)
-        ret = run.batchify_rays(rows, self.args.chunk, **{k: v for k, v in kw.items()
-                                                           if k not in ('ndc', 'use_viewdirs')})
-        return ret
+        return run.batchify_rays(rows, self.args.chunk, **self._kw(kw))
+
+    def _render_records(self, rays, **kw):
+        """render(H, W, focal, rays=[2, B, 3] fp16 records) of run.py:978-984: the reference's own row assembly
+        (view directions normalised in the records' precision), this rank's strided share of the batch."""
+        sc = self.scene
+        rows = run._assemble_rows_general(sc.H, sc.W, sc.focal, rays[0], rays[1], False, sc.near, sc.far, True, None, None)
+        return run.batchify_rays(rows, self.args.chunk, **self._kw(kw))
 
     def _render_frame(self, pose, hwf, key, **kw):
         """One full frame at (H, W, focal) = hwf, rays sharded over the ranks; returns the assembled
@@ -131,13 +160,48 @@ class SecondStageTrainer:
     def _allreduce_grads(self):
         self.bucket.all_reduce(self.dist, self.world)      # ONE 4.77 MB bucket over RCCL/xGMI
 
+    # -- the SDS terms, owned by different ranks ----------------------------------------------------------------
+    def _sds_view_sharded(self, i, combin_rgb, mask, normal_map, rgbs4, mask4):
+        """The terms `Pretrain_Model.cal_loss` would sum (DS_NeRF/nerf/utils.py:280-302: RGB; collaborative if i > 0;
+        normal if i > normal_start), each evaluated by ONE rank (sds_shard.evaluate); returns
+        sds_loss_weight * (sum of terms) as a surrogate whose gradient w.r.t. the frames is the terms' gradient."""
+        pm = self.guidance
+        opt, sd = pm.opt, pm.guidance['SD']
+        w = float(self.args.sds_loss_weight)
+        pm.global_step += 1
+        base = 7919 * (i + 1)                           # a term's noise depends on (iteration, term), not on its owner
+        terms = []
+        if opt.is_rgb_guidance:
+            terms.append(sds_shard.Term('rgb', 2, lambda _, b=base: sd.image_grad(
+                'rgb', i, mask, opt.text, combin_rgb, opt.rgb_guidance_scale, w, seed=b), image=combin_rgb))
+        if opt.is_normal_guidance and i > opt.normal_start:
+            terms.append(sds_shard.Term('normal', 2, lambda _, b=base + 1: sd.image_grad(
+                'normal', i, mask, opt.text_normal, normal_map, opt.normal_guidance_scale, w,
+                normal_start=opt.normal_start, seed=b), image=normal_map))
+        if opt.is_colla_guidance and i > 0:
+            V = rgbs4.shape[0]
+            last = V - 1
+            terms.append(sds_shard.Term('colla_last', 2, lambda share, b=base + 2 + last: sd.colla_last_view_image_grad(
+                last, mask4[last:last + 1], opt.text, rgbs4[last:last + 1], opt.colla_guidance_scale, share, w, seed=b),
+                image=rgbs4[last:last + 1], needs_latent_sum=True))
+            for k in range(last):
+                terms.append(sds_shard.Term(f'colla_{k}', 1, lambda k=k, b=base + 2 + k: sd.colla_view_share(
+                    k, mask4[k:k + 1], opt.text, rgbs4[k:k + 1], opt.colla_guidance_scale, seed=b)))
+        if not terms:
+            return None
+        return sds_shard.evaluate(terms, self.rank, self.world, self.dist, self.device)
+
     # -- one iteration -----------------------------------------------------------------------------
-    def step(self, i):
+    def step(self, i, img_i=None, records=None):
+        """One iteration.  `img_i` overrides the random view choice and `records` = (clf [B,3,4], inp [B,3,4]) the
+        drawn supervision batches (tests replay the reference's draws with them)."""
         args, sc = self.args, self.scene
-        img_i = int(self.rng.choice(sc.i_train))
+        if img_i is None:
+            img_i = int(self.rng.choice(sc.i_train))
         pose = sc.poses[img_i]
         # 1. masked pixels of the chosen view, with grad
-        sel = self._shard(sc.masked_idx)
+        masked_idx = sc.masked_idx_of(img_i)
+        sel = self._shard(masked_idx)
         r1 = self._render_pixels(pose, sel, retraw=True, **self.kw_train)
         rgb_masked = r1['rgb_map']
         rays_rendered = sel.numel()
@@ -145,11 +209,11 @@ class SecondStageTrainer:
         loss_sds = None
         if self.guidance is not None:
             # assemble the frame on every rank (local shard keeps its autograd history)
-            rgb_all = all_gather_ragged(rgb_masked, sc.masked_idx.numel(), self.rank, self.world, self.dist)
+            rgb_all = all_gather_ragged(rgb_masked, masked_idx.numel(), self.rank, self.world, self.dist)
             combin = sc.images[img_i].detach().clone().reshape(-1, 3)
-            combin = combin.index_put((sc.masked_idx,), rgb_all).reshape(sc.H, sc.W, 3)
+            combin = combin.index_put((masked_idx,), rgb_all).reshape(sc.H, sc.W, 3)
             combin_rgb = combin.permute(2, 0, 1).unsqueeze(0)
-            mask = sc.masks[img_i].float().reshape(1, 1, sc.H, sc.W)
+            mask = sc.mask_of(img_i).float().reshape(1, 1, sc.H, sc.W)
             normal_map = rgbs4 = mask4 = None
             if getattr(args, 'is_normal_guidance', False):      # run.py:948 (colla without normal is a NameError
                 normal_map, n = self._normal_map(pose)          # in the reference, run.py:1003; here it passes None)
@@ -157,40 +221,60 @@ class SecondStageTrainer:
             if getattr(args, 'is_colla_guidance', False):
                 rgbs4, mask4, n = self._colla_views(i)
                 rays_rendered += n
-            if self.world > 1:                         # replicated SDS term: identical noise on every rank
-                for sd in self.guidance.guidance.values():
-                    sd.generator = torch.Generator(device=self.device).manual_seed(777 + i)
-            loss_sds = self.guidance.cal_loss(i, rgbs4, normal_map, None, combin_rgb, None, mask, mask4, 1)
+            if self.view_shard and hasattr(self.guidance, 'guidance') and 'SD' in getattr(self.guidance, 'guidance', {}) \
+                    and hasattr(self.guidance.guidance['SD'], 'image_grad'):
+                loss_sds = self._sds_view_sharded(i, combin_rgb, mask, normal_map, rgbs4, mask4)
+            else:
+                if self.world > 1:                     # replicated SDS terms: identical noise on every rank
+                    for sd in self.guidance.guidance.values():
+                        if hasattr(sd, 'seed_generator'):
+                            sd.seed_generator(777 + i)
+                loss_sds = args.sds_loss_weight * self.guidance.cal_loss(i, rgbs4, normal_map, None, combin_rgb, None,
+                                                                         mask, mask4, 1)
 
         # 3. supervision batches: unmasked colour rays and inpainted-depth rays
-        g = torch.Generator(device=self.device).manual_seed(10007 * (i + 1))
-        pick = sc.unmasked_idx[torch.randint(0, sc.unmasked_idx.numel(), (self.N_rand,), device=self.device,
-                                              generator=g)]
-        pick = self._shard(pick)
-        r2 = self._render_pixels(pose, pick, retraw=True, **self.kw_train)
-        target_clf = sc.images[img_i].reshape(-1, 3)[pick]
-        pick_d = sc.masked_idx[torch.randint(0, sc.masked_idx.numel(), (self.N_rand,), device=self.device,
-                                             generator=g)]
-        pick_d = self._shard(pick_d)
-        r3 = self._render_pixels(pose, pick_d, retraw=True, **self.kw_train)
-        target_inp = sc.depths[img_i].reshape(-1)[pick_d]
-        rays_rendered += pick.numel() + pick_d.numel()
-
-        # 4. losses (run.py:1000-1027); means over the GLOBAL batch -> scale shards by 1/world
-        self.optimizer.zero_grad(set_to_none=True)
-        img_loss = img2mse(r2['rgb_map'], target_clf)
-        depth_loss = img2mse(r3['disp_map'], target_inp)
-        loss = img_loss + args.depth_lambda * depth_loss
-        if 'rgb0' in r2 and not getattr(args, 'no_coarse', False):
-            loss = loss + img2mse(r2['rgb0'], target_clf)
-        if self.world > 1:
-            loss = loss / self.world
-        if loss_sds is not None:
-            loss = loss + args.sds_loss_weight * loss_sds
+        if getattr(sc, 'sets', None) is not None or records is not None:
+            rays_c, target_clf, _ = sc.next_batch('rays_rgb_clf', self.N_rand, None if records is None else records[0])
+            rays_d, _, target_inp = sc.next_batch('rays_inp', self.N_rand, None if records is None else records[1])
+            n_clf, n_inp = rays_c.shape[1], rays_d.shape[1]
+            take = lambda t, dim: t if self.world == 1 else t.index_select(
+                dim, torch.arange(self.rank, t.shape[dim], self.world, device=t.device))
+            rays_c, target_clf = take(rays_c, 1), take(target_clf, 0)
+            rays_d, target_inp = take(rays_d, 1), take(target_inp, 0)
+            r2 = self._render_records(rays_c, retraw=True, **self.kw_train)
+            r3 = self._render_records(rays_d, retraw=True, **self.kw_train)
+            n_clf_local, n_inp_local = rays_c.shape[1], rays_d.shape[1]
         else:
+            g = torch.Generator(device=self.device).manual_seed(10007 * (i + 1))
+            pick = sc.unmasked_idx[torch.randint(0, sc.unmasked_idx.numel(), (self.N_rand,), device=self.device,
+                                                  generator=g)]
+            n_clf = n_inp = self.N_rand
+            pick = self._shard(pick)
+            r2 = self._render_pixels(pose, pick, retraw=True, **self.kw_train)
+            target_clf = sc.images[img_i].reshape(-1, 3)[pick]
+            pick_d = sc.masked_idx[torch.randint(0, sc.masked_idx.numel(), (self.N_rand,), device=self.device,
+                                                 generator=g)]
+            pick_d = self._shard(pick_d)
+            r3 = self._render_pixels(pose, pick_d, retraw=True, **self.kw_train)
+            target_inp = sc.depths[img_i].reshape(-1)[pick_d]
+            n_clf_local, n_inp_local = pick.numel(), pick_d.numel()
+        rays_rendered += n_clf_local + n_inp_local
+
+        # 4. losses (run.py:1000-1027); means over the GLOBAL batch: a shard's mean enters with n_local / n_global
+        self.optimizer.zero_grad(set_to_none=True)
+        wc, wi = n_clf_local / max(n_clf, 1), n_inp_local / max(n_inp, 1)
+        img_loss = img2mse(r2['rgb_map'], target_clf.float()) * wc if n_clf_local else 0.
+        depth_loss = img2mse(r3['disp_map'], target_inp.float()) * wi if n_inp_local else 0.
+        loss = img_loss + args.depth_lambda * depth_loss
+        if 'rgb0' in r2 and not getattr(args, 'no_coarse', False) and n_clf_local:
+            loss = loss + img2mse(r2['rgb0'], target_clf.float()) * wc
+        if loss_sds is not None:
+            loss = loss + loss_sds
+        elif self.guidance is None:
             # without a diffusion prior the masked render still has to be back-propagated for the
             # iteration to have the reference's cost structure: a plain colour loss stands in
-            loss = loss + args.sds_loss_weight * img2mse(rgb_masked, sc.images[img_i].reshape(-1, 3)[sel])
+            wm = sel.numel() / max(masked_idx.numel(), 1)
+            loss = loss + args.sds_loss_weight * img2mse(rgb_masked, sc.images[img_i].reshape(-1, 3)[sel]) * wm
         loss.backward()
         self._allreduce_grads()
         self.optimizer.step()
