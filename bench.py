@@ -1,14 +1,18 @@
 """bench.py -- throughput of the MVIP-NeRF hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode render|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of the hot path over one batch of synthetic input:
-  render : one 378x504 frame (190,512 rays), coarse 64 + fine 128 samples, test-mode kwargs;
-  train  : one second-stage iteration (masked-set render + clf batch + inp batch, losses,
-           backward through the fused kernels, Adam).
-For N > 1 the driver launches one process per GPU (torch.distributed / RCCL); every rank works
-on its own frames / ray sets (weak scaling) and in train mode the 4.77 MB gradient buffer is
-all-reduced once per step.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic input: one 378x504 frame
+(190,512 rays), coarse 64 + fine 128 samples, test-mode kwargs, per rank.  `value` = rays/s over all ranks (weak
+scaling: every rank renders its own frames, no data-path collective).  Further legs in the same JSON line: the
+second-stage training iteration (rays sharded, ONE 4.77 MB gradient all-reduce), the SDS step with its own roofline
+(FLOPs counted from the layer shapes), the full BASELINE configs[1]/[2]/[3] iterations (SDS terms owned by different
+ranks), and the CPU baseline (oracle on the host cores: render, train and SDS legs, >= 3 warm-ups, median of >= 5).
+
+Launch: with N > 1 and no WORLD_SIZE in the environment this process only SPAWNS the N ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py`, rendezvous on 127.0.0.1) before touching any
+GPU, relays rank 0's JSON line and exits with the children's status; under an external launcher (WORLD_SIZE set)
+--gpus must equal the world size.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -27,6 +31,7 @@ H, W, FOCAL, NEAR, FAR = 378, 504, 383.65, 1.2, 7.74
 N_SAMPLES, N_IMPORTANCE = 64, 64
 FLOP_PER_POINT = 2 * 593408            # algorithmic MACs of the 8x256 MLP, forward
 PEAK_F32_TFLOPS = 157.3                # MI355X_MICROARCH.md: fp32 MFMA / vector peak
+PEAK_F16_TFLOPS = 2500.0               # MI355X_MICROARCH.md: fp16 / bf16 dense MFMA peak
 
 
 def make_args():
@@ -47,24 +52,89 @@ def orbit_pose(k, device):
                         device=device)
 
 
-def cpu_baseline(n_rays=8192, threads=None):
-    """The oracle (a torch-CPU restatement of the reference, oracle/nerf_oracle.py) timed on the
-    host cores over a bounded sample of the same workload: `n_rays` rays of frame 0."""
+def _median_time(fn, warmup, reps):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def cpu_baseline(warmup=3, reps=5, threads=None, sds_flops_full=None):
+    """The oracle (a torch-CPU restatement of the reference: oracle/nerf_oracle.py, oracle/sds_oracle.py) timed on the
+    host cores over BOUNDED samples of the same workloads (>= 3 warm-ups, median of >= 5):
+      render : n rays of frame 0 through render_rays, no_grad (metric: rays/s);
+      train  : one second-stage iteration without the prior on a reduced batch: forward + backward + Adam (rays/s);
+      sds    : train_step_sd forward + backward with the SD-1.5-shaped networks at 256^2 (latents 32^2) -- a quarter
+               of the pixels -- scaled to 512^2 by the counted FLOP ratio (steps/s)."""
     from oracle import nerf_oracle as O
+    from oracle import sds_oracle as S
     cores = threads or min(os.cpu_count() or 1, 32)   # more threads than this only adds sync overhead here
     torch.set_num_threads(cores)
     pc, pf = O.mlp_init(0), O.mlp_init(1)
     ro, rd = O.get_rays(H, W, FOCAL, O.bench_poses(1)[0])
     rows = O.assemble_ray_batch(ro, rd, NEAR, FAR)
-    sel = torch.linspace(0, rows.shape[0] - 1, n_rays).long()
-    rows = rows[sel]
-    with torch.no_grad():
-        O.render_rays(rows[:256], pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True)   # warm-up
-        t0 = time.perf_counter()
-        O.render_rays(rows, pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True)
-        dt = time.perf_counter() - t0
-    return {'value': n_rays / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_rays} evenly spaced rays of frame 0, test mode, {dt:.1f} s'}
+    n_render = 1024
+    r_rows = rows[torch.linspace(0, rows.shape[0] - 1, n_render).long()]
+
+    def render():
+        with torch.no_grad():
+            O.render_rays(r_rows, pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True)
+    t_r, all_r = _median_time(render, warmup, reps)
+
+    n_m, n_b = 192, 64                                   # masked set / each supervision batch of the reduced iteration
+    g = torch.Generator().manual_seed(1)
+    params = [p.requires_grad_(True) for p in list(pc.values()) + list(pf.values())]
+    opt = torch.optim.Adam(params, lr=3e-3)
+    tgt = torch.rand(n_m + 2 * n_b, 3, generator=g)
+    t_rows = rows[torch.randint(0, rows.shape[0], (n_m + 2 * n_b,), generator=g)]
+
+    def train():
+        opt.zero_grad(set_to_none=True)
+        r = O.render_rays(t_rows, pc, pf, N_SAMPLES, N_IMPORTANCE, lindisp=True, white_bkgd=True,
+                          t_rand=torch.rand(t_rows.shape[0], N_SAMPLES, generator=g),
+                          u=torch.rand(t_rows.shape[0], N_IMPORTANCE, generator=g))
+        a, b = n_m, n_m + n_b
+        loss = (1e-4 * O.img2mse(r['rgb_map'][:a], tgt[:a]) + O.img2mse(r['rgb_map'][a:b], tgt[a:b])
+                + O.img2mse(r['rgb0'][a:b], tgt[a:b]) + 0.1 * O.img2mse(r['disp_map'][b:], tgt[b:, 0]))
+        loss.backward()
+        opt.step()
+    t_t, all_t = _median_time(train, warmup, reps)
+    for p in params:
+        p.requires_grad_(False)
+
+    legs = {'render': {'value': n_render / t_r, 'unit': 'rays/s', 'sample': f'{n_render} evenly spaced rays of frame 0, test mode',
+                       'seconds': [round(t, 3) for t in all_r]},
+            'train': {'value': (n_m + 2 * n_b) / t_t, 'unit': 'rays/s',
+                      'sample': f'{n_m} masked + {n_b} colour + {n_b} depth rays, forward + backward + Adam',
+                      'seconds': [round(t, 3) for t in all_t]}}
+    try:
+        from mvip_nerf_amd.guidance.sd_nets import SDNetworks
+        from mvip_nerf_amd.guidance.flops import sds_step_flops
+        nets = SDNetworks(torch.device('cpu'), torch.float32)
+        size = 256
+        pred = torch.rand(1, 3, 94, 126, generator=g).requires_grad_(True)
+        mask = torch.zeros(1, 1, 94, 126)
+        mask[:, :, 34:60, 49:77] = 1
+
+        def sds():
+            pred.grad = None
+            (1e-4 * S.train_step_sd(nets, 1000, mask, 'a stone bench in a park', pred, guidance_scale=7.5, size=size)).sum().backward()
+        t_s, all_s = _median_time(sds, min(warmup, 1), max(3, min(reps, 3)))
+        f_small = sds_step_flops(size)['per_step']
+        f_full = sds_flops_full or sds_step_flops(512)['per_step']
+        legs['sds'] = {'value': 1.0 / (t_s * f_full / f_small), 'unit': 'steps/s',
+                       'sample': f'train_step_sd forward + backward at {size}^2 ({f_small / 1e12:.2f} TFLOP), scaled to 512^2 '
+                                 f'({f_full / 1e12:.2f} TFLOP) by the counted FLOP ratio; 1 warm-up, median of 3',
+                       'seconds': [round(t, 3) for t in all_s]}
+        del nets
+    except Exception as e:                                  # a reported baseline, never fatal for the bench line
+        legs['sds'] = {'error': f'{type(e).__name__}: {e}'}
+    return {'value': legs['render']['value'], 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': legs['render']['sample'] + f'; {warmup} warm-ups, median of {reps}', 'legs': legs}
 
 
 def kernel_roofline(run_mod, nets, device, reps=3):
@@ -98,26 +168,79 @@ def kernel_roofline(run_mod, nets, device, reps=3):
             'points_per_launch': points, 'flop_per_point': FLOP_PER_POINT}
 
 
+def spawn_ranks(n, argv):
+    """Start n ranks of this script (one per GPU) under torch.distributed.run and relay rank 0's JSON line.
+    Runs BEFORE anything touches a GPU in this process, never re-executes this process, and returns the
+    launcher's exit status (non-zero if any rank failed or no JSON line came back)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if line is not None else 1
+
+
+def dry_run(world, rank, args):
+    """MVIP_BENCH_DRYRUN=1: the launch / rendezvous path without GPU work (CPU test of the launcher)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo')
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        assert float(t) == world * (world - 1) / 2
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run (launcher only)', 'value': 0.0, 'unit': 'rays/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--train-steps', type=int, default=3, help='second-stage iterations timed after the render leg')
-    ap.add_argument('--sds-steps', type=int, default=3, help='SDS / full-iteration steps timed in the third leg')
+    ap.add_argument('--sds-steps', type=int, default=5, help='SDS / full-iteration steps timed in the third leg')
     ap.add_argument('--no-hashgrid', dest='hashgrid', action='store_false')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-warmup', type=int, default=3)
+    ap.add_argument('--cpu-reps', type=int, default=5)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if os.environ.get('MVIP_BENCH_DRYRUN') == '1':
+        return dry_run(world, rank, args)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    # debug hooks for 1-GPU boxes: all ranks on device 0 over gloo (never set by the driver)
-    if os.environ.get('MVIP_BENCH_SINGLE_DEVICE') == '1':
+    # debug hook for 1-GPU boxes: all ranks on device 0 over gloo (never set by the driver)
+    single = os.environ.get('MVIP_BENCH_SINGLE_DEVICE') == '1'
+    if single:
         local_rank = 0
-    backend = os.environ.get('MVIP_DIST_BACKEND', 'nccl')
+    backend = os.environ.get('MVIP_DIST_BACKEND', 'gloo' if single else 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -387,8 +510,19 @@ def main():
         result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
                                           'iterations_per_sec': args.sds_steps / dt_full16,
                                           'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
-        result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': dt_sds / args.sds_steps * 1e3,
-                         'dtype': 'f32 tensors; 3x3 ResNet convolutions on fp16 MFMA in split precision (f16x3, ~1e-6 relative), the rest library fp32',
+        from mvip_nerf_amd.guidance.flops import sds_step_flops
+        fl = sds_step_flops(512)
+        sds_ms = dt_sds / args.sds_steps * 1e3
+        ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
+        sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
+                    'unet_forward_flops': fl['unet_forward'], 'vae_encoder_forward_flops': fl['vae_encoder_forward'],
+                    'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
+                    'peak': round(PEAK_F16_TFLOPS / 3, 1),
+                    'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / 3 products: the split-precision kernels (3x3 convolutions, GEMMs, '
+                               'attention) carry the step\'s contractions except the strided, 8x8-level and stem convolutions (library fp32)',
+                    'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
+        result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
+                         'dtype': 'f32 tensors; 3x3 convolutions, linear layers and attention on fp16 MFMA in split precision (f16x3, ~1e-6 relative), strided / 8x8 / stem convolutions library fp32',
                          'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
                          'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
                          'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
@@ -400,7 +534,8 @@ def main():
     if rank == 0:
         result['roofline'] = kernel_roofline(run, te, device)
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline()
+            result['cpu_baseline'] = cpu_baseline(args.cpu_warmup, args.cpu_reps,
+                                                  sds_flops_full=result.get('sds', {}).get('roofline', {}).get('flops_per_step'))
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -175,24 +175,42 @@ def _workspace(device, tile_points):
     return _WORKSPACE[key]
 
 
-# Keep the activations of a training forward for its backward when the live stashes stay under
-# this many bytes (9.9 KB per point); beyond it the backward recomputes them tile by tile.
-STASH_BUDGET_BYTES = 96 << 30
-_stash_live = [0]
+# Keep the activations of a training forward for its backward (9.9 KB per point) while they fit the DEVICE: the
+# budget is computed per call from what is free right now (hipMemGetInfo + the allocator's cached-but-unused blocks),
+# so two ranks sharing one device, a resident fp32 SD UNet + VAE, or a smaller-HBM part shrink it by themselves.
+# Beyond it -- or if the allocation fails -- the backward recomputes the activations tile by tile.
+# MVIP_STASH_BUDGET_BYTES overrides the computed budget (0 = always recompute).
+STASH_FREE_FRACTION = 0.6          # of the currently free bytes, after the backward workspace is set aside
+_stash_live = {}                   # device index -> bytes of live stashes
+
+
+def _stash_budget(device):
+    env = _os.environ.get('MVIP_STASH_BUDGET_BYTES')
+    if env is not None:
+        return int(env)
+    free, _total = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    ws_bytes = 0 if (device, BWD_TILE_POINTS) in _WORKSPACE else int(
+        _lib.load().mvip_mlp_backward_workspace_bytes(BWD_TILE_POINTS))
+    return int(STASH_FREE_FRACTION * max(free - ws_bytes, 0))
 
 
 def _take_stash(P, device):
     n = int(_lib.load().mvip_mlp_stash_floats(P))
-    if _stash_live[0] + 4 * n > STASH_BUDGET_BYTES:
+    if 4 * n > _stash_budget(device):
         return None
-    _stash_live[0] += 4 * n
-    t = torch.empty(n, device=device, dtype=_F32)
-    weakref.finalize(t, _stash_freed, 4 * n)        # also covers graphs that are dropped without backward
+    try:
+        t = torch.empty(n, device=device, dtype=_F32)
+    except torch.OutOfMemoryError:
+        return None                                  # fragmentation or a concurrent process: recompute instead
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    _stash_live[key] = _stash_live.get(key, 0) + 4 * n
+    weakref.finalize(t, _stash_freed, key, 4 * n)   # also covers graphs that are dropped without backward
     return t
 
 
-def _stash_freed(nbytes):
-    _stash_live[0] -= nbytes
+def _stash_freed(key, nbytes):
+    _stash_live[key] = _stash_live.get(key, 0) - nbytes
 
 
 class _MLPRays(torch.autograd.Function):

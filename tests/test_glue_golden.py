@@ -169,9 +169,10 @@ def test_trainer_two_steps_golden(golden, cuda):
             gr = N(p.grad).astype(np.float64).ravel()
             stat = g[f'gstat/{prefix}{k}']
             np.testing.assert_allclose(np.sqrt((gr * gr).sum()), stat[2], rtol=2e-2, err_msg=prefix + k)
-            # parameters after two Adam steps: the first step moves every entry by ~lr * sign(grad), so entries whose
-            # gradient is at rounding level may land 2 lr apart; all others must agree closely
+            # parameters after two Adam steps (lr = 3e-3): Adam's normalised update lr * m / sqrt(v) turns a relative
+            # gradient difference into an absolute parameter difference of that fraction of lr, and entries whose
+            # gradient is at rounding level may land up to 2 lr apart per step; bound both
             v = N(p).astype(np.float64).ravel()
             want = g[f'pval/{prefix}{k}']
             d = np.abs(v[g[f'pidx/{prefix}{k}']] - want)
-            assert np.mean(d > 2e-4) <= 0.05 and d.max() <= 4.1 * 3e-3, (prefix + k, d.max(), np.mean(d > 2e-4))
+            assert np.mean(d > 1e-3) <= 0.05 and d.max() <= 4.1 * 3e-3, (prefix + k, d.max(), np.mean(d > 1e-3))

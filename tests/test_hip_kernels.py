@@ -274,15 +274,22 @@ def test_mlp_backward_tiled_equals_untiled(cuda):
     z = ops.stratified_z(rows, 64, True)
     gout = torch.randn(40, 64, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
     outs = []
-    for tile, budget in ((65536, 96 << 30), (512, 96 << 30), (1024, 0)):   # kept stash, tiled stash, recompute
+    import os
+    for tile, budget in ((65536, None), (512, None), (1024, 0)):   # kept stash, tiled stash, recompute
         ops.BWD_TILE_POINTS = tile
-        ops.STASH_BUDGET_BYTES = budget
+        if budget is None:
+            os.environ.pop('MVIP_STASH_BUDGET_BYTES', None)       # budget from the device's free memory
+        else:
+            os.environ['MVIP_STASH_BUDGET_BYTES'] = str(budget)
         ps = [p.requires_grad_(True) for p in params_dev(32, cuda)]
         raw = ops.mlp_rays(rows, z, ops.mlp_pack(ps), ps)
         (raw * gout).sum().backward()
         outs.append([N(p.grad) for p in ps])
-    ops.BWD_TILE_POINTS, ops.STASH_BUDGET_BYTES = 65536, 96 << 30
-    assert ops._stash_live[0] == 0                       # every stash was released
+    ops.BWD_TILE_POINTS = 65536
+    os.environ.pop('MVIP_STASH_BUDGET_BYTES', None)
+    assert sum(ops._stash_live.values()) == 0           # every stash was released
+    free, _ = torch.cuda.mem_get_info(cuda)
+    assert 0 < ops._stash_budget(cuda) <= free + torch.cuda.memory_reserved(cuda)   # follows the device, not a constant
     for other in outs[1:]:
         for a, b, k in zip(outs[0], other, ops.PARAM_ORDER):
             np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5 * (np.abs(a).max() + 1e-12), err_msg=k)
@@ -368,15 +375,19 @@ def test_mlp_backward_f16x3_golden(golden, cuda):
     """train_precision=1: split-precision stash-forward + delta kernels; gradients vs the reference autograd."""
     from mvip_nerf_amd import ops
     g = golden('mlp_fwd_bwd')
-    for budget in (96 << 30, 0):                       # kept-stash path and recompute path
-        ops.STASH_BUDGET_BYTES = budget
+    import os
+    for budget in (None, 0):                           # kept-stash path and recompute path
+        if budget is None:
+            os.environ.pop('MVIP_STASH_BUDGET_BYTES', None)
+        else:
+            os.environ['MVIP_STASH_BUDGET_BYTES'] = str(budget)
         ps = [p.requires_grad_(True) for p in params_dev(g['seed'], cuda)]
         packed = ops.mlp_pack(ps)
         raw = ops.mlp_points(T(g['pts'], cuda), T(g['dirs'], cuda), packed, ps, train_f16x3=ops.mlp_pack_f16x3(ps, packed))
         np.testing.assert_allclose(N(raw), g['out'], rtol=5e-5, atol=5e-6)
         (raw * T(g['gout'], cuda)).sum().backward()
         _check_grads(g, '', {k: p.grad for k, p in zip(ops.PARAM_ORDER, ps)}, 2e-5, 2e-4)
-    ops.STASH_BUDGET_BYTES = 96 << 30
+    os.environ.pop('MVIP_STASH_BUDGET_BYTES', None)
 
 
 def test_empty_and_ragged_inputs(cuda, golden):

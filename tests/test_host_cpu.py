@@ -94,3 +94,23 @@ def test_pose_processing_on_fixture_poses(golden):
     hwf = g['poses'][0, :, 4]
     assert hwf[0] == 567 and hwf[1] == 1008 and abs(hwf[2] - 3069.17394 / 4) < 1e-2
     assert g['render_poses'].shape == (120, 3, 5)
+
+
+def test_bench_launcher_spawns_ranks_itself():
+    """`bench.py --gpus N` with no WORLD_SIZE starts N ranks before touching a GPU and relays ONE JSON line with
+    n_gpus = N (launcher-only dry run over gloo); under an external launcher a mismatching --gpus fails loudly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['MVIP_BENCH_DRYRUN'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3'], env=dict(env, WORLD_SIZE='2', RANK='0'),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr

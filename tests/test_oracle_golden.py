@@ -159,3 +159,31 @@ def test_misc(golden):
     mse = O.img2mse(T(g['a']), T(g['b']))
     np.testing.assert_allclose(mse.numpy(), g['mse'], rtol=1e-6)
     np.testing.assert_allclose(O.mse2psnr(mse).numpy(), g['psnr'].reshape(()), rtol=1e-6)
+
+
+# ---- the SDS wrapper oracle (oracle/sds_oracle.py) vs the reference's own wrapper on the stand-in networks --------
+def _standin_nets():
+    import types
+    from oracle.sds_standin import TinyVAE, TinyUNet, TinyScheduler, prompt_embedding
+    return types.SimpleNamespace(vae=TinyVAE(), unet=TinyUNet(), encode_prompt=prompt_embedding,
+                                 alphas_cumprod=TinyScheduler().alphas_cumprod)
+
+
+@pytest.mark.parametrize('name', ['sds_rgb_i0', 'sds_rgb_i100', 'sds_rgb_i5000', 'sds_rgb_i20000', 'sds_normal'])
+def test_sds_wrapper_oracle(golden, name):
+    from oracle import sds_oracle as S
+    g = golden(name)
+    nets = _standin_nets()
+    torch.manual_seed(int(g['seed']))
+    draws = iter([torch.randn(1, 4, 64, 64) for _ in range(4)])            # the reference's CPU draws, in its order
+    nets.vae.randn = lambda s: next(draws)
+    pred = T(g['pred']).requires_grad_(True)
+    kw = dict(guidance_scale=float(g['guidance_scale']), randn=lambda s: next(draws))
+    if name == 'sds_normal':
+        loss = S.train_step_sd_normal(nets, int(g['i']), T(g['mask']), 'a normal map of a stone bench', pred,
+                                      normal_start=int(g['normal_start']), **kw)
+    else:
+        loss = S.train_step_sd(nets, int(g['i']), T(g['mask']), 'a stone bench in a park', pred, **kw)
+    assert float(loss) == 1.0
+    (float(g['upstream']) * loss).sum().backward()
+    np.testing.assert_allclose(pred.grad.numpy(), g['d_pred'], rtol=1e-4, atol=1e-6 * np.abs(g['d_pred']).max())
