@@ -280,6 +280,13 @@ int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, 
 int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                     const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                     float *y, void *stream);
+/* The feed-forward's first projection with the GEGLU in the epilogue (the [N][2R][P] intermediate never exists):
+ * out [N][R][P] = (W_v x + b_v) * gelu(W_g x + b_g) for columns < L, zero beyond; `packed` / `bias` hold the M2 = 2R
+ * rows interleaved in 32-row tiles (value rows of tile t, then the gate rows of tile t); M2 % 64 == 0.  scale2 and
+ * zero_word as in mvip_geglu. */
+int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
+                          int64_t K, int64_t M2, int64_t P, int64_t L, float *out, float *scale2, void *zero_word,
+                          void *stream);
 /* the same with the workgroup tile forced (timing switch; identical arithmetic per output element up to the k order
  * inside a stage, which is the same): cfg 0 = by shape (what mvip_gemm_f16x3 does), 1 = 32/64 rows x 256 columns,
  * 2 = 128 x 256 (M % 128 == 0), 3 = 128 x 128 (M % 128 == 0), 4 = 64 x 128 (M % 64 == 0). */

@@ -85,6 +85,7 @@ _SIGNATURES = {
     'mvip_gemm_pack_a': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
     'mvip_attention_supported': (_int, [_i64]),
     'mvip_attention_v_bytes': (_i64, [_i64, _i64, _i64, _i64]),

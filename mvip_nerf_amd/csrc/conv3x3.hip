@@ -383,6 +383,10 @@ struct GemmArgs {
     float *y;
     int N, CK, M, MB, tiles;
     int64_t P;
+    // GEGLU epilogue (MT = 2 only): the rows are interleaved in 32-row tiles (value tile, gate tile); the kernel
+    // writes value * gelu(gate) as [N][M/2][P], zero for columns >= geglu_L, and collects the absolute maximum
+    int geglu_L;                 // 0: plain epilogue
+    unsigned *absmax_bits;
 };
 
 template <int MT>
@@ -463,6 +467,30 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
         }
     }
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+    if (MT == 2 && a.geglu_L > 0) {
+        // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
+        // two row tiles; the [N][8C][P] intermediate never exists
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
+                float av = acc[0][j][r] * inv, gv = acc[MT - 1][j][r] * inv;
+                if (a.bias) { av += a.bias[(mb * 2 + 0) * 32 + r32]; gv += a.bias[(mb * 2 + 1) * 32 + r32]; }
+                float v = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+                if (px >= a.geglu_L) v = 0.f;
+                const float w = fabsf(v);
+                mx = (w == w && w < 3.0e38f) ? fmaxf(mx, w) : mx;
+                a.y[((int64_t)n * (a.M / 2) + mb * 32 + r32) * a.P + px] = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) atomicMax(a.absmax_bits, __float_as_uint(mx));
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -479,6 +507,22 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
                 a.y[o] = v;
             }
         }
+}
+
+// scale2 = {2^k, 2^-k} from the maximum collected in *bits, which is left zero (caller-owned scratch word)
+__global__ void gm_scale_from_bits_kernel(float *__restrict__ scale2, unsigned *__restrict__ bits) {
+    const float m = __uint_as_float(*bits);
+    *bits = 0u;
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e;
+        frexpf(m, &e);
+        int k = 10 - e;
+        k = k > 60 ? 60 : (k < -60 ? -60 : k);
+        s = ldexpf(1.f, k);
+    }
+    scale2[0] = s;
+    scale2[1] = 1.f / s;
 }
 
 // ---- the same GEMM with a square-ish workgroup tile ---------------------------------------------------------
@@ -742,6 +786,7 @@ extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const flo
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
+    a.geglu_L = 0; a.absmax_bits = nullptr;
     hipStream_t st = as_stream(stream);
     if (cfg == 0) {
         // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
@@ -781,4 +826,31 @@ extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *
                                const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                                float *y, void *stream) {
     return mvip_gemm_f16x3_cfg(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, stream);
+}
+
+// First projection of the transformer feed-forward with the GEGLU fused into the epilogue:
+//   out[n][r][p] = (W_v x + b_v)[r] * gelu((W_g x + b_g)[r])   for p < L, zero beyond,
+// `packed` / `bias` hold the 2R rows interleaved in 32-row tiles (value rows 32 t .. 32 t + 31, then the gate rows of
+// the same t); scale2 receives the power-of-two scale of |out|max; zero_word as in mvip_absmax_scale_sections.
+extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias, const float *x_scale2,
+                                     int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, float *out, float *scale2,
+                                     void *zero_word, void *stream) {
+    if (N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+        !scale2 || !zero_word)
+        return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (N > 0) {
+        if (!xs || !packed || !out) return MVIP_EINVAL;
+        GemmArgs a;
+        a.xs = (const char *)xs; a.wp = (const char *)packed;
+        a.w_scale2 = (const float *)((const char *)packed + M2 * K * 4);
+        a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = out;
+        a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
+        a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word;
+        const int64_t blocks = N * a.tiles * a.MB;
+        if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+        hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(gm_scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2, (unsigned *)zero_word);
+    return check_launch();
 }

@@ -67,8 +67,9 @@ class _Packed:
         self.o2 = pack(a2.to_out[0].weight.detach().contiguous(), C, C, C, 1)
         self.bo2 = a2.to_out[0].bias.detach().contiguous()
         w1 = ff.net[0].proj
-        self.ff1 = pack(w1.weight.detach().contiguous(), 8 * C, C, C, 1)
-        self.b1 = w1.bias.detach().contiguous()
+        wi, bi = ops.geglu_interleave(w1.weight.detach(), w1.bias.detach())       # value / gate rows in 32-row tiles
+        self.ff1 = pack(wi, 8 * C, C, C, 1)
+        self.b1 = bi
         self.ff2 = pack(ff.net[2].weight.detach().contiguous(), C, 4 * C, 4 * C, 1)
         self.b2 = ff.net[2].bias.detach().contiguous()
         self.pin = pack(mod.proj_in.weight.detach().reshape(C, C).contiguous(), C, C, C, 1)
@@ -156,8 +157,7 @@ def _block(h, pk, ctx, N, L, LP):
     # ---- GEGLU feed-forward ----
     g, b, eps, s, st = pk.ln[2]
     xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
-    y = ops.gemm_f16x3(xs, pk.ff1, N, C, 8 * C, LP, bias=pk.b1, x_scale2=st)
-    act, sa = ops.geglu(y, N, 4 * C, L, LP)
+    act, sa = ops.gemm_geglu_f16x3(xs, pk.ff1, pk.b1, N, C, 8 * C, LP, L, x_scale2=st)   # GEGLU in the GEMM's epilogue
     as_ = ops.split_planes_strided(act, N, 4 * C, LP, 4 * C * LP, LP, 1, sa)
     return ops.gemm_f16x3(as_, pk.ff2, N, 4 * C, C, LP, bias=pk.b2, residual=h, x_scale2=sa)
 

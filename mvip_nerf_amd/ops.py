@@ -176,7 +176,7 @@ def _workspace(device, tile_points):
 
 
 # Keep the activations of a training forward for its backward (9.9 KB per point) while they fit the DEVICE: the
-# budget is computed per call from what is free right now (hipMemGetInfo + the allocator's cached-but-unused blocks),
+# budget (for ALL live stashes together) is computed per call from what is free right now (hipMemGetInfo + the allocator's cached-but-unused blocks),
 # so two ranks sharing one device, a resident fp32 SD UNet + VAE, or a smaller-HBM part shrink it by themselves.
 # Beyond it -- or if the allocation fails -- the backward recomputes the activations tile by tile.
 # MVIP_STASH_BUDGET_BYTES overrides the computed budget (0 = always recompute).
@@ -192,7 +192,10 @@ def _stash_budget(device):
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
     ws_bytes = 0 if (device, BWD_TILE_POINTS) in _WORKSPACE else int(
         _lib.load().mvip_mlp_backward_workspace_bytes(BWD_TILE_POINTS))
-    return int(STASH_FREE_FRACTION * max(free - ws_bytes, 0))
+    # all live stashes together may hold STASH_FREE_FRACTION of what is available to them (free now + already held)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    live = _stash_live.get(key, 0)
+    return int(STASH_FREE_FRACTION * max(free + live - ws_bytes, 0)) - live
 
 
 def _take_stash(P, device):
@@ -1041,6 +1044,25 @@ def geglu(y, N, R, L, LP):
     scale2 = torch.empty(4, device=y.device, dtype=_F32)
     call('mvip_geglu', ptr(y), int(N), int(R), int(L), int(LP), ptr(out), ptr(scale2),
          ptr(_zero_words(y.device), torch.int32), stream())
+    return out, scale2
+
+
+def geglu_interleave(weight, bias):
+    """[2R, K] weight / [2R] bias of a GEGLU projection (value rows, then gate rows) -> the same rows interleaved in
+    32-row tiles (value tile t, gate tile t), the order `gemm_geglu_f16x3` expects."""
+    R = weight.shape[0] // 2
+    w = torch.stack([weight[:R].reshape(R // 32, 32, -1), weight[R:].reshape(R // 32, 32, -1)], 1).reshape(2 * R, -1)
+    b = torch.stack([bias[:R].reshape(R // 32, 32), bias[R:].reshape(R // 32, 32)], 1).reshape(2 * R)
+    return w.contiguous(), b.contiguous()
+
+
+def gemm_geglu_f16x3(xs, packed, bias, N, K, M2, P, L, x_scale2=None):
+    """(value * gelu(gate)) of the interleaved projection `packed` applied to split planes xs -> ([N, M2/2, P] fp32,
+    its power-of-two scale2); columns >= L are zero."""
+    out = torch.empty((N, M2 // 2, P), device=xs.device, dtype=_F32)
+    scale2 = torch.empty(4, device=xs.device, dtype=_F32)
+    call('mvip_gemm_geglu_f16x3', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
+         int(K), int(M2), int(P), int(L), ptr(out), ptr(scale2), ptr(_zero_words(xs.device), torch.int32), stream())
     return out, scale2
 
 

@@ -119,10 +119,16 @@ def _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_view
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., pytest=False,
-                sigma_loss=None, verbose=False, need_alpha=False, detach_weights=False):
+                sigma_loss=None, verbose=False, need_alpha=False, detach_weights=False, coarse_grad=True):
     """DS_NeRF/run.py:1703-1847: stratified depths -> coarse MLP -> compositing -> inverse-CDF
     resampling + merge -> fine MLP -> compositing.  Five kernel launches per chunk on the native
-    path (z, MLP, composite, sample+merge, MLP, composite) instead of ~150 torch ops."""
+    path (z, MLP, composite, sample+merge, MLP, composite) instead of ~150 torch ops.
+
+    `coarse_grad` (extension, default = the reference's behaviour): with N_importance > 0 the fine outputs depend on
+    the coarse network only through the DETACHED resampled depths (run.py:1812), so a caller that uses only
+    rgb_map / disp_map / depth_map / acc_map of a render (the masked set, the normal frame, the neighbour views of
+    run.py:919-974) gets exactly zero gradient from it into the coarse network; coarse_grad=False runs that pass
+    without autograd (no activation stash, no backward: a third of the points), changing no value and no gradient."""
     ray_batch = ray_batch.float() if ray_batch.dtype != torch.float32 else ray_batch
     ray_batch = ray_batch.contiguous()
     N_rays, ncols = ray_batch.shape
@@ -151,10 +157,11 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
 
     coarse_net = network_fn if network_fn is not None else (
         network_fine.alpha_model if getattr(network_fine, 'alpha_model', None) is not None else network_fine)
-    raw = query(z_vals, coarse_net)
-    noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
-    rgb_map, disp_map, acc_map, weights, depth_map, alpha = ops.composite(
-        raw, z_vals, rows, noise, white_bkgd, detach_weights, need_alpha)
+    with torch.set_grad_enabled(torch.is_grad_enabled() and (coarse_grad or N_importance <= 0)):
+        raw = query(z_vals, coarse_net)
+        noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
+        rgb_map, disp_map, acc_map, weights, depth_map, alpha = ops.composite(
+            raw, z_vals, rows, noise, white_bkgd, detach_weights, need_alpha)
 
     if N_importance > 0:
         rgb_map_0, disp_map_0, acc_map_0, alpha0 = rgb_map, disp_map, acc_map, alpha

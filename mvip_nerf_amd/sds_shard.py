@@ -53,7 +53,13 @@ def evaluate(terms, rank, world, dist, device):
                 with torch.no_grad():
                     latent_sum += terms[k].run().reshape(latent_sum.shape).float()
         if world > 1:
-            work = dist.all_reduce(latent_sum, async_op=True)
+            # overlapped with this rank's independent image terms on RCCL; the gloo transport (CPU tests, and the
+            # several-ranks-on-one-GPU debug mode, where an async device-tensor collective faulted) runs it in place
+            if latent_sum.is_cuda and dist.get_backend() != 'nccl':
+                torch.cuda.synchronize(device)
+                dist.all_reduce(latent_sum)
+            else:
+                work = dist.all_reduce(latent_sum, async_op=True)
     # ---- phase 2: image gradients; terms that do not need the latent sum run under the all_reduce ---------------
     grads = {}
     order = [k for k, t in enumerate(terms) if t.phase == 2]

@@ -19,7 +19,9 @@ Two kinds of scene feed it:
     rays generated on the GPU in fp32.
 Deliberate differences: the masked rays come from (pose, pixel index) on the GPU instead of a full-frame
 get_rays + 94 % discard (run.py:869-883); the neighbour views that receive no gradient in the reference's
-collaborative term are rendered without autograd; the Tk GUI thread, PNG dumps and host syncs are gone.
+collaborative term are rendered without autograd, and so is the COARSE pass of every render of which only the fine
+outputs are used (masked set, normal frame, last neighbour view: the coarse network gets exactly zero gradient from
+them, run.py:1812 detaches the resampled depths); the Tk GUI thread, PNG dumps and host syncs are gone.
 
 Multi-GPU (world > 1, torch.distributed over RCCL): every per-step ray set is sharded by index
 across ranks (rank r takes rays r::world), frames are assembled with all_gather (the local shard keeps its autograd
@@ -130,7 +132,8 @@ class SecondStageTrainer:
         plane-fit normals -> (n + 1) / 2, [1, 3, H_r, W_r]."""
         sc, f = self.scene, self.args.normalmap_render_factor
         H_r, W_r, focal_r = sc.H // f, sc.W // f, sc.focal / f
-        depth, n = self._render_frame(pose, (H_r, W_r, focal_r), 'depth_map', retraw=True, **self.kw_train)
+        depth, n = self._render_frame(pose, (H_r, W_r, focal_r), 'depth_map', retraw=True, coarse_grad=False,
+                                      **self.kw_train)
         K = torch.tensor([[focal_r, 0, W_r / 2], [0, focal_r, H_r / 2], [0, 0, 1]], dtype=torch.float32)
         points = run.depth2xyz_torch(depth.reshape(H_r, W_r), K)
         points = points.unsqueeze(0).transpose(2, 3).transpose(1, 2)
@@ -151,7 +154,7 @@ class SecondStageTrainer:
             # autograd changes no value and no gradient and skips their activation stash and backward.
             with torch.set_grad_enabled(k == views[-1]):
                 rgb, m = self._render_frame(sc.poses[k], hwf, 'rgb_map', retraw=True, need_alpha=True,
-                                            **self.kw_test)
+                                            coarse_grad=False, **self.kw_test)
             rgbs.append(rgb.reshape(hwf[0], hwf[1], 3))
             n += m if k == views[-1] else 0
         masks = sc.masks[lo:min(len(sc.masks), it + 5):2]
@@ -202,7 +205,7 @@ class SecondStageTrainer:
         # 1. masked pixels of the chosen view, with grad
         masked_idx = sc.masked_idx_of(img_i)
         sel = self._shard(masked_idx)
-        r1 = self._render_pixels(pose, sel, retraw=True, **self.kw_train)
+        r1 = self._render_pixels(pose, sel, retraw=True, coarse_grad=False, **self.kw_train)     # only rgb_map is used
         rgb_masked = r1['rgb_map']
         rays_rendered = sel.numel()
 

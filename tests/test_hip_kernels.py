@@ -140,12 +140,18 @@ def test_sample_pdf_golden(golden, cuda):
         # integer semantics of the search are exact given the kernel's own cdf ...
         want = np.stack([np.searchsorted(cdf_h[b], u[b], side='right') for b in range(u.shape[0])])
         np.testing.assert_array_equal(inds_h, want)
-        # ... and equal the reference's indices except where u sits within 2 ulp of a cdf knot
+        # ... and against the reference's own indices: EXACT on this fixture (2,560 draws per mode, incl. the all-zero,
+        # single-spike and uniform-weight rows).  The kernel's cdf is within 2 ulp of torch-CPU's, not bit-equal to it
+        # (torch's CPU `sum` is a vectorised cascade whose rounding depends on the build), so a u within 2 ulp of a
+        # cdf knot COULD land in the neighbouring bin; the count is asserted, not assumed.
         diff = inds_h != g[f'inds_{mode}']
+        n_tie = int((np.min(np.abs(g['cdf'][:, None, :] - u[:, :, None]), axis=-1) <= 2.5e-7).sum())
+        print(f'sample_pdf {mode}: {int(diff.sum())} index mismatches of {diff.size}; {n_tie} draws within 2 ulp of a knot')
         if diff.any():
             bb, jj = np.nonzero(diff)
             gap = np.min(np.abs(g['cdf'][bb] - u[bb, jj][:, None]), axis=1)
             assert gap.max() <= 2.5e-7, f'{diff.sum()} index mismatches away from ties'
+        assert int(diff.sum()) <= n_tie
         # bins of near-zero mass have cdf gaps ~1e-5, right at the reference's `denom < 1e-5 -> 1` switch:
         # a 1-ulp difference in the gap flips the branch, so allow isolated outliers inside their bin
         assert_close_outliers(N(s), g[f'samples_{mode}'], 1e-5, 2e-6, outlier_frac=0.002, outlier_atol=0.2,
@@ -175,7 +181,14 @@ def test_sample_pdf_merge_vs_oracle(cuda, Nc, Nf):
     assert (np.diff(N(zm), axis=-1) >= 0).all()                                    # sortedness
     np.testing.assert_array_equal(np.sort(np.concatenate([z, N(zs)], -1), -1), N(zm))   # a permutation of its inputs
     np.testing.assert_allclose(N(zstd), torch.std(s_ref, dim=-1, unbiased=False).numpy(), rtol=1e-4, atol=1e-6)
-    assert (N(inds) != inds_ref.numpy()).mean() < 1e-3
+    # indices: exact except at ties of u with a cdf knot (the cdf is within 2 ulp of the oracle's); count them
+    mism = N(inds) != inds_ref.numpy()
+    pdf = (wt[:, 1:-1] + 1e-5) / torch.sum(wt[:, 1:-1] + 1e-5, -1, keepdim=True)
+    cdf_ref = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1).numpy()
+    if mism.any():
+        bb, jj = np.nonzero(mism)
+        assert np.min(np.abs(cdf_ref[bb] - u[bb, jj][:, None]), axis=1).max() <= 2.5e-7
+    print(f'sample_pdf_merge Nc={Nc} Nf={Nf}: {int(mism.sum())} index mismatches of {mism.size}')
 
 
 # ---------------------------------------------------------------------------------------------- MLP
@@ -269,7 +282,10 @@ def test_mlp_backward_ragged_vs_oracle(cuda, P):
 
 def test_mlp_backward_tiled_equals_untiled(cuda):
     """The recompute tile size is an implementation knob: results agree to fp32 summation order."""
+    import gc
     from mvip_nerf_amd import ops
+    gc.collect()
+    live0 = sum(ops._stash_live.values())                # graphs other tests still hold (e.g. a failed test's frame)
     rows = T(bench_like_rays(40, seed=19), cuda)
     z = ops.stratified_z(rows, 64, True)
     gout = torch.randn(40, 64, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
@@ -287,7 +303,9 @@ def test_mlp_backward_tiled_equals_untiled(cuda):
         outs.append([N(p.grad) for p in ps])
     ops.BWD_TILE_POINTS = 65536
     os.environ.pop('MVIP_STASH_BUDGET_BYTES', None)
-    assert sum(ops._stash_live.values()) == 0           # every stash was released
+    del raw
+    gc.collect()
+    assert sum(ops._stash_live.values()) == live0       # every stash of this test was released
     free, _ = torch.cuda.mem_get_info(cuda)
     assert 0 < ops._stash_budget(cuda) <= free + torch.cuda.memory_reserved(cuda)   # follows the device, not a constant
     for other in outs[1:]:

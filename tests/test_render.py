@@ -63,8 +63,11 @@ def test_render_rays_test_mode_golden(golden, cuda):
         np.testing.assert_allclose(N(r[k]), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
     for k in ('weights', 'alpha'):        # per-sample values at the (few) displaced fine depths move with them
         assert_close_outliers(N(r[k]), g[k], 1e-4, 1e-5, outlier_frac=0.01, outlier_atol=5e-2, err_msg=k)
-    # raw is compared where the fine depths agree to 1e-6 (z feeds sin(512 z): conditioning ~4e3)
-    assert_close_outliers(N(r['raw']), g['raw'], 5e-3, 5e-3, outlier_frac=0.01, outlier_atol=1e9, err_msg='raw')
+    # raw at the (few) displaced fine depths moves with them (z feeds sin(512 z): conditioning ~4e3); the bound on those
+    # outliers is not "anything": test_render_rays_error_against_fp64_truth shows the HIP values are as close to the
+    # fp64 value of the same expressions as the reference's are.  Here: 99 % within 5e-3, the rest within the range of raw.
+    assert_close_outliers(N(r['raw']), g['raw'], 5e-3, 5e-3, outlier_frac=0.01,
+                          outlier_atol=float(np.abs(g['raw']).max()), err_msg='raw')
 
 
 def test_render_rays_pytest_train_mode_golden(golden, cuda):
@@ -81,6 +84,59 @@ def test_render_rays_pytest_train_mode_golden(golden, cuda):
     for k in ('rgb_map', 'disp_map', 'acc_map', 'depth_map', 'rgb0', 'disp0', 'acc0', 'z_std'):
         np.testing.assert_allclose(N(r[k]), g[k], rtol=2e-4, atol=2e-5, err_msg=k)
     assert_close_outliers(N(r['weights']), g['weights'], 2e-4, 2e-5, outlier_frac=0.01, outlier_atol=5e-2, err_msg='weights')
+
+
+def _oracle_fp64(rays, seed_c, seed_f, **rand):
+    """The oracle's algorithm evaluated in float64 (inputs, weights, constants): the 'true value' of the same
+    expressions, against which the fp32 reference and the HIP path are both measured."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        pc = {k: torch.from_numpy(v).double() for k, v in seeded_state_dict(int(seed_c)).items()}
+        pf = {k: torch.from_numpy(v).double() for k, v in seeded_state_dict(int(seed_f)).items()}
+        with torch.no_grad():
+            return O.render_rays(torch.from_numpy(rays).double(), pc, pf, 64, 64, lindisp=True, white_bkgd=True, retraw=True,
+                                 **{k: (None if v is None else torch.from_numpy(np.ascontiguousarray(v)).double())
+                                    for k, v in rand.items()})
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('mode', ['test', 'pytest_train'])
+def test_render_rays_error_against_fp64_truth(golden, cuda, mode):
+    """Where the algorithm itself is ill-conditioned (inverse-CDF depths inside near-empty bins, and the fine
+    network's raw outputs at those depths) elementwise agreement between two fp32 implementations is the wrong
+    yardstick.  Measure both against the SAME algorithm in fp64: the HIP path must be as close to the true value as
+    the fp32 reference is -- error quantiles within 2x of the reference's own (plus a 2-ulp floor)."""
+    from mvip_nerf_amd import run
+    g = golden('render_rays_test' if mode == 'test' else 'render_rays_pytest_train')
+    tr, te, _, _ = build(g['seed_coarse'], g['seed_fine'], cuda)
+    Bn = g['rays'].shape[0]
+    if mode == 'test':
+        rand = {}
+        with torch.no_grad():
+            r = run.render_rays(T(g['rays'], cuda), te['network_fn'], te['network_query_fn'], 64, retraw=True, lindisp=True,
+                                perturb=0., N_importance=64, network_fine=te['network_fine'], white_bkgd=True, raw_noise_std=0.)
+    else:                                           # the reference's pytest hooks: every draw is np.random.seed(0)
+        def draw(*shape):
+            np.random.seed(0)
+            return np.random.rand(*shape)
+        rand = dict(t_rand=draw(Bn, 64).astype(np.float32), noise0=draw(Bn, 64).astype(np.float32),
+                    u=draw(Bn, 64).astype(np.float32), noise1=draw(Bn, 128).astype(np.float32))
+        with torch.no_grad():
+            r = run.render_rays(T(g['rays'], cuda), tr['network_fn'], tr['network_query_fn'], 64, retraw=True, lindisp=True,
+                                perturb=1., N_importance=64, network_fine=tr['network_fine'], white_bkgd=True,
+                                raw_noise_std=1., pytest=True)
+    truth = _oracle_fp64(g['rays'], g['seed_coarse'], g['seed_fine'], **rand)
+    report = {}
+    for key, floor in (('z_vals', 2 * 7.74 * 6e-8), ('raw', 1e-5), ('weights', 2e-7), ('rgb_map', 2e-7), ('depth_map', 1e-6)):
+        t64 = truth[key].numpy()
+        e_hip = np.abs(N(r[key]).astype(np.float64) - t64).ravel()
+        e_ref = np.abs(g[key].astype(np.float64) - t64).ravel()
+        report[key] = (e_hip.mean(), e_ref.mean(), e_hip.max(), e_ref.max())
+        for q in (50, 99, 99.9, 100):
+            assert np.percentile(e_hip, q) <= 2.0 * np.percentile(e_ref, q) + floor, (key, q, report[key])
+        assert e_hip.mean() <= 2.0 * e_ref.mean() + floor, (key, report[key])
+    print('error vs fp64 truth (mean hip, mean ref, max hip, max ref):', report)
 
 
 def test_render_fullframe_golden(golden, cuda):
