@@ -1,0 +1,54 @@
+"""Per-kernel device time of ONE steady-state `train_step_sd` (forward + backward to the image) at SD-1.5-inpaint
+shapes, from the torch profiler: top kernels with call counts, device-busy total and the wall time of the step."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvip_nerf_amd.guidance.sd_utils import StableDiffusion          # noqa: E402
+
+
+def main():
+    dev = torch.device('cuda', 0)
+    sd = StableDiffusion(dev, False, False)
+    g = torch.Generator(device=dev).manual_seed(2)
+    H, W = 378, 504
+    pred = torch.rand(1, 3, H, W, device=dev, generator=g).requires_grad_(True)
+    mask = torch.zeros(1, 1, H, W, device=dev)
+    mask[:, :, 137:241, 196:307] = 1
+
+    def step(i):
+        pred.grad = None
+        (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
+    for k in range(3):
+        step(1000 + k)
+    torch.cuda.synchronize()
+    ts = []
+    for k in range(7):
+        t0 = time.perf_counter()
+        step(1010 + k)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        step(1100)
+        torch.cuda.synchronize()
+    ev = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+    total = sum(e.device_time_total for e in ev) / 1e3
+    n = sum(e.count for e in ev)
+    print(f'== train_step_sd: median wall {sorted(ts)[len(ts) // 2]:.2f} ms {[round(t, 1) for t in ts]}, device-busy {total:.2f} ms, {n} kernels')
+    rows = []
+    for e in ev[:40]:
+        print(f'  {e.device_time_total / 1e3:8.3f} ms  x{e.count:4d}  {e.key[:120]}')
+        rows.append([round(e.device_time_total / 1e3, 3), e.count, e.key[:120]])
+    own = sum(e.device_time_total for e in ev if 'mvip::' in e.key) / 1e3
+    print(f'   hand-written (mvip::) kernels: {own:.2f} ms of {total:.2f} ms device-busy')
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump({'median_wall_ms': sorted(ts)[len(ts) // 2], 'wall_ms': ts, 'device_busy_ms': total, 'kernels': n,
+               'mvip_kernels_ms': own, 'top': rows}, open('gpurun_out/sds_step_profile.json', 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
