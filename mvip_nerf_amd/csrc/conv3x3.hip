@@ -387,6 +387,9 @@ struct GemmArgs {
     // writes value * gelu(gate) as [N][M/2][P], zero for columns >= geglu_L, and collects the absolute maximum
     int geglu_L;                 // 0: plain epilogue
     unsigned *absmax_bits;
+#ifdef MVIP_EXPERIMENT_GEMM
+    int dbg;                     // timing experiments: 1 = no epilogue stores, 2 = no MFMAs, 4 = no LDS reads either
+#endif
 };
 
 template <int MT>
@@ -457,6 +460,9 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
             for (int m = 0; m < MT; ++m) {
                 const h16x8 ah = *reinterpret_cast<const h16x8 *>(wb + ((kc * MT + m) * 2 + 0) * 1024);
                 const h16x8 al = *reinterpret_cast<const h16x8 *>(wb + ((kc * MT + m) * 2 + 1) * 1024);
+#ifdef MVIP_EXPERIMENT_GEMM
+                if (a.dbg & 2) { acc[m][0][0] += (float)ah[0] + (float)bh[0][0] + (float)bl[1][0] + (float)al[0] + (float)bh[1][0] + (float)bl[0][0]; continue; }
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[m][j], 0, 0, 0);
@@ -467,6 +473,14 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
         }
     }
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+#ifdef MVIP_EXPERIMENT_GEMM
+    if (a.dbg & 1) {
+        float t = 0.f;
+        for (int m = 0; m < MT; ++m) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[m][j][r];
+        if (t == 123.456f) a.y[0] = t;
+        return;
+    }
+#endif
     if (MT == 2 && a.geglu_L > 0) {
         // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
         // two row tiles; the [N][8C][P] intermediate never exists
@@ -787,6 +801,9 @@ extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const flo
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
     a.geglu_L = 0; a.absmax_bits = nullptr;
+#ifdef MVIP_EXPERIMENT_GEMM
+    a.dbg = cfg >> 8; cfg &= 255;
+#endif
     hipStream_t st = as_stream(stream);
     if (cfg == 0) {
         // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
