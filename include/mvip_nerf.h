@@ -310,7 +310,8 @@ int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, c
  *   out    : fp32 [N][heads*D][LqP], columns < Lq written;
  *   out[n, h*D + d, i] = sum_j softmax_j(softmax_scale q_i . k_j)[j < Lk] v_j[d].
  *   D in {40, 80, 160} (mvip_attention_supported), Lq % 32 == 0, LkP % 64 == 0, LkP >= Lk.
- *   flags bit 0: 64-key LDS tiles for D = 40 (tuning switch; same results).
+ *   flags (tuning switches, same results): bit 0 = 64-key LDS tiles for D = 40, bit 1 = never use the 256-query
+ *   workgroup.
  * mvip_attention_pack_v: v[n*sn + (h*DP + d)*sr + key*sk], d < D <= DP, key < Lk -> A fragments whose k order
  *   is the accumulator-row order of the score tile (so the probabilities feed the second product from
  *   registers), zero padded to LkP.

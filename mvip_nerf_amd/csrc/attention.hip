@@ -24,7 +24,7 @@
 //          k = keys in the permuted order above, zero beyond Lk.
 //   out  : fp32 channel-major [N][heads*D][LqP] (what the output projection's split-plane writer reads).
 //
-// Workgroup = 4 waves = 128 queries of one (sample, head); each wave owns 32 queries for the whole key loop.
+// Workgroup = 4 (or 8) waves = 128 (256) queries of one (sample, head); each wave owns 32 queries for the whole key loop.
 // K / V tiles of KT keys are staged through LDS by DMA (global_load_lds), double-buffered, one barrier per
 // tile; 124 registers and 28 KB of LDS for the 40-channel heads (32-key tiles) so that four waves share a SIMD and
 // one wave's softmax (VALU) runs under the others' MFMAs.
@@ -52,8 +52,12 @@ struct AttnArgs {
 
 constexpr float P_SHIFT = 10.0f;          // probabilities travel as p * 2^10 so that their fp16 lo terms stay normal
 
-template <int NCH, int DT, int KT>
-__global__ void __launch_bounds__(256, (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 5 ? 2 : 1))) attn_f16x3_kernel(const AttnArgs a) {
+// NW waves per workgroup = NW * 32 queries sharing every K / V tile: the tiles arrive by LDS-DMA, whose rate per CU
+// (11-13 B/clk, MI355X_MICROARCH.md) is what bounds this kernel at 128 queries per workgroup (14 KB of operands per
+// 21 MFMAs per wave = 21 B/clk/CU at full matrix rate); 256 queries halve the bytes per FLOP.
+template <int NCH, int DT, int KT, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 5 ? 2 : 1))))
+attn_f16x3_kernel(const AttnArgs a) {
     constexpr int KB = NCH * 4 * KT * 16;                 // K tile bytes: [NCH][kg][hl][KT][16 B]
     constexpr int VB = DT * (KT / 16) * 2 * 1024;         // V tile bytes: [DT][KT/16][hl][64][16 B]
     constexpr int NKP = NCH * 4 * KT / 64;                // 1-KiB DMA pieces of a K tile
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(256, (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 
     const int QC = a.heads * NCH;
 
     // ---- Q fragments of this wave's 32 queries (B operands), kept in registers for the whole key loop ----
-    int q = qb * 128 + wave * 32 + l32;
+    int q = qb * (NW * 32) + wave * 32 + l32;
     const bool q_ok = q < a.Lq;
     if (!q_ok) q = a.Lq - 1;
     h16x8 qh[NCH], ql[NCH];
@@ -90,7 +94,7 @@ __global__ void __launch_bounds__(256, (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 
         char *kd = lds + buf * (KB + VB), *vd = kd + KB;
         const int k0 = t * KT;
 #pragma unroll
-        for (int p0 = 0; p0 < NKP; p0 += 4) {
+        for (int p0 = 0; p0 < NKP; p0 += NW) {
             const int p = p0 + wave;
             if (p < NKP) {
                 if (KT == 64) {            // piece = (chunk, kg, hl): 64 keys x 16 B, contiguous in the plane
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(256, (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 
             }
         }
 #pragma unroll
-        for (int p0 = 0; p0 < NVP; p0 += 4) {
+        for (int p0 = 0; p0 < NVP; p0 += NW) {
             const int p = p0 + wave;
             if (p < NVP) {
                 const int dt = p / ((KT / 16) * 2), r = p % ((KT / 16) * 2);
@@ -345,12 +349,16 @@ extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *
     a.qs = (const char *)qs; a.ks = (const char *)ks; a.vp = (const char *)vp;
     a.q_scale2 = q_scale2; a.k_scale2 = k_scale2; a.v_scale2 = v_scale2; a.o = out;
     a.N = (int)N; a.heads = (int)heads; a.Lq = (int)Lq; a.LqP = (int)LqP; a.Lk = (int)Lk; a.LkP = (int)LkP; a.D = (int)D;
-    a.qblocks = (int)((Lq + 127) / 128);
+    // 256 queries per workgroup (8 waves) once that still gives every CU a workgroup; flags bit 1 forces 128
+    const bool wide = D == 40 && !(flags & 2) && N * heads * ((Lq + 255) / 256) >= 256;
+    a.qblocks = (int)(wide ? (Lq + 255) / 256 : (Lq + 127) / 128);
     a.softmax_scale = softmax_scale;
     const int64_t blocks = N * heads * a.qblocks;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (D == 40 && (flags & 1))          // tuning switch: 64-key tiles (two workgroups per CU) instead of 32-key tiles (four)
+    if (wide)
+        hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+    else if (D == 40 && (flags & 1))          // tuning switch: 64-key tiles (two workgroups per CU) instead of 32-key tiles (four)
         hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 64>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else if (D == 40)
         hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32>), dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -19,7 +19,8 @@ import torch.nn.functional as F
 # Which layers take the hand-written split-precision kernels (csrc/conv3x3.hip) instead of the library ones;
 # switches exist for A/B timing (tools/sds_bench.py), every combination computes the same function.
 USE_MFMA_CONV3X3 = True
-USE_MFMA_CONV1X1 = False      # measured slower than the library at these small K (A/B: +4 ms per step)
+USE_MFMA_CONV1X1 = True       # 1x1 shortcut convolutions on the split-precision GEMM: +0.2 ms per UNet forward against the
+                              # library's GEMM-based 1x1 path (tools/attn_bench.py), kept on so that no library GEMM runs in the step
 USE_MFMA_VAE_ATTENTION = True
 USE_HIP_TRANSFORMER = True    # UNet transformer blocks on csrc/attention.hip + csrc/transformer.hip (guidance/transformer_cm.py)
 USE_HIP_TIME_LINEARS = True   # timestep-embedding MLP and the ResNet blocks' time projections on mvip_linear_small

@@ -89,7 +89,13 @@ def test_attention_full_size_level(cuda):
     qs = ops.split_planes_strided(qd, Nb, R, L, R * L, L, 1, sq)
     ks = ops.split_planes_strided(kd, Nb, R, L, R * L, L, 1, sk)
     vp = ops.attention_pack_v(vd, Nb, heads, D, DP, L, L, R * L, L, 1, sv)
-    out = ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, L, L, L, L)
+    out = ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, L, L, L, L)      # 256-query workgroups (8 waves)
+    ops.ATTENTION_FLAGS = 2
+    try:
+        narrow = ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, L, L, L, L)   # 128-query workgroups
+    finally:
+        ops.ATTENTION_FLAGS = 0
+    assert torch.equal(out, narrow)              # the workgroup shape changes no arithmetic
     rows = torch.arange(0, L, 37)
     s = torch.einsum('nhdi,nhdj->nhij', q[..., rows].double(), k.double()) * D ** -0.5
     ref = torch.einsum('nhij,nhdj->nhdi', torch.softmax(s, -1), v.double()).reshape(Nb, heads * D, -1)
@@ -209,7 +215,7 @@ def test_unet_forward_has_no_library_attention_or_gemm(cuda):
     np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-4 * float(ref.abs().max()))
     names = [e.key for e in prof.key_averages()]
     assert any('attn_f16x3_kernel' in n for n in names)
-    assert not [n for n in names if 'attn_fwd' in n or 'Cijk_Alik' in n], names        # no library attention, no hipBLASLt linear
+    assert not [n for n in names if 'attn_fwd' in n or 'Cijk_' in n], names        # no library attention, no library GEMM
 
 
 @pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4])

@@ -40,7 +40,7 @@ def main():
         vp = ops.attention_pack_v(v, Nb, heads, D, DP, Lk, LkP, R * LkP, LkP, 1, sv)
         o = torch.empty(Nb, heads * D, L, device=dev)
         flops = 4.0 * Nb * heads * L * Lk * D
-        for flags in ((0, 1) if D == 40 else (0,)):
+        for flags in ((0, 2, 3) if D == 40 else (0,)):
             ops.ATTENTION_FLAGS = flags
             ms = timed(lambda: ops.attention_f16x3(qs, ks, vp, sq, sk, sv, Nb, heads, D, L, L, Lk, LkP, out=o))
             out[f'attn_D{D}_L{L}_Lk{Lk}_flags{flags}'] = {'ms': round(ms, 4), 'TFLOPs_fp32_equiv': round(flops / ms / 1e9, 1)}
