@@ -248,7 +248,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)       # RCCL over xGMI
+            import datetime
+            dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=300))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
 
@@ -291,252 +292,280 @@ def main():
                    'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
                    'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
     }
-    # ---- extra leg: the reference's second model (hash grid + tiny MLPs, the shipped config's `no_tcnn = False`),
-    # same frames / same training iteration; SURVEY.md 8(f) row 4
-    if args.hashgrid:
-        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
-        a_h = make_args()
-        a_h.no_tcnn, a_h.netchunk, a_h.lrate = False, 1 << 20, 1e-2
-        scene_h = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
-        tr_h = SecondStageTrainer(a_h, scene_h, device, guidance=None, world=world, rank=rank, dist=dist)
+    # The further legs exercise collectives (sharded training iteration, view-sharded SDS terms).  With more than one
+    # rank they run under a deadline and a guard, so that the headline line above is printed even if one of them fails
+    # or stalls on a machine this code has not been run on (RCCL paths cannot be exercised on the 1-GPU build boxes).
+    def finish(code=None):
+        if rank == 0:
+            result['roofline'] = kernel_roofline(run, te, device) if code is None else result.get('roofline')
+            if code is None and world == 1 and not args.no_cpu_baseline:
+                result['cpu_baseline'] = cpu_baseline(args.cpu_warmup, args.cpu_reps,
+                                                      sds_flops_full=result.get('sds', {}).get('roofline', {}).get('flops_per_step'))
+            print(json.dumps(result), flush=True)
+        if code is not None:
+            os._exit(code)
 
-        def render_h(k):
-            with torch.no_grad():
-                return run.render(H, W, FOCAL, chunk=1 << 15, c2w=orbit_pose(rank * 7 + k, device), near=NEAR, far=FAR,
-                                  **tr_h.kw_test)
-        render_h(0)
-        barrier()
-        th = time.perf_counter()
-        for k in range(args.steps):
-            render_h(k + 1)
-        barrier()
-        dt_h = time.perf_counter() - th
-        tr_h.step(0)
-        barrier()
-        th = time.perf_counter()
-        for k in range(args.train_steps):
-            tr_h.step(1 + k)
-        barrier()
-        dt_ht = time.perf_counter() - th
-        if dist is not None:
-            t = torch.tensor([dt_h, dt_ht], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_h, dt_ht = float(t[0]), float(t[1])
-        result['hashgrid_model'] = {
-            'render_rays_per_sec': H * W * world * args.steps / dt_h, 'render_ms_per_frame': dt_h / args.steps * 1e3,
-            'train_ms_per_step': dt_ht / max(args.train_steps, 1) * 1e3,
-            'what': 'NeRF_TCNN (16-level hash grid + 64-wide MLPs, coarse+fine), same frames and same training '
-                    'iteration as the 8x256 legs; renders through the fused gather + fp32-MFMA kernel '
-                    '(csrc/hashgrid_fused.hip); parity unpinned (tiny-cuda-nn absent)'}
-        del tr_h
+    def on_deadline(signum, frame):
+        result['extra_legs_error'] = 'deadline: a multi-rank leg did not finish; legs reported so far are complete'
+        finish(3)
 
-    # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on
-    #      hi/lo splits of both operands, fp32 accumulate).  Reported separately; `value` stays exact fp32. ----
-    with torch.no_grad():
-        ref_img = step(0)
-        for net in (te['network_fn'], te['network_fine']):
-            net.inference_precision = 1
-        fast_img = step(0)
-        barrier()
-        tf = time.perf_counter()
-        for k in range(args.steps):
-            step(args.warmup + k)
-        barrier()
-        dt_fast = time.perf_counter() - tf
-        for net in (te['network_fn'], te['network_fine']):
-            net.inference_precision = 0
-    if dist is not None:
-        t = torch.tensor([dt_fast], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_fast = float(t.item())
-    mse_fast = float(((fast_img - ref_img) ** 2).mean())
-    result['render_f16x3'] = {
-        'rays_per_sec': rays_per_step * args.steps / dt_fast, 'ms_per_step': dt_fast / args.steps * 1e3,
-        'dtype': 'f16x3 (fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate)',
-        'psnr_vs_f32_render_dB': -10 * math.log10(max(mse_fast, 1e-30)),
-        'max_abs_pixel_diff': float((fast_img - ref_img).abs().max())}
+    def extra_legs():
+        # ---- extra leg: the reference's second model (hash grid + tiny MLPs, the shipped config's `no_tcnn = False`),
+        # same frames / same training iteration; SURVEY.md 8(f) row 4
+        if args.hashgrid:
+            from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+            a_h = make_args()
+            a_h.no_tcnn, a_h.netchunk, a_h.lrate = False, 1 << 20, 1e-2
+            scene_h = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+            tr_h = SecondStageTrainer(a_h, scene_h, device, guidance=None, world=world, rank=rank, dist=dist)
 
-    # ---- second leg: the training iteration (masked render + 2 supervision batches, fwd+bwd+Adam) ----
-    if args.train_steps > 0:
-        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
-        torch.manual_seed(1)
-        scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
-        trainer = SecondStageTrainer(make_args(), scene, device, guidance=None, world=world, rank=rank, dist=dist)
-        trainer.step(0)
-        barrier()
-        t1 = time.perf_counter()
-        n_rays = 0
-        for k in range(args.train_steps):
-            _, nr = trainer.step(1 + k)
-            n_rays += nr
-        barrier()
-        dt_tr = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([dt_tr], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_tr = float(t.item())
-        # the same iteration with the split-precision kernels (train_precision = 1: f16x3 forward, delta and
-        # weight-gradient kernels; same stash, same atomics, fp32 accumulation everywhere)
-        for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
-            n.train_precision = 1
-        trainer.step(100)
-        barrier()
-        t1b = time.perf_counter()
-        for k in range(args.train_steps):
-            trainer.step(101 + k)
-        barrier()
-        dt_tr16 = time.perf_counter() - t1b
-        for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
-            n.train_precision = 0
-        if dist is not None:
-            t = torch.tensor([dt_tr16], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_tr16 = float(t.item())
-        result['train_f16x3'] = {'rays_per_sec': n_rays * world / dt_tr16, 'ms_per_step': dt_tr16 / args.train_steps * 1e3,
-                                 'what': 'the same iteration with train_precision=1 (split-precision MFMA kernels)'}
-        result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
-                           'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
-                           'what': 'second-stage iteration without the diffusion prior: masked-set render '
-                                   '(11,544 rays) + 1024 colour rays + 1024 depth rays, losses, backward through '
-                                   'both MLPs, gradient all-reduce, Adam'}
-    # ---- third leg: the diffusion prior (BASELINE configs[1]: RGB SDS only) ----
-    if args.sds_steps > 0:
-        import types
-        from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
-        from mvip_nerf_amd.nerf.utils import Pretrain_Model
-        from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
-        sd = StableDiffusion(device, False, False)                  # SD-1.5-inpaint shapes, random weights, fp32
-        g2 = torch.Generator(device=device).manual_seed(2)
-        pred = torch.rand(1, 3, H, W, device=device, generator=g2).requires_grad_(True)
-        mask = torch.zeros(1, 1, H, W, device=device)
-        mask[:, :, (H - 104) // 2:(H - 104) // 2 + 104, (W - 111) // 2:(W - 111) // 2 + 111] = 1
-
-        def sds_step(i):
-            pred.grad = None
-            (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
-        sds_step(1000)
-        barrier()
-        sds_times = []                        # per-step timing: the leg reports the MEDIAN step (a library
-        for k in range(args.sds_steps):       # autotune or allocator hiccup in one step was seen to cost 600 ms)
-            t2 = time.perf_counter()
-            sds_step(1000 + k)
+            def render_h(k):
+                with torch.no_grad():
+                    return run.render(H, W, FOCAL, chunk=1 << 15, c2w=orbit_pose(rank * 7 + k, device), near=NEAR, far=FAR,
+                                      **tr_h.kw_test)
+            render_h(0)
             barrier()
-            sds_times.append(time.perf_counter() - t2)
-        dt_sds = float(np.median(sds_times)) * args.sds_steps
-
-        # the same step replayed as ONE captured hipGraph (fp32), and the reference's --fp16 mode replayed the same way
-        def graphed_ms(sd_g, scale):
-            sd_g.use_graphs = True
-            pg = pred.detach().clone().requires_grad_(True)
-
-            def one(i):
-                pg.grad = None
-                (scale * sd_g.train_step_sd(i, mask, 'a stone bench in a park', pg, guidance_scale=7.5)).sum().backward()
-            one(1000)
-            one(1001)
+            th = time.perf_counter()
+            for k in range(args.steps):
+                render_h(k + 1)
             barrier()
-            ts = []
-            for k in range(max(args.sds_steps, 3)):
-                tg = time.perf_counter()
-                one(1002 + k)
-                barrier()
-                ts.append(time.perf_counter() - tg)
-            sd_g.use_graphs = False
-            return float(np.median(ts)) * 1e3
-        ms_graph32 = ms_graph16 = None
-        if world == 1:       # per-GPU numbers; not captured next to a live RCCL communicator (its watchdog thread may
-            try:             # touch the device during a global-mode capture)
-                ms_graph32 = graphed_ms(sd, 1e-4)
-                sd16 = StableDiffusion(device, True, False)
-                ms_graph16 = graphed_ms(sd16, 1.0)
-                del sd16
-            except Exception as e:                            # reported, never fatal for the bench line
-                print(f'[bench] hipGraph leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
-            torch.cuda.empty_cache()
-        opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
-                                    text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
-                                    colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
-                                    lambda_guidance=1)
-        scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
-        full = SecondStageTrainer(make_args(), scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}),
-                                  world=world, rank=rank, dist=dist)
-        full.step(1000)
-        barrier()
-        t3 = time.perf_counter()
-        for k in range(args.sds_steps):
-            full.step(1001 + k)
-        barrier()
-        dt_full = time.perf_counter() - t3
-        for n in (full.kw_train['network_fn'], full.kw_train['network_fine']):
-            n.train_precision = 1
-        full.step(2000)
-        barrier()
-        t4 = time.perf_counter()
-        for k in range(args.sds_steps):
-            full.step(2001 + k)
-        barrier()
-        dt_full16 = time.perf_counter() - t4
-        if dist is not None:
-            t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
-        # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
-        # collaborative SDS over <=5 neighbour views); NeRF kernels in split precision (train_ and inference_precision = 1)
-        for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
-            a2 = make_args()
-            a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
-            opt.is_normal_guidance, opt.is_colla_guidance, opt.normal_start = True, colla, 500
-            opt.text_normal = 'a normal map of a stone bench in a park'
-            tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
-                                     rank=rank, dist=dist)
-            for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
-                n.train_precision = n.inference_precision = 1       # split precision for every NeRF kernel of the step
-            tr2.step(1000)
+            dt_h = time.perf_counter() - th
+            tr_h.step(0)
             barrier()
-            t5 = time.perf_counter()
-            rays = 0
-            for k in range(nsteps):
-                rays += tr2.step(1001 + k)[1]
+            th = time.perf_counter()
+            for k in range(args.train_steps):
+                tr_h.step(1 + k)
             barrier()
-            dt5 = time.perf_counter() - t5
+            dt_ht = time.perf_counter() - th
             if dist is not None:
-                t = torch.tensor([dt5], device=device, dtype=torch.float64)
+                t = torch.tensor([dt_h, dt_ht], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt5 = float(t.item())
-            result[name] = {'ms_per_step': dt5 / nsteps * 1e3, 'rays_with_grad_per_step_per_gpu': rays // nsteps,
-                            'sds_evaluations_per_step': 2 + (5 if colla else 0)}
-            del tr2
-        opt.is_normal_guidance = opt.is_colla_guidance = False
-        result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
-                                          'iterations_per_sec': args.sds_steps / dt_full16,
-                                          'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
-        from mvip_nerf_amd.guidance.flops import sds_step_flops
-        fl = sds_step_flops(512)
-        sds_ms = dt_sds / args.sds_steps * 1e3
-        ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
-        sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
-                    'unet_forward_flops': fl['unet_forward'], 'vae_encoder_forward_flops': fl['vae_encoder_forward'],
-                    'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
-                    'peak': round(PEAK_F16_TFLOPS / 3, 1),
-                    'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / 3 products: the split-precision kernels (3x3 convolutions, GEMMs, '
-                               'attention) carry the step\'s contractions except the strided, 8x8-level and stem convolutions (library fp32)',
-                    'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
-        result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
-                         'dtype': 'f32 tensors; 3x3 convolutions, linear layers and attention on fp16 MFMA in split precision (f16x3, ~1e-6 relative), strided / 8x8 / stem convolutions library fp32',
-                         'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
-                         'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
-                         'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
-                         '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
-        result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
-                                    'iterations_per_sec': args.sds_steps / dt_full,
-                                    'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
-                                            '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}
-    if rank == 0:
-        result['roofline'] = kernel_roofline(run, te, device)
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.cpu_warmup, args.cpu_reps,
-                                                  sds_flops_full=result.get('sds', {}).get('roofline', {}).get('flops_per_step'))
-        print(json.dumps(result), flush=True)
+                dt_h, dt_ht = float(t[0]), float(t[1])
+            result['hashgrid_model'] = {
+                'render_rays_per_sec': H * W * world * args.steps / dt_h, 'render_ms_per_frame': dt_h / args.steps * 1e3,
+                'train_ms_per_step': dt_ht / max(args.train_steps, 1) * 1e3,
+                'what': 'NeRF_TCNN (16-level hash grid + 64-wide MLPs, coarse+fine), same frames and same training '
+                        'iteration as the 8x256 legs; renders through the fused gather + fp32-MFMA kernel '
+                        '(csrc/hashgrid_fused.hip); parity unpinned (tiny-cuda-nn absent)'}
+            del tr_h
+
+        # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on
+        #      hi/lo splits of both operands, fp32 accumulate).  Reported separately; `value` stays exact fp32. ----
+        with torch.no_grad():
+            ref_img = step(0)
+            for net in (te['network_fn'], te['network_fine']):
+                net.inference_precision = 1
+            fast_img = step(0)
+            barrier()
+            tf = time.perf_counter()
+            for k in range(args.steps):
+                step(args.warmup + k)
+            barrier()
+            dt_fast = time.perf_counter() - tf
+            for net in (te['network_fn'], te['network_fine']):
+                net.inference_precision = 0
+        if dist is not None:
+            t = torch.tensor([dt_fast], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_fast = float(t.item())
+        mse_fast = float(((fast_img - ref_img) ** 2).mean())
+        result['render_f16x3'] = {
+            'rays_per_sec': rays_per_step * args.steps / dt_fast, 'ms_per_step': dt_fast / args.steps * 1e3,
+            'dtype': 'f16x3 (fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate)',
+            'psnr_vs_f32_render_dB': -10 * math.log10(max(mse_fast, 1e-30)),
+            'max_abs_pixel_diff': float((fast_img - ref_img).abs().max())}
+
+        # ---- second leg: the training iteration (masked render + 2 supervision batches, fwd+bwd+Adam) ----
+        if args.train_steps > 0:
+            from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+            torch.manual_seed(1)
+            scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+            trainer = SecondStageTrainer(make_args(), scene, device, guidance=None, world=world, rank=rank, dist=dist)
+            trainer.step(0)
+            barrier()
+            t1 = time.perf_counter()
+            n_rays = 0
+            for k in range(args.train_steps):
+                _, nr = trainer.step(1 + k)
+                n_rays += nr
+            barrier()
+            dt_tr = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([dt_tr], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_tr = float(t.item())
+            # the same iteration with the split-precision kernels (train_precision = 1: f16x3 forward, delta and
+            # weight-gradient kernels; same stash, same atomics, fp32 accumulation everywhere)
+            for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
+                n.train_precision = 1
+            trainer.step(100)
+            barrier()
+            t1b = time.perf_counter()
+            for k in range(args.train_steps):
+                trainer.step(101 + k)
+            barrier()
+            dt_tr16 = time.perf_counter() - t1b
+            for n in (trainer.kw_train['network_fn'], trainer.kw_train['network_fine']):
+                n.train_precision = 0
+            if dist is not None:
+                t = torch.tensor([dt_tr16], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_tr16 = float(t.item())
+            result['train_f16x3'] = {'rays_per_sec': n_rays * world / dt_tr16, 'ms_per_step': dt_tr16 / args.train_steps * 1e3,
+                                     'what': 'the same iteration with train_precision=1 (split-precision MFMA kernels)'}
+            result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
+                               'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
+                               'what': 'second-stage iteration without the diffusion prior: masked-set render '
+                                       '(11,544 rays) + 1024 colour rays + 1024 depth rays, losses, backward through '
+                                       'both MLPs, gradient all-reduce, Adam'}
+        # ---- third leg: the diffusion prior (BASELINE configs[1]: RGB SDS only) ----
+        if args.sds_steps > 0:
+            import types
+            from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+            from mvip_nerf_amd.nerf.utils import Pretrain_Model
+            from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
+            sd = StableDiffusion(device, False, False)                  # SD-1.5-inpaint shapes, random weights, fp32
+            g2 = torch.Generator(device=device).manual_seed(2)
+            pred = torch.rand(1, 3, H, W, device=device, generator=g2).requires_grad_(True)
+            mask = torch.zeros(1, 1, H, W, device=device)
+            mask[:, :, (H - 104) // 2:(H - 104) // 2 + 104, (W - 111) // 2:(W - 111) // 2 + 111] = 1
+
+            def sds_step(i):
+                pred.grad = None
+                (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
+            sds_step(1000)
+            barrier()
+            sds_times = []                        # per-step timing: the leg reports the MEDIAN step (a library
+            for k in range(args.sds_steps):       # autotune or allocator hiccup in one step was seen to cost 600 ms)
+                t2 = time.perf_counter()
+                sds_step(1000 + k)
+                barrier()
+                sds_times.append(time.perf_counter() - t2)
+            dt_sds = float(np.median(sds_times)) * args.sds_steps
+
+            # the same step replayed as ONE captured hipGraph (fp32), and the reference's --fp16 mode replayed the same way
+            def graphed_ms(sd_g, scale):
+                sd_g.use_graphs = True
+                pg = pred.detach().clone().requires_grad_(True)
+
+                def one(i):
+                    pg.grad = None
+                    (scale * sd_g.train_step_sd(i, mask, 'a stone bench in a park', pg, guidance_scale=7.5)).sum().backward()
+                one(1000)
+                one(1001)
+                barrier()
+                ts = []
+                for k in range(max(args.sds_steps, 3)):
+                    tg = time.perf_counter()
+                    one(1002 + k)
+                    barrier()
+                    ts.append(time.perf_counter() - tg)
+                sd_g.use_graphs = False
+                return float(np.median(ts)) * 1e3
+            ms_graph32 = ms_graph16 = None
+            if world == 1:       # per-GPU numbers; not captured next to a live RCCL communicator (its watchdog thread may
+                try:             # touch the device during a global-mode capture)
+                    ms_graph32 = graphed_ms(sd, 1e-4)
+                    sd16 = StableDiffusion(device, True, False)
+                    ms_graph16 = graphed_ms(sd16, 1.0)
+                    del sd16
+                except Exception as e:                            # reported, never fatal for the bench line
+                    print(f'[bench] hipGraph leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
+                torch.cuda.empty_cache()
+            opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
+                                        text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
+                                        colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
+                                        lambda_guidance=1)
+            scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+            full = SecondStageTrainer(make_args(), scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}),
+                                      world=world, rank=rank, dist=dist)
+            full.step(1000)
+            barrier()
+            t3 = time.perf_counter()
+            for k in range(args.sds_steps):
+                full.step(1001 + k)
+            barrier()
+            dt_full = time.perf_counter() - t3
+            for n in (full.kw_train['network_fn'], full.kw_train['network_fine']):
+                n.train_precision = 1
+            full.step(2000)
+            barrier()
+            t4 = time.perf_counter()
+            for k in range(args.sds_steps):
+                full.step(2001 + k)
+            barrier()
+            dt_full16 = time.perf_counter() - t4
+            if dist is not None:
+                t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
+            # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
+            # collaborative SDS over <=5 neighbour views); NeRF kernels in split precision (train_ and inference_precision = 1)
+            for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
+                a2 = make_args()
+                a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
+                opt.is_normal_guidance, opt.is_colla_guidance, opt.normal_start = True, colla, 500
+                opt.text_normal = 'a normal map of a stone bench in a park'
+                tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
+                                         rank=rank, dist=dist)
+                for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
+                    n.train_precision = n.inference_precision = 1       # split precision for every NeRF kernel of the step
+                tr2.step(1000)
+                barrier()
+                t5 = time.perf_counter()
+                rays = 0
+                for k in range(nsteps):
+                    rays += tr2.step(1001 + k)[1]
+                barrier()
+                dt5 = time.perf_counter() - t5
+                if dist is not None:
+                    t = torch.tensor([dt5], device=device, dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt5 = float(t.item())
+                result[name] = {'ms_per_step': dt5 / nsteps * 1e3, 'rays_with_grad_per_step_per_gpu': rays // nsteps,
+                                'sds_evaluations_per_step': 2 + (5 if colla else 0)}
+                del tr2
+            opt.is_normal_guidance = opt.is_colla_guidance = False
+            result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
+                                              'iterations_per_sec': args.sds_steps / dt_full16,
+                                              'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
+            from mvip_nerf_amd.guidance.flops import sds_step_flops
+            fl = sds_step_flops(512)
+            sds_ms = dt_sds / args.sds_steps * 1e3
+            ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
+            sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
+                        'unet_forward_flops': fl['unet_forward'], 'vae_encoder_forward_flops': fl['vae_encoder_forward'],
+                        'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
+                        'peak': round(PEAK_F16_TFLOPS / 3, 1),
+                        'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / 3 products: the split-precision kernels (3x3 convolutions, GEMMs, '
+                                   'attention) carry the step\'s contractions except the strided, 8x8-level and stem convolutions (library fp32)',
+                        'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
+            result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
+                             'dtype': 'f32 tensors; 3x3 convolutions, linear layers and attention on fp16 MFMA in split precision (f16x3, ~1e-6 relative), strided / 8x8 / stem convolutions library fp32',
+                             'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
+                             'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
+                             'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
+                             '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
+            result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
+                                        'iterations_per_sec': args.sds_steps / dt_full,
+                                        'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
+                                                '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}
+
+    if world > 1:
+        import signal
+        signal.signal(signal.SIGALRM, on_deadline)
+        signal.alarm(int(os.environ.get('MVIP_BENCH_EXTRA_DEADLINE_S', 1200)))
+    try:
+        extra_legs()
+    except Exception as e:
+        if world == 1:
+            raise
+        result['extra_legs_error'] = f'{type(e).__name__}: {e}'
+        print(f'[bench] rank {rank}: extra legs stopped: {type(e).__name__}: {e}', file=sys.stderr, flush=True)
+        finish(4)                      # the other ranks may be waiting in a collective: leave without joining them
+    if world > 1:
+        signal.alarm(0)
+    finish()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
