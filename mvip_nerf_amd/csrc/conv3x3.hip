@@ -21,6 +21,7 @@
 //     and the input tile double-buffered in LDS, one barrier per stage.
 //   * epilogue: x 1/scale, + bias, + per-(sample, channel) addend (time embedding), + residual, NCHW fp32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mvip {
 
@@ -29,9 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CV_TH = 8, CV_TW = 32;
 constexpr int CV_HW = CV_TW + 2;                    // haloed tile width
-constexpr int CV_PIX = (CV_TH + 2) * CV_HW;         // 340 haloed pixels
-constexpr int CV_IN_ROUNDS = 6;                     // 4 planes x 340 = 1360 slots in 6 rounds of 256 lanes (last one partial)
-constexpr int CV_IN_BYTES = 4 * CV_PIX * 16;        // 21,760 B
+constexpr int CV_PIX = (CV_TH + 2) * CV_HW;         // 340 haloed pixels of the 8 x 32 tile (4 planes x 340 slots = 21,760 B)
 
 __device__ __forceinline__ void glds16b(const void *src_lane, void *dst_wave) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
@@ -212,10 +211,16 @@ struct ConvArgs {
 // reads, waits and epilogue run under the other wave's MFMAs.
 // TW = 32: pixel tile 8 rows x 32 columns, an MFMA column block (32 pixels) = one image row of the tile.
 // TW = 16 (images narrower than 32 pixels: the UNet's 16x16 level): tile 16 x 16, a column block = two rows of 16.
-template <int MT, int TW = CV_TW>
-__global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(const ConvArgs a) {
-    constexpr int TH = 256 / TW, HW = TW + 2, PIX = (TH + 2) * HW, RPB = 32 / TW;    // RPB: image rows per column block
-    static_assert(PIX <= CV_PIX, "haloed tile must fit the input buffers");
+// NW = 8 (TW = 32 only, opt-in): a workgroup of eight waves owns a 16 x 32 pixel tile, so the weights of a stage and
+// the haloed input tile are shared by twice the MFMAs (10.9 instead of 16.8 B/clk/CU of LDS-DMA at full matrix rate for
+// MT = 2).  Built to test whether operand delivery bounds this kernel as it bounds the plain GEMM and the attention
+// kernel: it does not -- both shapes run the VAE / UNet convolutions in the same time (round 2, tools/conv_wide_ab.py).
+template <int MT, int TW = CV_TW, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int TH = NT / TW, HW = TW + 2, PIX = (TH + 2) * HW, RPB = 32 / TW;    // RPB: image rows per column block
+    constexpr int CV_IN_BYTES = 4 * PIX * 16;          // shadows the 8 x 32 constants: sized for this tile
+    constexpr int CV_IN_ROUNDS = (4 * PIX + NT - 1) / NT;
     constexpr int WB = 3 * MT * 2 * 1024;              // weights of one stage (kernel row, 16 channels)
     __shared__ __attribute__((aligned(16))) char lds[3 * WB + 2 * CV_IN_BYTES];
     char *lds_w = lds, *lds_in = lds + 3 * WB;
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
     int in_off[CV_IN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < CV_IN_ROUNDS; ++r) {
-        const int s = r * 256 + tid;
+        const int s = r * NT + tid;
         in_off[r] = s < 4 * PIX ? -1 : -2;             // -1: halo outside the image (zero page), -2: no slot
         if (s < 4 * PIX) {
             const int piece = s / PIX, p = s - piece * PIX;
@@ -258,13 +263,13 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) conv3x3_f16x3_kernel(c
         char *dst = lds_in + buf * CV_IN_BYTES + wave * 1024;
 #pragma unroll
         for (int r = 0; r < CV_IN_ROUNDS; ++r)
-            if (in_off[r] != -2) glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * 4096);
+            if (in_off[r] != -2) glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * (NT * 16));
     };
     auto issue_weights = [&](int t, int buf) {
         const char *src = wp_b + (int64_t)t * WROW + lane * 16;
         char *dst = lds_w + buf * WB;
 #pragma unroll
-        for (int b0 = 0; b0 < 6 * MT; b0 += 4) {        // LDS block b = m*6 + kx*2 + hl
+        for (int b0 = 0; b0 < 6 * MT; b0 += NW) {       // LDS block b = m*6 + kx*2 + hl
             const int b = b0 + wave;
             if (b < 6 * MT) glds16b(src + (int64_t)(b / 6) * a.CK * 3 * WROW + (b % 6) * 1024, dst + b * 1024);
         }
@@ -755,6 +760,23 @@ extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const floa
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(Cin / 16); a.Cout = (int)Cout; a.H = (int)H; a.W = (int)W;
     a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
+    // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
+    // four-wave tile on every VAE / UNet shape and on the whole step, 7.56 vs 7.65 ms -- tools/conv_wide_ab.py)
+    static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
+    if (tw == CV_TW && wide_mode && H % 16 == 0) {
+        const int64_t tiles16 = N * (W / CV_TW) * (H / 16);
+        const int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
+        if (mtw) {
+            a.tilesY = (int)(H / 16); a.MB = (int)(Cout / (32 * mtw));
+            const int64_t wb = tiles16 * a.MB;
+            if (wb > 0x7fffffffLL) return MVIP_EINVAL;
+            if (mtw == 2)
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, as_stream(stream), a);
+            else
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, as_stream(stream), a);
+            return check_launch();
+        }
+    }
     const int64_t blocks = N * a.tilesX * a.tilesY * a.MB;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
     if (tw == 16)

@@ -20,6 +20,7 @@
 // FLOPs: R + B1 + B2 ~= 2.9x the forward.  HBM: ~20 KB/point of stash traffic each way, i.e.
 // ~90 FLOP/B -- still MFMA-bound at fp32 rates.
 #include "common.h"
+#include <stdlib.h>
 #include "mlp_layout.h"
 #include "mlp_device.h"
 #include "mlp_device_f16.h"
@@ -605,9 +606,14 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         } else
             hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
                                act_n_pt, act_pt0, gst, n_pt);
+        // stages (32 points each) per workgroup; every workgroup ends with a flush of its 128 x 256 partial product as
+        // fp32 atomics (512 wave-instructions).  Measured (round 2, tools/wgrad_ab.py): 32 / 64 / 128 / 256 stages give
+        // 63.2 / 62.7 / 62.9 / 62.8 ms per training iteration -- the flush is not what holds this kernel at 0.6 of the
+        // matrix peak.  MVIP_WGRAD_STAGES overrides (tuning).
+        static const int sps_cap = [] { const char *e = getenv("MVIP_WGRAD_STAGES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
         int sps = (int)((n_pt + 63) / 64);
         if (sps < 1) sps = 1;
-        if (sps > 32) sps = 32;
+        if (sps > sps_cap) sps = sps_cap;
         const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), N_PRODUCTS);
         if (precision == 1)
             hipLaunchKernelGGL(mlp_wgrad_kernel<1>, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
