@@ -36,3 +36,47 @@ def bench_like_rays(n, seed, near=1.2, far=7.74):
     v = d / np.linalg.norm(d, axis=-1, keepdims=True)
     rows = np.concatenate([o, d, np.full((n, 1), near), np.full((n, 1), far), v], -1)
     return rows.astype(np.float32)
+
+
+def seeded_clip_text_state(seed, vocab=49408, d=768, layers=12, ctx=77):
+    """State dict of the CLIP ViT-L/14 TEXT tower in `mvip_nerf_amd.guidance.sd_nets.CLIPTextModel`'s key names
+    (fp32 numpy, deterministic in `seed`): N(0, 0.02) matrices and embeddings, LayerNorm gains 1 + N(0, 0.1),
+    biases N(0, 0.02) -- non-trivial everywhere so a wrong mapping or a missing bias shows up."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def mat(name, *shape):
+        sd[name] = (rs.standard_normal(size=shape) * 0.02).astype(np.float32)
+
+    def ln(name):
+        sd[name + '.weight'] = (1.0 + 0.1 * rs.standard_normal(size=(d,))).astype(np.float32)
+        sd[name + '.bias'] = (0.02 * rs.standard_normal(size=(d,))).astype(np.float32)
+    mat('token_embedding.weight', vocab, d)
+    mat('position_embedding.weight', ctx, d)
+    for i in range(layers):
+        ln(f'layers.{i}.layer_norm1')
+        ln(f'layers.{i}.layer_norm2')
+        for p in ('q_proj', 'k_proj', 'v_proj', 'out_proj'):
+            mat(f'layers.{i}.{p}.weight', d, d)
+            mat(f'layers.{i}.{p}.bias', d)
+        mat(f'layers.{i}.fc1.weight', 4 * d, d)
+        mat(f'layers.{i}.fc1.bias', 4 * d)
+        mat(f'layers.{i}.fc2.weight', d, 4 * d)
+        mat(f'layers.{i}.fc2.bias', d)
+    ln('final_layer_norm')
+    return sd
+
+
+def clip_key_to_transformers(k):
+    """Our CLIPTextModel key -> the key of transformers' CLIPTextModel (what the reference instantiates,
+    DS_NeRF/guidance/sd_utils.py:69-74 through the diffusers pipeline)."""
+    if k.startswith(('token_embedding', 'position_embedding')):
+        return 'embeddings.' + k
+    if k.startswith('final_layer_norm'):
+        return k
+    _, i, rest = k.split('.', 2)
+    if rest.startswith(('q_proj', 'k_proj', 'v_proj', 'out_proj')):
+        return f'encoder.layers.{i}.self_attn.{rest}'
+    if rest.startswith(('fc1', 'fc2')):
+        return f'encoder.layers.{i}.mlp.{rest}'
+    return f'encoder.layers.{i}.{rest}'

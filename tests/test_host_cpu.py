@@ -114,3 +114,18 @@ def test_bench_launcher_spawns_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3'], env=dict(env, WORLD_SIZE='2', RANK='0'),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr
+
+
+def test_clip_text_tower_matches_transformers(golden):
+    """The prompt encoder body against the library class the reference instantiates (transformers' CLIPTextModel,
+    seeded weights, fixture from oracle/gen_golden_clip.py): same key mapping, causal mask, quick-GELU, final norm."""
+    import numpy as np
+    import torch
+    from mvip_nerf_amd.guidance.sd_nets import CLIPTextModel
+    from oracle.weights import seeded_clip_text_state
+    g = golden('clip_text')
+    m = CLIPTextModel().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_clip_text_state(int(g['seed'])).items()})
+    with torch.no_grad():
+        out = m(torch.from_numpy(g['ids']))
+    np.testing.assert_allclose(out.numpy(), g['last_hidden_state'], rtol=0, atol=2e-5 * float(np.abs(g['last_hidden_state']).max()))
