@@ -56,8 +56,21 @@ class TinyVAE(nn.Module):
                 p.copy_(_seeded(tuple(p.shape), seed + k, 0.3 / np.sqrt(max(p[0].numel(), 1))))
         self.randn = torch.randn          # replaced by tests to replay recorded draws
 
+    @staticmethod
+    def _patch_conv(conv, x):
+        """conv (kernel == stride, no padding) as pixel_unshuffle + channel contraction: the same arithmetic without
+        the convolution library.  Used on the GPU, where MIOpen's backward-data solver for these unusual stride-4 /
+        stride-2 stand-in layers faulted once the library's tuning database had seen the full-size VAE."""
+        r = conv.stride[0]
+        w = conv.weight.reshape(conv.out_channels, -1)
+        return torch.einsum('ok,bkhw->bohw', w, F.pixel_unshuffle(x, r)) + conv.bias[None, :, None, None]
+
     def encode(self, x):
-        return EncOut(DiagGaussian(self.c2(torch.tanh(self.c1(x))), lambda s: self.randn(s)))
+        if x.is_cuda:
+            h = self._patch_conv(self.c2, torch.tanh(self._patch_conv(self.c1, x)))
+        else:
+            h = self.c2(torch.tanh(self.c1(x)))
+        return EncOut(DiagGaussian(h, lambda s: self.randn(s)))
 
     def decode(self, z, return_dict=False):
         return (F.interpolate(self.d(z), scale_factor=8),)
