@@ -248,7 +248,9 @@ int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G,
  * Weights are packed once per layer by mvip_conv3x3_pack into mvip_conv3x3_packed_bytes(Cout, Cin)
  * bytes; transpose = 1 packs the data-gradient operator (then the conv maps dY [N,Cout,H,W] -> dX
  * [N,Cin,H,W]: call mvip_conv3x3_f16x3 with Cin and Cout swapped).
- * scale2 = {s, 1/s, scratch, scratch} (device, 16 bytes): power-of-two scale from the absolute maximum.
+ * scale2 = {s, 1/s, scratch, scratch} (device, 16 bytes): power-of-two scale from the absolute maximum
+ * (mvip_absmax_scale; zero_words2 nullable: two caller-owned 32-bit scratch words, zero on entry and on exit, make it
+ * ONE launch -- maximum by atomics, the last workgroup writes the scale -- instead of zero + reduce + scale).
  *   y[n,co,h,w] = conv(x, W)[n,co,h,w] / (s_w s_x) + bias[co] + chan_add[n,co] + residual[n,co,h,w]
  * (bias, chan_add, residual, x_scale2 may be NULL).  Supported: Cout % 32 == 0, Cin % 16 == 0,
  * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0) (mvip_conv3x3_supported); anything else returns
@@ -256,7 +258,7 @@ int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G,
 int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W);
 int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
 int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
-int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *stream);
+int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *zero_words2, void *stream);
 int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
                       void *stream);
 int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
@@ -316,7 +318,8 @@ int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, c
  *   is the accumulator-row order of the score tile (so the probabilities feed the second product from
  *   registers), zero padded to LkP.
  * mvip_absmax_scale_sections: x [outer][sections][len] -> scale2[s] = {2^k, 2^-k, -, -} per section
- *   (|x|max 2^k in [2^9, 2^10)), sections <= 64; one launch for the q / k / v thirds of a fused projection.
+ *   (|x|max 2^k in [2^9, 2^10)), sections <= 63; ONE launch for the q / k / v thirds of a fused projection (the last
+ *   workgroup writes the scales).
  *   zero_words64: 64 caller-owned 32-bit scratch words that are ZERO on entry and left zero on exit (allocate
  *   zeroed once per stream; the maxima are collected there with atomics, which saves a zeroing launch per use). */
 int mvip_attention_supported(int64_t D);

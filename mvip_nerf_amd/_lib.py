@@ -68,7 +68,7 @@ _SIGNATURES = {
     'mvip_conv3x3_supported': (_int, [_i64, _i64, _i64, _i64]),
     'mvip_conv3x3_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_conv3x3_pack': (_int, [_c_f, _i64, _i64, _int, _c_f, _c_f]),
-    'mvip_absmax_scale': (_int, [_c_f, _i64, _c_f, _c_f]),
+    'mvip_absmax_scale': (_int, [_c_f, _i64, _c_f, _c_f, _c_f]),
     'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _c_f]),
     'mvip_conv3x3_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),

@@ -250,7 +250,8 @@ attn_pack_v_kernel(const float *__restrict__ v, int heads, int DP, int Lk, int L
 // ---- absolute maxima of several equally long sections at once -> one power-of-two scale per section ----
 // x is [outer][sections][len]; section s collects over every outer index.
 __global__ void __launch_bounds__(256)
-absmax_sections_kernel(const float *__restrict__ x, int64_t outer, int sections, int64_t len, unsigned *__restrict__ bits) {
+absmax_sections_kernel(const float *__restrict__ x, int64_t outer, int sections, int64_t len, unsigned *__restrict__ bits,
+                       float *__restrict__ scale2) {
     const int s = blockIdx.y;
     float m = 0.f;
     auto take = [&](float v) { v = fabsf(v); m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m; };
@@ -272,7 +273,29 @@ absmax_sections_kernel(const float *__restrict__ x, int64_t outer, int sections,
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(bits + s, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    if (threadIdx.x == 0) {
+        atomicMax(bits + s, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+        // the last workgroup of the launch (ticket in bits[63]) turns every section's maximum into its scale and leaves
+        // the scratch words zero for the next user: no separate scale launch
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        if (atomicAdd(bits + 63, 1u) == total - 1) {
+            atomicExch(bits + 63, 0u);
+            for (int q = 0; q < sections; ++q) {
+                const float m2 = __uint_as_float(atomicExch(bits + q, 0u));
+                float sc = 1.f;
+                if (m2 > 0.f && m2 < 3.0e38f) {
+                    int e;
+                    frexpf(m2, &e);
+                    int k = 10 - e;
+                    k = k > 60 ? 60 : (k < -60 ? -60 : k);
+                    sc = ldexpf(1.f, k);
+                }
+                scale2[4 * q] = sc;
+                scale2[4 * q + 1] = 1.f / sc;
+            }
+        }
+    }
 }
 
 // scale2[s] = {2^k, 2^-k, -, -} with |x|max 2^k in [2^9, 2^10)  (same rule as csrc/conv3x3.hip); the maxima were
@@ -323,16 +346,17 @@ extern "C" int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, i
 
 extern "C" int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, int64_t len, float *scale2,
                                           void *zero_words64, void *stream) {
-    if (outer < 0 || sections <= 0 || sections > 64 || len < 0 || !scale2 || !zero_words64) return MVIP_EINVAL;
+    if (outer < 0 || sections <= 0 || sections > 63 || len < 0 || !scale2 || !zero_words64) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     if (outer > 0 && len > 0) {
         if (!x) return MVIP_EINVAL;
         int64_t b = (len + 256 * 32 - 1) / (256 * 32);
         b = b < 1 ? 1 : (b > 256 ? 256 : b);
         hipLaunchKernelGGL(absmax_sections_kernel, dim3((unsigned)b, (unsigned)sections), dim3(256), 0, st, x, outer,
-                           (int)sections, len, (unsigned *)zero_words64);
+                           (int)sections, len, (unsigned *)zero_words64, scale2);
+    } else {
+        hipLaunchKernelGGL(scale_sections_kernel, dim3(1), dim3(64), 0, st, scale2, (unsigned *)zero_words64, (int)sections);
     }
-    hipLaunchKernelGGL(scale_sections_kernel, dim3(1), dim3(64), 0, st, scale2, (unsigned *)zero_words64, (int)sections);
     return check_launch();
 }
 

@@ -73,6 +73,49 @@ __global__ void __launch_bounds__(256) cv_absmax_kernel(const float *__restrict_
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
+// One-launch form: the maxima are collected in words[0] (zero on entry), every workgroup takes a ticket in words[1]
+// (zero on entry) and the LAST one turns the maximum into scale2 = {s, 1/s} and leaves both words zero again.  The two
+// words are caller-owned scratch that travels zero between calls on a stream (saves the zeroing and the scale launch).
+__global__ void __launch_bounds__(256) cv_absmax_scale_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ words,
+                                                             float *__restrict__ scale2) {
+    float m = 0.f;
+    auto take = [&](float v) { v = fabsf(v); m = (v == v && v < 3.0e38f) ? fmaxf(m, v) : m; };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) take(x[i]);
+    } else {
+        for (int64_t i = tid; i < n; i += stride) take(x[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(words, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+        __threadfence();
+        const unsigned ticket = atomicAdd(words + 1, 1u);
+        if (ticket == gridDim.x - 1) {
+            const float mx = __uint_as_float(atomicExch(words, 0u));         // every workgroup's maximum has landed
+            atomicExch(words + 1, 0u);
+            float sc = 1.f;
+            if (mx > 0.f && mx < 3.0e38f) {
+                int e;
+                frexpf(mx, &e);
+                int k = 10 - e;
+                k = k > 60 ? 60 : (k < -60 ? -60 : k);
+                sc = ldexpf(1.f, k);
+            }
+            scale2[0] = sc;
+            scale2[1] = 1.f / sc;
+        }
+    }
+}
+
 static inline unsigned absmax_blocks(int64_t n) {
     int64_t b = (n + 256 * 32 - 1) / (256 * 32);
     return (unsigned)(b < 1 ? 1 : (b > 512 ? 512 : b));
@@ -698,9 +741,14 @@ extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin,
     return check_launch();
 }
 
-extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *stream) {
+extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *zero_words2, void *stream) {
     if (n < 0 || !scale2 || (n > 0 && !x)) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
+    if (zero_words2 && n > 0) {                 // one launch: caller-owned scratch words that are zero between calls
+        hipLaunchKernelGGL(cv_absmax_scale_kernel, dim3(absmax_blocks(n)), dim3(256), 0, st, x, n, (unsigned *)zero_words2,
+                           scale2);
+        return check_launch();
+    }
     zero_words(scale2, 4, st);
     if (n > 0) hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(n)), dim3(256), 0, st, x, n, (unsigned *)(scale2 + 2));
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(scale2 + 2), scale2);

@@ -107,6 +107,20 @@ def _packed(mod):
     return pk
 
 
+_UNIT_SECTIONS = {}
+
+
+def _scales(x, outer, sections, length):
+    """Power-of-two scales of the q / k / v sections: 1 for every section when the UNet's forward activations are
+    split at a fixed scale (ops.FORWARD_UNIT_SCALE), else measured in one launch."""
+    if ops.FORWARD_UNIT_SCALE:
+        key = (x.device, sections)
+        if key not in _UNIT_SECTIONS:
+            _UNIT_SECTIONS[key] = ops.unit_scale(x.device).repeat(sections)
+        return _UNIT_SECTIONS[key]
+    return ops.absmax_scale_sections(x, outer, sections, length)
+
+
 def _prompt_kv(pk, ctx):
     """Key planes / value fragments of the prompt tokens for the cross-attention (constant per prompt)."""
     key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
@@ -118,9 +132,9 @@ def _prompt_kv(pk, ctx):
     assert T <= TP and E == pk.ctx_dim
     cpad = torch.zeros((N, GP, E), device=ctx.device, dtype=torch.float32)
     cpad[:, :T] = ctx.detach().float()
-    xs, s2 = ops._scaled_planes(cpad, N, E, GP, GP * E, 1, E)                       # X[n][k][p] = ctx[n][p][k]
+    xs, s2 = ops._scaled_planes(cpad, N, E, GP, GP * E, 1, E, forward_activation=True)   # X[n][k][p] = ctx[n][p][k]
     kv = ops.gemm_f16x3(xs, pk.kv2, N, E, 2 * pk.R, GP, x_scale2=s2)                # [N, 2R, GP]
-    sc = ops.absmax_scale_sections(kv, N, 2, pk.R * GP)
+    sc = _scales(kv, N, 2, pk.R * GP)
     flat = kv.reshape(-1)
     ks = ops.split_planes_strided(flat, N, pk.R, TP, 2 * pk.R * GP, GP, 1, sc[0:4])
     vp = ops.attention_pack_v(flat[pk.R * GP:], N, pk.heads, pk.D, pk.DP, T, TP, 2 * pk.R * GP, GP, 1, sc[4:8])
@@ -136,7 +150,7 @@ def _block(h, pk, ctx, N, L, LP):
     g, b, eps, s, st = pk.ln[0]
     xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
     qkv = ops.gemm_f16x3(xs, pk.qkv1, N, C, 3 * R, LP, x_scale2=st)                  # [N, 3R, LP]
-    sc = ops.absmax_scale_sections(qkv, N, 3, R * LP)
+    sc = _scales(qkv, N, 3, R * LP)
     flat = qkv.reshape(-1)
     qs = ops.split_planes_strided(flat, N, R, L, 3 * R * LP, LP, 1, sc[0:4])
     ks = ops.split_planes_strided(flat[R * LP:], N, R, L, 3 * R * LP, LP, 1, sc[4:8])
@@ -148,7 +162,7 @@ def _block(h, pk, ctx, N, L, LP):
     g, b, eps, s, st = pk.ln[1]
     xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
     q = ops.gemm_f16x3(xs, pk.q2, N, C, R, LP, x_scale2=st)
-    sq = ops.absmax_scale_sections(q, 1, 1, N * R * LP)
+    sq = _scales(q, 1, 1, N * R * LP)
     qs = ops.split_planes_strided(q, N, R, L, R * LP, LP, 1, sq)
     ks2, vp2, sk2, sv2, T, TP = _prompt_kv(pk, ctx)
     o = ops.attention_f16x3(qs, ks2, vp2, sq, sk2, sv2, N, heads, D, L, LP, T, TP)
@@ -177,12 +191,12 @@ def transformer2d_forward(mod, x, ctx):
         hn = ops.group_norm(xc, mod.norm.weight, mod.norm.bias, mod.norm.num_groups, mod.norm.eps, False)
         hp = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
         hp[:, :, :L] = hn.reshape(N, C, L)
-        xs, s2 = ops._scaled_planes(hp, N, C, LP, C * LP, LP, 1)
+        xs, s2 = ops._scaled_planes(hp, N, C, LP, C * LP, LP, 1, forward_activation=True)
         h = ops.gemm_f16x3(xs, pk.pin, N, C, C, LP, bias=pk.bin, x_scale2=s2)
         res = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
         res[:, :, :L] = xc.reshape(N, C, L)
     h = _block(h, pk, ctx, N, L, LP)
-    xs, s2 = ops._scaled_planes(h, N, C, LP, C * LP, LP, 1)
+    xs, s2 = ops._scaled_planes(h, N, C, LP, C * LP, LP, 1, forward_activation=True)
     y = ops.gemm_f16x3(xs, pk.pout, N, C, C, LP, bias=pk.bout, residual=res, x_scale2=s2)
     if LP != L:
         y = y[:, :, :L].contiguous()

@@ -182,6 +182,15 @@ def test_transformer2d_hip_path_vs_fp64_module(cuda, C, heads, H, W):
     assert torch.equal(got, again)
     scale = float(ref.abs().max())
     np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=1e-5 * scale)
+    from mvip_nerf_amd import ops
+    assert ops.FORWARD_UNIT_SCALE is False                         # default: measured (magnitude-invariant) scales
+    ops.FORWARD_UNIT_SCALE = True                                  # opt-in: fixed scale 1 for forward activations
+    try:
+        with torch.no_grad():
+            unit = mod(xd, cd)
+    finally:
+        ops.FORWARD_UNIT_SCALE = False
+    np.testing.assert_allclose(N(unit), ref.float().numpy(), rtol=0, atol=1e-5 * scale)   # O(1) activations: same grade
     # a changed weight invalidates the packed images
     with torch.no_grad():
         mod.proj_out.bias.add_(1.0)
