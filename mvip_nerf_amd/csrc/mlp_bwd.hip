@@ -235,7 +235,12 @@ __global__ void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *
 // BSPLIT (used by the f16 path of the 128x256 products): instead of each wave owning NTW gradient
 // tiles x ALL act tiles, each wave owns ALL NTW(=4) gradient tiles x KT(=2) act tiles -- the same
 // 8 accumulator tiles and 24 MFMAs per k-step, but 6 instead of 9 operand conversions.
-template <int NTW, int KT, int PREC = 0, bool BSPLIT = false>
+// EXTRA (0 none, 1 sigma row, 2 rgb rows) is a template parameter: as a run-time field its branches sat inside the
+// point-group loop and cost ~1 VALU move per MFMA in phi copies on every product (PMC, round 2: 2.7 VALU + 2.4 SALU
+// per MFMA against 1.7 + 0.1 in the forward kernel); the per-block source addresses of a stage are hoisted into
+// scalar base pointers (a stage advances every block by the same 4 KB), which removes the 64-bit multiply chain that
+// issue_stage re-ran for each of the 12 blocks of every stage.
+template <int NTW, int KT, int PREC = 0, bool BSPLIT = false, int EXTRA = 0>
 __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act, int64_t act_n_pt,
                                            int64_t act_pt0, const float *__restrict__ gst, int64_t n_pt,
                                            int64_t pt0, int64_t pt1, float *lds, int wave, int lane,
@@ -245,26 +250,34 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     const int a_first = BSPLIT ? 0 : wave * NTW;         // this wave's first gradient tile
     const int b_first = BSPLIT ? wave * KT : 0;          // this wave's first act tile
     const int i = lane & 31, hh = lane >> 5;
-    const int extra = G.extra;
-    const int nextra = extra == 2 ? 5 : (extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
-    const int nblk = NT + KTT + nextra;
+    constexpr int extra = EXTRA;
+    constexpr int nextra = extra == 2 ? 5 : (extra == 1 ? 1 : 0);      // V tiles (4) + d^T tile
+    constexpr int nblk = NT + KTT + nextra;
     const int g_tile0 = G.g_tile0, a0 = G.a_tile0[0], a1 = G.a_tile0[1], ac0 = G.a_count0;
 
     // wave w stages rows 8w..8w+7 of every block of the stage (one LDS-DMA per block and wave)
     const int r = 8 * wave + (lane >> 3), c = lane & 7;
     const int lane_off = r * 32 + ((c ^ ((r >> 1) & 7)) << 2);
+    const float *blk_base[nblk];                                   // wave-uniform: stage pt of block b = base + pt * 4 KB
+#pragma unroll
+    for (int b = 0; b < nblk; ++b) {
+        int tile;
+        bool from_g = false;
+        if (b < NT) { tile = g_tile0 + b; from_g = true; }
+        else if (b < NT + KTT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
+        else if (extra == 2 && b < NT + KTT + 4) tile = AT_V + (b - NT - KTT);
+        else { tile = GT_D; from_g = true; }
+        blk_base[b] = from_g ? gst + (int64_t)tile * n_pt * TILE_FLOATS
+                             : act + ((int64_t)tile * act_n_pt + act_pt0) * TILE_FLOATS;
+    }
     auto issue_stage = [&](int64_t pt, float *dst) {
-        for (int b = 0; b < nblk; ++b) {
-            int tile;
-            bool from_g = false;
-            if (b < NT) { tile = g_tile0 + b; from_g = true; }
-            else if (b < NT + KTT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
-            else if (extra == 2 && b < NT + KTT + 4) tile = AT_V + (b - NT - KTT);
-            else { tile = GT_D; from_g = true; }
-            const float *src = from_g ? gst + ((int64_t)tile * n_pt + pt) * TILE_FLOATS
-                                      : act + ((int64_t)tile * act_n_pt + act_pt0 + pt) * TILE_FLOATS;
-            glds16(src + lane_off, dst + b * TILE_FLOATS + wave * 256);
-        }
+        // scalar base + 32-bit per-lane byte offset (a backward tile spans < 2^32 bytes per stash row): the form the
+        // global_load_lds instruction takes directly (saddr + voffset), no 64-bit vector address per block
+        const unsigned voff = (unsigned)(((unsigned)pt * (unsigned)TILE_FLOATS + (unsigned)lane_off) * 4u);
+#pragma unroll
+        for (int b = 0; b < nblk; ++b)
+            glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff),
+                   dst + b * TILE_FLOATS + wave * 256);
     };
 
     f32x16 acc[NTW][KT];
@@ -411,15 +424,20 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     float *buf0 = lds, *buf1 = lds + W_STAGE_FLOATS;
     issue_stage(pt0, buf0);
     __syncthreads();
-    for (int64_t pt = pt0; pt < pt1; pt += 2) {
-        if (pt + 1 < pt1) issue_stage(pt + 1, buf1);
+    // The loop body is a whole PAIR of stages with its only exit at the bottom, and an odd last stage runs after it:
+    // with an exit between the two stages the accumulators reached the flush from two places and the register
+    // allocator kept two copies of all eight tiles, moving 128 registers from one to the other every stage.
+    const int64_t n_pairs = (pt1 - pt0) >> 1;
+    int64_t pt = pt0;
+    for (int64_t pr = 0; pr < n_pairs; ++pr, pt += 2) {
+        issue_stage(pt + 1, buf1);
         compute(buf0);
         __syncthreads();          // stage pt+1 landed (vmcnt(0)) and everyone is done with buf0
-        if (pt + 1 >= pt1) break;
         if (pt + 2 < pt1) issue_stage(pt + 2, buf0);
         compute(buf1);
         __syncthreads();
     }
+    if (pt < pt1) compute(buf0);
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
 #pragma unroll
@@ -502,13 +520,18 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restric
         gs = __int_as_float((127 + 6 - e) << 23);
         igs = __int_as_float((127 + e - 6) << 23);
     }
-    if (id < 16) {
-        if constexpr (PREC == 1) wgrad_body<4, 2, 1, true>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-        else wgrad_body<1, 8, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    if (id < 16) {                                    // 256 x 256 products; product 14 also carries the sigma row
+        if (G.extra == 1) {
+            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 1>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            else wgrad_body<1, 8, 0, false, 1>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        } else {
+            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            else wgrad_body<1, 8, 0, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        }
     }
-    else if (id < 18) wgrad_body<2, 2, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-    else if (id == 18) wgrad_body<1, 5, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-    else wgrad_body<1, 4, PREC>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else if (id < 18) wgrad_body<2, 2, PREC, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else if (id == 18) wgrad_body<1, 5, PREC, false, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else wgrad_body<1, 4, PREC, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
 }
 
 static_assert(sizeof(Gemm) * N_PRODUCTS <= 1024 * 4 - 16, "table room (+ the absmax word)");

@@ -168,6 +168,47 @@ __device__ __forceinline__ void bitonic_sort(float (&v)[M]) {
     }
 }
 
+// #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
+// +inf): six binary-search steps on cross-lane reads + one probe for the count 64.
+template <bool STRICT>
+__device__ __forceinline__ int count_below(const float key, const float x) {
+    int cnt = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int probe = cnt + step;
+        const float c = __shfl(key, (probe - 1) & 63, 64);
+        if (probe <= 64 && (STRICT ? c < x : c <= x)) cnt = probe;
+    }
+    const float c63 = __shfl(key, 63, 64);
+    if (cnt == 63 && (STRICT ? c63 < x : c63 <= x)) cnt = 64;
+    return cnt;
+}
+
+// Merge of two SORTED lists of <= 64 values each by rank: element i of a lands at i + #{b < a_i}, element j of b at
+// j + #{a <= b_j} (ties: the coarse depth first; the VALUES equal those of sort(cat[a, b]) in every case).  12
+// cross-lane reads and two scattered 4-byte stores into the ray's own 512-byte row instead of the 28-stage / 54-shuffle
+// bitonic network over 128 values.  Returns false (nothing written) if either list is not sorted.
+__device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int nb, bool b_may_be_unsorted,
+                                             float *__restrict__ out_row) {
+    const int l = lane_id();
+    const float a_key = l < na ? a : INFINITY;
+    float b_key = l < nb ? b : INFINITY;
+    const float a_next = __shfl_down(a_key, 1, 64), b_next = __shfl_down(b_key, 1, 64);
+    if (__any(l < 63 && a_next < a_key)) return false;
+    if (__any(l < 63 && b_next < b_key)) {
+        if (!b_may_be_unsorted) return false;
+        float v[1] = {b_key};                                    // random u: sort the 64 new samples (21 stages)
+        bitonic_sort<1>(v);
+        b_key = v[0];
+    }
+    if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
+    const int pa = l + count_below<true>(b_key, a_key);
+    const int pb = l + count_below<false>(a_key, b_key);
+    if (l < na) out_row[pa] = a_key;
+    if (l < nb) out_row[pb] = b_key;
+    return true;
+}
+
 template <int IT>
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u, int u_is_row,
@@ -217,7 +258,11 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     }
     s2 = wave_sum(s2);
     if (l == 0) z_std[ray] = sqrtf(s2 / (float)Nf);
-    // merge: sort(cat[z, z_samples])
+    // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
+    // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
+    if constexpr (IT == 1) {
+        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf))) return;
+    }
     constexpr int M = 2 * IT;
     float v[M];
 #pragma unroll

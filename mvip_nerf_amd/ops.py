@@ -750,12 +750,15 @@ def linear_cm(W, X):
 
 # Split-precision GEMM building blocks and the VAE mid-block attention built from them ------------------------
 
+ABSMAX_THREE_LAUNCHES = bool(int(_os.environ.get('MVIP_ABSMAX_THREE_LAUNCHES', '0')))     # A/B switch: zero + reduce + scale
+
+
 def absmax_scale(t):
     """Device-side {s, 1/s, scratch, scratch}: power of two with |t|max * s in [2^9, 2^10)."""
     tc = t.contiguous()
     scale2 = torch.empty(4, device=t.device, dtype=torch.float32)
-    zw = _zero_words(t.device)
-    call('mvip_absmax_scale', ptr(tc), tc.numel(), ptr(scale2), ptr(zw[32:34], torch.int32), stream())
+    zw = None if ABSMAX_THREE_LAUNCHES else _zero_words(t.device)[32:34]
+    call('mvip_absmax_scale', ptr(tc), tc.numel(), ptr(scale2), ptr(zw, torch.int32), stream())
     return scale2
 
 

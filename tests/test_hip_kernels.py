@@ -191,6 +191,30 @@ def test_sample_pdf_merge_vs_oracle(cuda, Nc, Nf):
     print(f'sample_pdf_merge Nc={Nc} Nf={Nf}: {int(mism.sum())} index mismatches of {mism.size}')
 
 
+def test_sample_pdf_merge_rank_paths(cuda):
+    """The three routes of the merge give sort(cat[z, samples]) exactly: both lists sorted (deterministic u: rank merge
+    only), samples unsorted (random u: 64-value sort + rank merge), coarse depths unsorted (full bitonic network)."""
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(77)
+    B = 41
+    z = np.sort(rs.uniform(1.2, 7.7, size=(B, 64)), -1).astype(np.float32)
+    z[3, 10:14] = z[3, 10]                                    # ties inside the coarse list
+    w = (rs.uniform(0, 1, size=(B, 64)) ** 2).astype(np.float32)
+    w[5] = 0
+    for u in (np.linspace(0., 1., 64, dtype=np.float32), rs.uniform(0, 1, size=(B, 64)).astype(np.float32)):
+        for zz in (z, z[:, ::-1].copy()):
+            zs, zm, zstd, _, _ = ops.sample_pdf_merge(T(zz, cuda), T(w, cuda), T(u, cuda))
+            want = np.sort(np.concatenate([zz, N(zs)], -1), -1)
+            np.testing.assert_array_equal(N(zm), want)
+    # a sample that equals a coarse depth exactly (u = 0 maps onto the first midpoint; duplicate it into z)
+    zs, _, _, _, _ = ops.sample_pdf_merge(T(z, cuda), T(w, cuda), T(np.zeros(64, np.float32), cuda))
+    z2 = z.copy()
+    z2[:, 0] = N(zs)[:, 0]
+    z2 = np.sort(z2, -1)
+    zs2, zm2, _, _, _ = ops.sample_pdf_merge(T(z2, cuda), T(w, cuda), T(np.zeros(64, np.float32), cuda))
+    np.testing.assert_array_equal(N(zm2), np.sort(np.concatenate([z2, N(zs2)], -1), -1))
+
+
 # ---------------------------------------------------------------------------------------------- MLP
 def test_mlp_pack_roundtrip(cuda):
     """pack -> unpack(grad path) is the identity on every real parameter element."""
