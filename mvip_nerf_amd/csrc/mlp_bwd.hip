@@ -216,6 +216,16 @@ __device__ __forceinline__ f32x4 read_piece(const float *tile, int row, int cw) 
     return *reinterpret_cast<const f32x4 *>(tile + row * 32 + ((cw ^ ((row >> 1) & 7)) << 2));
 }
 
+// half stages (16 points): the LDS image of a block is [32 units][16 points] = 2 KB, 16-B pieces XOR-swizzled by
+// ((row>>2)&3) so that the 16 lanes of a ds_read_b128 phase (rows 16m..16m+15, one logical piece) hit 16 distinct
+// 16-B bank groups
+constexpr int HALF_FLOATS = 512;
+template <int SP>
+__device__ __forceinline__ f32x4 read_stage_piece(const float *tile, int row, int cw) {
+    if constexpr (SP == 32) return read_piece(tile, row, cw);
+    else return *reinterpret_cast<const f32x4 *>(tile + row * 16 + ((cw ^ ((row >> 2) & 3)) << 2));
+}
+
 // |d_raw| maximum of a backward call (bits of a non-negative float order like unsigned integers)
 __global__ void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
     float m = 0.f;
@@ -240,7 +250,7 @@ __global__ void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *
 // per MFMA against 1.7 + 0.1 in the forward kernel); the per-block source addresses of a stage are hoisted into
 // scalar base pointers (a stage advances every block by the same 4 KB), which removes the 64-bit multiply chain that
 // issue_stage re-ran for each of the 12 blocks of every stage.
-template <int NTW, int KT, int PREC = 0, bool BSPLIT = false, int EXTRA = 0>
+template <int NTW, int KT, int PREC = 0, bool BSPLIT = false, int EXTRA = 0, int SP = 32>
 __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act, int64_t act_n_pt,
                                            int64_t act_pt0, const float *__restrict__ gst, int64_t n_pt,
                                            int64_t pt0, int64_t pt1, float *lds, int wave, int lane,
@@ -255,9 +265,18 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     constexpr int nblk = NT + KTT + nextra;
     const int g_tile0 = G.g_tile0, a0 = G.a_tile0[0], a1 = G.a_tile0[1], ac0 = G.a_count0;
 
-    // wave w stages rows 8w..8w+7 of every block of the stage (one LDS-DMA per block and wave)
-    const int r = 8 * wave + (lane >> 3), c = lane & 7;
-    const int lane_off = r * 32 + ((c ^ ((r >> 1) & 7)) << 2);
+    // SP = 32: wave w stages rows 8w..8w+7 of every block of the stage (one LDS-DMA per block and wave).
+    // SP = 16: a 1-KB DMA piece is 16 rows x 16 points; wave w stages rows 16(w&1).. of the blocks b = (w>>1) mod 2.
+    constexpr int BLK = SP == 32 ? TILE_FLOATS : HALF_FLOATS;       // floats of a block in LDS
+    constexpr int NPG = SP / 8;                                     // 8-point groups per stage
+    int lane_off;
+    if constexpr (SP == 32) {
+        const int r = 8 * wave + (lane >> 3), c = lane & 7;
+        lane_off = r * 32 + ((c ^ ((r >> 1) & 7)) << 2);
+    } else {
+        const int r = 16 * (wave & 1) + (lane >> 2), c = lane & 3;
+        lane_off = r * 32 + ((c ^ ((r >> 2) & 3)) << 2);
+    }
     const float *blk_base[nblk];                                   // wave-uniform: stage pt of block b = base + pt * 4 KB
 #pragma unroll
     for (int b = 0; b < nblk; ++b) {
@@ -270,14 +289,30 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         blk_base[b] = from_g ? gst + (int64_t)tile * n_pt * TILE_FLOATS
                              : act + ((int64_t)tile * act_n_pt + act_pt0) * TILE_FLOATS;
     }
-    auto issue_stage = [&](int64_t pt, float *dst) {
+    // `st` counts stages of SP points from the start of the tile
+    auto issue_stage = [&](int64_t st, float *dst) {
         // scalar base + 32-bit per-lane byte offset (a backward tile spans < 2^32 bytes per stash row): the form the
         // global_load_lds instruction takes directly (saddr + voffset), no 64-bit vector address per block
-        const unsigned voff = (unsigned)(((unsigned)pt * (unsigned)TILE_FLOATS + (unsigned)lane_off) * 4u);
+        if constexpr (SP == 32) {
+            const unsigned voff = (unsigned)(((unsigned)st * (unsigned)TILE_FLOATS + (unsigned)lane_off) * 4u);
 #pragma unroll
-        for (int b = 0; b < nblk; ++b)
-            glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff),
-                   dst + b * TILE_FLOATS + wave * 256);
+            for (int b = 0; b < nblk; ++b)
+                glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff),
+                       dst + b * TILE_FLOATS + wave * 256);
+        } else {
+            const unsigned voff = (unsigned)((((unsigned)st >> 1) * (unsigned)TILE_FLOATS + ((unsigned)st & 1u) * 16u +
+                                              (unsigned)lane_off) * 4u);
+            float *d = dst + (wave & 1) * 256;
+            if (wave >> 1) {
+#pragma unroll
+                for (int b = 1; b < nblk; b += 2)
+                    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff), d + b * HALF_FLOATS);
+            } else {
+#pragma unroll
+                for (int b = 0; b < nblk; b += 2)
+                    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff), d + b * HALF_FLOATS);
+            }
+        }
     };
 
     f32x16 acc[NTW][KT];
@@ -298,17 +333,17 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
     auto load_ops = [&](const float *stg, int pg, f32x4 (&A)[NTW], f32x4 (&Bv)[KT]) {
         const int cw = 2 * pg + hh;
 #pragma unroll
-        for (int a = 0; a < NTW; ++a) A[a] = read_piece(stg + (wave * NTW + a) * TILE_FLOATS, i, cw);
+        for (int a = 0; a < NTW; ++a) A[a] = read_stage_piece<SP>(stg + (wave * NTW + a) * BLK, i, cw);
 #pragma unroll
-        for (int b = 0; b < KT; ++b) Bv[b] = read_piece(stg + (NT + b) * TILE_FLOATS, i, cw);
+        for (int b = 0; b < KT; ++b) Bv[b] = read_stage_piece<SP>(stg + (NT + b) * BLK, i, cw);
     };
     auto compute_stage = [&](const float *stg) {
         f32x4 A[NTW], Bv[KT], An[NTW], Bn[KT];
         load_ops(stg, 0, A, Bv);
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) {
+        for (int pg = 0; pg < NPG; ++pg) {
             const int cw = 2 * pg + hh;
-            if (pg < 3) load_ops(stg, pg + 1, An, Bn);      // operands of the next point group, one MFMA block early
+            if (pg < NPG - 1) load_ops(stg, pg + 1, An, Bn);      // operands of the next point group, one MFMA block early
 #pragma unroll
             for (int a = 0; a < NTW; ++a) bsum[a] += (A[a][0] + A[a][1]) + (A[a][2] + A[a][3]);
 #pragma unroll
@@ -318,7 +353,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[a][b] = mfma(A[a][s], Bv[b][s], acc[a][b]);
             if (extra == 1 && wave == 0) {             // d(alpha_linear.weight)[k] = sum_p d_sigma[p] h7[k][p]
-                const f32x4 ds = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw);
+                const f32x4 ds = read_stage_piece<SP>(stg + (NT + KTT) * BLK, 3, cw);
                 if constexpr (KT == 8) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b)
@@ -328,20 +363,20 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                 xb[0] += (ds[0] + ds[1]) + (ds[2] + ds[3]);
             }
             if (extra == 2 && wave == 0) {             // d(rgb_linear.weight)[c][k] = sum_p d_rgb[c][p] v[k][p]
-                const float *xt = stg + (NT + KTT) * TILE_FLOATS;
+                const float *xt = stg + (NT + KTT) * BLK;
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
-                    const f32x4 dc = read_piece(xt + 4 * TILE_FLOATS, cc, cw);
+                    const f32x4 dc = read_stage_piece<SP>(xt + 4 * BLK, cc, cw);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f32x4 vv = read_piece(xt + t * TILE_FLOATS, i, cw);
+                        const f32x4 vv = read_stage_piece<SP>(xt + t * BLK, i, cw);
 #pragma unroll
                         for (int s = 0; s < 4; ++s) xw[cc * 4 + t] = fmaf(dc[s], vv[s], xw[cc * 4 + t]);
                     }
                     xb[cc] += (dc[0] + dc[1]) + (dc[2] + dc[3]);
                 }
             }
-            if (pg < 3) {
+            if (pg < NPG - 1) {
 #pragma unroll
                 for (int a = 0; a < NTW; ++a) A[a] = An[a];
 #pragma unroll
@@ -352,7 +387,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 
     auto compute_stage_f16 = [&](const float *stg) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                 // 16 points per k-step; lane (i,hh) takes points 16ks+8hh..+7
+        for (int ks = 0; ks < SP / 16; ++ks) {           // 16 points per k-step; lane (i,hh) takes points 16ks+8hh..+7
             const int cw = 4 * ks + 2 * hh;
             h16x8 Ah[NTW], Al[NTW], Bh[KT], Bl[KT];
             auto split8 = [&](const f32x4 &p0, const f32x4 &p1, float sc, h16x8 &hi, h16x8 &lo) {
@@ -366,22 +401,22 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
             };
 #pragma unroll
             for (int a = 0; a < NTW; ++a) {
-                const float *t = stg + (a_first + a) * TILE_FLOATS;
-                const f32x4 p0 = read_piece(t, i, cw), p1 = read_piece(t, i, cw + 1);
+                const float *t = stg + (a_first + a) * BLK;
+                const f32x4 p0 = read_stage_piece<SP>(t, i, cw), p1 = read_stage_piece<SP>(t, i, cw + 1);
                 bsum[a] += ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
                 split8(p0, p1, gscale, Ah[a], Al[a]);
             }
             f32x4 ds0, ds1;
             const bool do_alpha = extra == 1 && (BSPLIT || wave == 0);     // sigma-row dots over this wave's act tiles
             if (do_alpha) {
-                ds0 = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw);
-                ds1 = read_piece(stg + (NT + KTT) * TILE_FLOATS, 3, cw + 1);
+                ds0 = read_stage_piece<SP>(stg + (NT + KTT) * BLK, 3, cw);
+                ds1 = read_stage_piece<SP>(stg + (NT + KTT) * BLK, 3, cw + 1);
                 xb[0] += ((ds0[0] + ds0[1]) + (ds0[2] + ds0[3])) + ((ds1[0] + ds1[1]) + (ds1[2] + ds1[3]));
             }
 #pragma unroll
             for (int b = 0; b < KT; ++b) {
-                const float *t = stg + (NT + b_first + b) * TILE_FLOATS;
-                const f32x4 p0 = read_piece(t, i, cw), p1 = read_piece(t, i, cw + 1);
+                const float *t = stg + (NT + b_first + b) * BLK;
+                const f32x4 p0 = read_stage_piece<SP>(t, i, cw), p1 = read_stage_piece<SP>(t, i, cw + 1);
                 split8(p0, p1, 1.f, Bh[b], Bl[b]);
                 if (do_alpha) {
                     if constexpr (KT <= 8) {
@@ -399,13 +434,13 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                     acc[a][b] = mfma16(Al[a], Bh[b], acc[a][b]);
                 }
             if (extra == 2 && wave == 0) {             // rgb rows: fp32 VALU dots on the same 8 points
-                const float *xt = stg + (NT + KTT) * TILE_FLOATS;
+                const float *xt = stg + (NT + KTT) * BLK;
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
-                    const f32x4 d0 = read_piece(xt + 4 * TILE_FLOATS, cc, cw), d1 = read_piece(xt + 4 * TILE_FLOATS, cc, cw + 1);
+                    const f32x4 d0 = read_stage_piece<SP>(xt + 4 * BLK, cc, cw), d1 = read_stage_piece<SP>(xt + 4 * BLK, cc, cw + 1);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f32x4 v0 = read_piece(xt + t * TILE_FLOATS, i, cw), v1 = read_piece(xt + t * TILE_FLOATS, i, cw + 1);
+                        const f32x4 v0 = read_stage_piece<SP>(xt + t * BLK, i, cw), v1 = read_stage_piece<SP>(xt + t * BLK, i, cw + 1);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) xw[cc * 4 + t] = fmaf(d1[q], v1[q], fmaf(d0[q], v0[q], xw[cc * 4 + t]));
                     }
@@ -421,23 +456,24 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 
     // double-buffered stages with COMPILE-TIME buffer addresses (so LDS-DMA writes into one buffer
     // provably do not alias the ds_reads of the other and no wait is inserted between them)
-    float *buf0 = lds, *buf1 = lds + W_STAGE_FLOATS;
-    issue_stage(pt0, buf0);
-    __syncthreads();
+    float *buf0 = lds, *buf1 = lds + W_STAGE_BLOCKS * BLK;
     // The loop body is a whole PAIR of stages with its only exit at the bottom, and an odd last stage runs after it:
     // with an exit between the two stages the accumulators reached the flush from two places and the register
     // allocator kept two copies of all eight tiles, moving 128 registers from one to the other every stage.
-    const int64_t n_pairs = (pt1 - pt0) >> 1;
-    int64_t pt = pt0;
-    for (int64_t pr = 0; pr < n_pairs; ++pr, pt += 2) {
-        issue_stage(pt + 1, buf1);
+    const int64_t st0 = pt0 * (32 / SP), st1 = pt1 * (32 / SP);
+    issue_stage(st0, buf0);
+    __syncthreads();
+    const int64_t n_pairs = (st1 - st0) >> 1;
+    int64_t st = st0;
+    for (int64_t pr = 0; pr < n_pairs; ++pr, st += 2) {
+        issue_stage(st + 1, buf1);
         compute(buf0);
-        __syncthreads();          // stage pt+1 landed (vmcnt(0)) and everyone is done with buf0
-        if (pt + 2 < pt1) issue_stage(pt + 2, buf0);
+        __syncthreads();          // stage st+1 landed (vmcnt(0)) and everyone is done with buf0
+        if (st + 2 < st1) issue_stage(st + 2, buf0);
         compute(buf1);
         __syncthreads();
     }
-    if (pt < pt1) compute(buf0);
+    if (st < st1) compute(buf0);
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave (two 128-B row segments) ----
 #pragma unroll
@@ -496,13 +532,15 @@ __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
 // blockIdx.y: 0..15 the eight 256x256 products as two 128-row halves each, 16..17 the two 256x64
 // products with the encoding, 18..19 the view branch in two column groups.  No wave holds more than
 // 128 accumulator registers: with 256 hipcc shuttles tiles between AGPRs and VGPRs every stage.
-template <int PREC>
-__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
+// SP = 16 (half stages, 56 KB of LDS, <= 128 + 128 registers): TWO workgroups per CU, so the barrier / LDS-latency bubble
+// at every stage boundary of one workgroup runs under the other's MFMAs.
+template <int PREC, int SP>
+__global__ __launch_bounds__(256, SP == 16 ? 2 : 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
                                                           const float *__restrict__ act, int64_t act_n_pt,
                                                           int64_t act_pt0, const float *__restrict__ gst,
                                                           int64_t n_pt, int stages_per_slab,
                                                           const unsigned *__restrict__ absmax_bits) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_BLOCKS * (SP == 32 ? TILE_FLOATS : HALF_FLOATS)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int id = blockIdx.y;
@@ -522,16 +560,16 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(const Gemm *__restric
     }
     if (id < 16) {                                    // 256 x 256 products; product 14 also carries the sigma row
         if (G.extra == 1) {
-            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 1>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-            else wgrad_body<1, 8, 0, false, 1>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 1, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            else wgrad_body<1, 8, 0, false, 1, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
         } else {
-            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-            else wgrad_body<1, 8, 0, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            if constexpr (PREC == 1) wgrad_body<4, 2, 1, true, 0, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            else wgrad_body<1, 8, 0, false, 0, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
         }
     }
-    else if (id < 18) wgrad_body<2, 2, PREC, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-    else if (id == 18) wgrad_body<1, 5, PREC, false, 2>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
-    else wgrad_body<1, 4, PREC, false, 0>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else if (id < 18) wgrad_body<2, 2, PREC, false, 0, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else if (id == 18) wgrad_body<1, 5, PREC, false, 2, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+    else wgrad_body<1, 4, PREC, false, 0, SP>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
 }
 
 static_assert(sizeof(Gemm) * N_PRODUCTS <= 1024 * 4 - 16, "table room (+ the absmax word)");
@@ -638,10 +676,18 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         if (sps < 1) sps = 1;
         if (sps > sps_cap) sps = sps_cap;
         const dim3 grid2((unsigned)((n_pt + sps - 1) / sps), N_PRODUCTS);
-        if (precision == 1)
-            hipLaunchKernelGGL(mlp_wgrad_kernel<1>, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
-        else
-            hipLaunchKernelGGL(mlp_wgrad_kernel<0>, grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+        // 16-point stages with two workgroups per CU for the exact-fp32 products (round 2, same box: 56.9 vs 58.1 ms per
+        // training iteration); the split-precision products are bound by their operand conversions on the VALU and run
+        // 1 % slower that way, so they keep 32-point stages.  MVIP_WGRAD_HALF=0/1 forces one shape (tuning / A-B switch).
+        static const int half_env = [] { const char *e = getenv("MVIP_WGRAD_HALF"); return e ? atoi(e) : -1; }();
+        const int half_stages = half_env >= 0 ? half_env : (precision == 1 ? 0 : 1);
+        if (precision == 1) {
+            if (half_stages) hipLaunchKernelGGL((mlp_wgrad_kernel<1, 16>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+            else hipLaunchKernelGGL((mlp_wgrad_kernel<1, 32>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+        } else {
+            if (half_stages) hipLaunchKernelGGL((mlp_wgrad_kernel<0, 16>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+            else hipLaunchKernelGGL((mlp_wgrad_kernel<0, 32>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+        }
     }
     return check_launch();
 }

@@ -3,7 +3,7 @@
 # barrier), WAIT_INST_ANY (issue stall), ACTIVE_INST_ANY, plus LDS / VMEM instruction mix.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-for W in train sds; do
+for W in ${PMC_DIAG_WORKLOADS:-train sds}; do
   if [ $W = train ]; then PROG="tools/train_speed.py"; else PROG="tools/sds_profile.py"; fi
   for P in A B; do
     if [ $P = A ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES";
@@ -16,7 +16,8 @@ for W in train sds; do
 done
 python3 - <<'PY'
 import json
-for W in ('train', 'sds'):
+import os
+for W in os.environ.get('PMC_DIAG_WORKLOADS', 'train sds').split():
     a = {e['kernel']: e for e in json.load(open(f'gpurun_out/pmc_diag_{W}_A/summary.json'))}
     b = {e['kernel']: e for e in json.load(open(f'gpurun_out/pmc_diag_{W}_B/summary.json'))}
     print('==', W)
