@@ -253,8 +253,13 @@ int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G,
  * ONE launch -- maximum by atomics, the last workgroup writes the scale -- instead of zero + reduce + scale).
  *   y[n,co,h,w] = conv(x, W)[n,co,h,w] / (s_w s_x) + bias[co] + chan_add[n,co] + residual[n,co,h,w]
  * (bias, chan_add, residual, x_scale2 may be NULL).  Supported: Cout % 32 == 0, Cin % 16 == 0,
- * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0) (mvip_conv3x3_supported); anything else returns
- * MVIP_EINVAL. */
+ * (H % 8 == 0 and W % 32 == 0) or (H % 16 == 0 and W % 16 == 0) or H == W == 8 (mvip_conv3x3_supported); anything
+ * else returns MVIP_EINVAL.
+ * mvip_conv3x3_f16x3_ws takes a caller-owned workspace of mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W) bytes (0 for
+ * most shapes; workspace may then be NULL): layers whose (pixel tile, 32-row block) grid would occupy a fraction of the
+ * chip -- the UNet's 1280-channel levels at 16x16 and 8x8, whose weights are 59-118 MB per layer -- are split over the
+ * input channels, each workgroup writing raw partial sums, and a second launch adds the splits in index order
+ * (deterministic) and applies the epilogue.  Results equal mvip_conv3x3_f16x3's up to fp32 summation order. */
 int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W);
 int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
 int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
@@ -267,6 +272,10 @@ int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float 
 int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, void *stream);
+int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                          const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                          int64_t H, int64_t W, float *y, void *workspace, void *stream);
 
 /* The same split-precision machinery as a plain GEMM (1x1 convolutions and the products of the VAE
  * mid-block attention, vae.encode at DS_NeRF/guidance/sd_utils.py:207):

@@ -72,6 +72,8 @@ _SIGNATURES = {
     'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _c_f]),
     'mvip_conv3x3_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_conv3x3_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    'mvip_conv3x3_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_hashgrid_forward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_hashgrid_backward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_sh4': (_int, [_c_f, _i64, _c_f, _c_f]),

@@ -242,12 +242,18 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---- the convolution -------------------------------------------------------------------------------------
 struct ConvArgs {
     const char *xs, *wp, *zero16;
     const float *bias, *chan_add, *residual, *x_scale2, *w_scale2;
     float *y;
     int N, CK, Cout, H, W, tilesX, tilesY, MB;
+    // split-K (partial != nullptr): workgroup `split` of `splits` contracts channel chunks [split*cks, (split+1)*cks) and
+    // writes its raw accumulators to partial[split][n][Cout][H][W]; cv_split_reduce_kernel sums them in order
+    int splits, cks;
+    float *partial;
 };
 
 // MT <= 2: 80 KB of LDS and 256 registers, i.e. TWO workgroups per CU = two waves per SIMD, so one wave's LDS
@@ -258,10 +264,16 @@ struct ConvArgs {
 // the haloed input tile are shared by twice the MFMAs (10.9 instead of 16.8 B/clk/CU of LDS-DMA at full matrix rate for
 // MT = 2).  Built to test whether operand delivery bounds this kernel as it bounds the plain GEMM and the attention
 // kernel: it does not -- both shapes run the VAE / UNet convolutions in the same time (round 2, tools/conv_wide_ab.py).
+// TW = 8 (8 x 8 images, the UNet's innermost level): a workgroup takes FOUR images, wave w image w (two column blocks of
+// 4 rows x 8 pixels); the LDS tile holds the four haloed 10 x 10 images one after the other.
+// Split-K: at the inner UNet levels the grid of (pixel tile, row block) pairs is far smaller than the chip (1280 channels
+// at 16 x 16 x 2 images: 80 workgroups, at 8 x 8: 40) while one layer's weights are 59-118 MB, so those layers are bound by
+// how many CUs pull weights at once; with a.partial set the channel range is divided over a.splits workgroups.
 template <int MT, int TW = CV_TW, int NW = 4>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
     constexpr int NT = NW * 64;
-    constexpr int TH = NT / TW, HW = TW + 2, PIX = (TH + 2) * HW, RPB = 32 / TW;    // RPB: image rows per column block
+    constexpr int TH = NT / TW, HW = TW + 2, RPB = 32 / TW;                         // RPB: image rows per column block
+    constexpr int PIX = TW == 8 ? 4 * 10 * HW : (TH + 2) * HW;
     constexpr int CV_IN_BYTES = 4 * PIX * 16;          // shadows the 8 x 32 constants: sized for this tile
     constexpr int CV_IN_ROUNDS = (4 * PIX + NT - 1) / NT;
     constexpr int WB = 3 * MT * 2 * 1024;              // weights of one stage (kernel row, 16 channels)
@@ -276,14 +288,18 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
     int id = blockIdx.x;
     const int total = gridDim.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int split = id % a.splits;                    // the splits of one (tile, row block) adjacent: they share the input tile
+    id /= a.splits;
     const int mb = id % a.MB;
     int tile = id / a.MB;
     const int tx = tile % a.tilesX; tile /= a.tilesX;
     const int ty = tile % a.tilesY;
-    const int n = tile / a.tilesY;
+    const int n = (TW == 8 ? 4 : 1) * (tile / a.tilesY);                 // first image of the workgroup
     const int y0 = ty * TH, x0 = tx * TW;
     const int H = a.H, W = a.W;
     const int64_t plane = (int64_t)H * W * 16;
+    const int ck0 = split * a.cks;
+    const int nck = (a.CK - ck0 < a.cks) ? a.CK - ck0 : a.cks;           // channel chunks of this workgroup (>= 1)
 
     int in_off[CV_IN_ROUNDS];
 #pragma unroll
@@ -293,13 +309,19 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
         if (s < 4 * PIX) {
             const int piece = s / PIX, p = s - piece * PIX;
             const int row = p / HW, col = p - row * HW;
-            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[r] = (int)(piece * plane) + (gy * W + gx) * 16;
+            if constexpr (TW == 8) {
+                const int img = row / 10, gy = row - img * 10 - 1, gx = col - 1;
+                if (n + img < a.N && gy >= 0 && gy < 8 && gx >= 0 && gx < 8)
+                    in_off[r] = (int)(img * a.CK * 4 * plane) + (int)(piece * plane) + (gy * 8 + gx) * 16;
+            } else {
+                const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[r] = (int)(piece * plane) + (gy * W + gx) * 16;
+            }
         }
     }
-    const char *xs_n = a.xs + (int64_t)n * a.CK * 4 * plane;
+    const char *xs_n = a.xs + ((int64_t)n * a.CK + ck0) * 4 * plane;
     constexpr int WROW = 3 * 2 * 1024;                 // one stage of one 32-channel row block
-    const char *wp_b = a.wp + (int64_t)mb * MT * a.CK * 3 * WROW;
+    const char *wp_b = a.wp + ((int64_t)mb * MT * a.CK + ck0) * 3 * WROW;
 
     auto issue_input = [&](int ck, int buf) {
         const char *base = xs_n + (int64_t)ck * 4 * plane;
@@ -333,8 +355,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
     // read, waited and multiplied group by group and kept the matrix pipe 34 % busy).  Weights are staged TWO
     // stages ahead in three LDS buffers so that the next stage's fragments can be read before the barrier.
     constexpr int NG = 3 * MT;                          // groups per stage, kx-major
-    const int nstage = a.CK * 3;
+    const int nstage = nck * 3;
     const int jrow0 = 2 * wave;
+    const int img_rows = TW == 8 ? 2 * wave : 0;        // TW = 8: every image in front of this wave's adds two halo rows
     h16x8 Ah[3], Al[3];                                 // set = group % 3  (NG % 3 == 0: the rotation survives stages)
     h16x8 Bh[3][2], Bl[3][2];                           // set = kx
     auto load_a = [&](const char *wb, int g, int set) {
@@ -345,7 +368,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
     auto load_b = [&](const char *inb, int ky, int kx) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = ((jrow0 + j) * RPB + l32 / TW + ky) * HW + l32 % TW + kx;
+            const int p = ((jrow0 + j) * RPB + img_rows + l32 / TW + ky) * HW + l32 % TW + kx;
             Bh[kx][j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
             Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + PIX * 16 + p * 16);
         }
@@ -358,7 +381,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
     if (nstage > 1) issue_weights(1, 1);
     __syncthreads();                                    // stages 0 and 1 (and input chunk 0) have landed
     if (nstage > 2) issue_weights(2, 2);
-    if (a.CK > 1) issue_input(1, 1);
+    if (nck > 1) issue_input(1, 1);
     load_b(in_base(0), 0, 0);
     load_a(w_base(0), 0, 0);
     if (NG > 1) load_a(w_base(0), 1, 1);
@@ -368,7 +391,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
         if (t > 0) {
             __syncthreads();                   // stage t+1 landed (vmcnt(0)); every wave is done with stage t-1
             if (t + 2 < nstage) issue_weights(t + 2, (t + 2) % 3);
-            if (ky == 0 && ck + 1 < a.CK) issue_input(ck + 1, (ck + 1) & 1);
+            if (ky == 0 && ck + 1 < nck) issue_input(ck + 1, (ck + 1) & 1);
         }
         const char *wb = w_base(t), *inb = in_base(t);
         const char *wb_n = w_base(t + 1), *inb_n = in_base(t + 1);
@@ -400,22 +423,46 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) co
 
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
     const int gx = x0 + l32 % TW;
+    const int n_out = TW == 8 ? n + wave : n;
+    if (TW == 8 && n_out >= a.N) return;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int gy = y0 + (jrow0 + j) * RPB + l32 / TW;
+            const int gy = TW == 8 ? j * RPB + l32 / TW : y0 + (jrow0 + j) * RPB + l32 / TW;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                const int64_t o = (((int64_t)n_out * a.Cout + co) * H + gy) * W + gx;
+                if (a.partial) {
+                    a.partial[(int64_t)split * a.N * a.Cout * H * W + o] = acc[m][j][r];
+                    continue;
+                }
                 float v = acc[m][j][r] * inv;
                 if (a.bias) v += a.bias[co];
-                if (a.chan_add) v += a.chan_add[(int64_t)n * a.Cout + co];
-                const int64_t o = (((int64_t)n * a.Cout + co) * H + gy) * W + gx;
+                if (a.chan_add) v += a.chan_add[(int64_t)n_out * a.Cout + co];
                 if (a.residual) v += a.residual[o];
                 a.y[o] = v;
             }
         }
+}
+
+// y = (sum_s partial[s]) / (s_w s_x) + bias + chan_add + residual, the splits added in index order (deterministic)
+__global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int splits, int64_t total, int Cout, int64_t HW,
+                                       const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
+                                       const float *__restrict__ bias, const float *__restrict__ chan_add,
+                                       const float *__restrict__ residual, float *__restrict__ y) {
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;        // HW % 4 == 0: four pixels of one channel
+    if (i4 >= total) return;
+    const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(partial + i4);
+    for (int s = 1; s < splits; ++s) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)s * total + i4);
+    const int64_t nc = i4 / HW;                        // n * Cout + co
+    f32x4 v = sum * inv;                               // same order of roundings as the unsplit epilogue
+    if (bias) v += bias[nc % Cout];
+    if (chan_add) v += chan_add[nc];
+    if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i4);
+    *reinterpret_cast<f32x4 *>(y + i4) = v;
 }
 
 // ---- plain GEMM (1x1 convolution, attention products) on the same operand formats -----------------------
@@ -715,7 +762,7 @@ using namespace mvip;
 
 extern "C" int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W) {
     return Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 16 == 0 && H > 0 && W > 0 &&
-           ((H % CV_TH == 0 && W % CV_TW == 0) || (H % 16 == 0 && W % 16 == 0)) &&
+           ((H % CV_TH == 0 && W % CV_TW == 0) || (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8)) &&
            H * W <= (1 << 24);
 }
 
@@ -793,14 +840,43 @@ extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, c
     return check_launch();
 }
 
-extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
-                                  const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                                  int64_t H, int64_t W, float *y, void *stream) {
+// Number of channel splits for a launch whose unsplit grid has `blocks` workgroups: fill ~2 workgroups per CU, keep at
+// least 4 channel chunks (12 stages) per workgroup so the pipeline prologue stays small.
+static inline int cv_splits(int64_t blocks, int64_t CK) {
+    static const int forced = [] { const char *e = getenv("MVIP_CONV_SPLITS"); return e ? atoi(e) : 0; }();   // tuning
+    int64_t s = forced > 0 ? forced : (blocks >= 256 ? 1 : (512 + blocks - 1) / blocks);
+    if (s > CK / 4) s = CK / 4;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    const int64_t cks = (CK + s - 1) / s;
+    return (int)((CK + cks - 1) / cks);                // no empty split
+}
+static inline void cv_geometry(int64_t N, int64_t Cout, int64_t H, int64_t W, int &tw, int &MT, int64_t &blocks) {
+    tw = (W % CV_TW == 0 && H % CV_TH == 0) ? CV_TW : (H == 8 && W == 8 ? 8 : 16);
+    const int th = 256 / tw;
+    MT = tw != CV_TW ? 1 : cv_mt(Cout, N * (W / tw) * (H / th));
+    blocks = (tw == 8 ? (N + 3) / 4 : N * (W / tw) * (H / th)) * (Cout / (32 * MT));
+}
+
+extern "C" int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    if (N <= 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return 0;
+    int tw, MT;
+    int64_t blocks;
+    cv_geometry(N, Cout, H, W, tw, MT, blocks);
+    const int s = cv_splits(blocks, Cin / 16);
+    return s > 1 ? (int64_t)s * N * Cout * H * W * 4 : 0;
+}
+
+static int conv3x3_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                          const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                          int64_t H, int64_t W, float *y, void *workspace, void *stream) {
     if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
-    const int tw = (W % CV_TW == 0 && H % CV_TH == 0) ? CV_TW : 16, th = 256 / tw;      // 16 x 16 tiles for narrow images
-    const int MT = tw == 16 ? 1 : cv_mt(Cout, N * (W / tw) * (H / th));
+    int tw, MT;
+    int64_t blocks;
+    cv_geometry(N, Cout, H, W, tw, MT, blocks);
+    const int th = 256 / tw;
     ConvArgs a;
     a.xs = (const char *)xs; a.wp = (const char *)packed;
     const char *tail = (const char *)packed + Cout * Cin * 36;
@@ -808,6 +884,9 @@ extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const floa
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(Cin / 16); a.Cout = (int)Cout; a.H = (int)H; a.W = (int)W;
     a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
+    if (tw == 8) { a.tilesX = 1; a.tilesY = 1; }
+    a.splits = 1; a.cks = a.CK; a.partial = nullptr;
+    hipStream_t st = as_stream(stream);
     // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
     // four-wave tile on every VAE / UNet shape and on the whole step, 7.56 vs 7.65 ms -- tools/conv_wide_ab.py)
     static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
@@ -819,23 +898,49 @@ extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const floa
             const int64_t wb = tiles16 * a.MB;
             if (wb > 0x7fffffffLL) return MVIP_EINVAL;
             if (mtw == 2)
-                hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, as_stream(stream), a);
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
             else
-                hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, as_stream(stream), a);
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
             return check_launch();
         }
     }
-    const int64_t blocks = N * a.tilesX * a.tilesY * a.MB;
+    if (workspace) {
+        a.splits = cv_splits(blocks, a.CK);
+        if (a.splits > 1) { a.cks = (a.CK + a.splits - 1) / a.splits; a.partial = (float *)workspace; }
+    }
+    blocks *= a.splits;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    if (tw == 16)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    if (tw == 8)
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (tw == 16)
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else if (MT == 4)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else if (MT == 2)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.partial) {
+        const int64_t total = N * Cout * H * W;
+        hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
+                           a.splits, total, (int)Cout, H * W, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+    }
     return check_launch();
+}
+
+extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                  const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                                  int64_t H, int64_t W, float *y, void *stream) {
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, nullptr, stream);
+}
+
+// The same with a caller-owned workspace of mvip_conv3x3_workspace_bytes(...) bytes (may be null when that is 0): layers
+// whose grid would leave most of the chip idle are split over the input channels and summed by a second launch.
+extern "C" int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                     const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                                     int64_t H, int64_t W, float *y, void *workspace, void *stream) {
+    if (!workspace && mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W) > 0) return MVIP_EINVAL;
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, workspace, stream);
 }
 
 /* ---- plain GEMM ---------------------------------------------------------------------------------------- */

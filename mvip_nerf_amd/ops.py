@@ -583,8 +583,7 @@ class _NormActConv3x3(torch.autograd.Function):
         bias = None if conv.bias is None else conv.bias.detach().contiguous()
         ca = None if chan_add is None else chan_add.detach().contiguous()
         rs = None if residual is None else residual.detach().contiguous()
-        call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(_conv_packed(conv, False), torch.uint8), ptr(bias),
-             ptr(ca), ptr(rs), ptr(None), N, C, Cout, H, W, ptr(y), stream())
+        _conv3x3_launch(xs, _conv_packed(conv, False), bias, ca, rs, None, N, C, Cout, H, W, y)
         ctx.save_for_backward(xc, gw, gb, mean, rstd)
         ctx.mods = (norm, conv, bool(silu))
         return y
@@ -605,8 +604,7 @@ class _NormActConv3x3(torch.autograd.Function):
             dys = _split_buffer(N, Cout, HW, dev)
             call('mvip_split_planes', ptr(dyc), N, Cout, HW, ptr(scale2), ptr(dys, torch.float16), stream())
             dact = torch.empty_like(xc)
-            call('mvip_conv3x3_f16x3', ptr(dys, torch.float16), ptr(_conv_packed(conv, True), torch.uint8), ptr(None),
-                 ptr(None), ptr(None), ptr(scale2), N, Cout, C, H, W, ptr(dact), stream())
+            _conv3x3_launch(dys, _conv_packed(conv, True), None, None, None, scale2, N, Cout, C, H, W, dact)
             del dys
             dx = torch.empty_like(xc)
             ws = _gn_workspace(N, C, HW, dev)
@@ -615,6 +613,14 @@ class _NormActConv3x3(torch.autograd.Function):
         d_ca = dyc.sum((2, 3)) if ctx.needs_input_grad[1] else None
         d_rs = dyc if ctx.needs_input_grad[2] else None
         return dx, d_ca, d_rs, None, None, None
+
+
+def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, H, W, y):
+    """mvip_conv3x3_f16x3_ws with the split-K workspace the library asks for this shape (none for most)."""
+    nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W))
+    ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
+    call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
+         ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), stream())
 
 
 def conv3x3_plain(x, conv):
@@ -629,8 +635,7 @@ def conv3x3_plain(x, conv):
     call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), stream())
     y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
     bias = None if conv.bias is None else _f32c(conv.bias.detach())
-    call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(_conv_packed(conv, False), torch.uint8), ptr(bias), ptr(None),
-         ptr(None), ptr(scale2), N, C, Cout, H, W, ptr(y), stream())
+    _conv3x3_launch(xs, _conv_packed(conv, False), bias, None, None, scale2, N, C, Cout, H, W, y)
     return y
 
 

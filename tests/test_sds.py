@@ -231,7 +231,9 @@ def test_group_norm_fp16_and_errors(cuda):
                                                   (1, 16, 64, 8, 32, False), (1, 160, 64, 8, 64, True),
                                                   (2, 320, 320, 32, 32, True), (2, 64, 64, 16, 16, True),
                                                   (1, 128, 64, 32, 16, True), (2, 160, 96, 16, 48, False),    # these three: 16x16 tiles
-                                                  (1, 128, 128, 256, 256, True), (1, 64, 96, 256, 256, False)])   # large frames (eight-wave tiles when MVIP_CONV_WIDE=1)
+                                                  (1, 128, 128, 256, 256, True), (1, 64, 96, 256, 256, False),    # large frames (eight-wave tiles when MVIP_CONV_WIDE=1)
+                                                  (2, 320, 64, 8, 8, True), (5, 160, 96, 8, 8, True),             # 8x8 images (four per workgroup), channel splits
+                                                  (2, 640, 64, 16, 16, True), (1, 256, 32, 8, 32, False)])        # channel splits on the 16x16 and 8x32 tiles
 def test_norm_act_conv3x3(cuda, N_, cin, cout, H, W, grad):
     from mvip_nerf_amd import ops
     from mvip_nerf_amd.guidance.sd_nets import GroupNorm, norm_act_conv
