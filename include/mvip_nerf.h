@@ -216,6 +216,16 @@ int mvip_sds_grad_dev(const float *eps_uncond, const float *eps_cond, const floa
                       void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a14-a16  bilinear resize, align_corners = False: F.interpolate(pred_rgb, (512, 512), mode='bilinear') in front of
+ * vae.encode (DS_NeRF/guidance/sd_utils.py:282-284, :449-452) and its adjoint.  x [planes, H, W] -> y [planes, OH, OW]
+ * with torch's source-index convention (scale = in/out, src = scale*(dst+0.5)-0.5 clamped at 0); the backward gathers
+ * (deterministic), dx [planes, H, W] = J^T dy. */
+int mvip_resize_bilinear(const float *x, int64_t planes, int64_t H, int64_t W, int64_t OH, int64_t OW, float *y,
+                         void *stream);
+int mvip_resize_bilinear_backward(const float *dy, int64_t planes, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                                  float *dx, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14-a16  GroupNorm (+ fused SiLU) of the SDS networks: the `norm -> silu -> conv` prologue of every
  * ResNet block inside vae.encode / unet (call sites DS_NeRF/guidance/sd_utils.py:148, :162, :189,
  * :212; the blocks themselves live in `diffusers`, absent from the reference tree -- published
@@ -304,6 +314,14 @@ int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias,
 int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
                         const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                         float *y, int cfg, void *stream);
+/* mvip_gemm_f16x3 with a caller-owned workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (0 for most shapes;
+ * workspace may then be NULL): launches with fewer workgroups than CUs and a long contraction (the UNet's 1280-channel
+ * transformer blocks at 16x16 and 8x8) are split over K, each workgroup writing raw partial sums, and a second launch
+ * adds the splits in index order and applies the epilogue. */
+int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, int64_t P);
+int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                       const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                       float *y, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a14-a16  transformer blocks of the SD UNet (unet(...) at DS_NeRF/guidance/sd_utils.py:390-403 and :240;

@@ -61,6 +61,8 @@ _SIGNATURES = {
     'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
     'mvip_sds_add_noise_dev': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_sds_grad_dev': (_int, [_c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_resize_bilinear': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_resize_bilinear_backward': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_groupnorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'mvip_groupnorm_forward': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _flt, _int, _int, _c_f, _c_f, _c_f, _c_f,
                                       _c_f]),
@@ -88,6 +90,8 @@ _SIGNATURES = {
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64]),
+    'mvip_gemm_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
     'mvip_attention_supported': (_int, [_i64]),
     'mvip_attention_v_bytes': (_i64, [_i64, _i64, _i64, _i64]),

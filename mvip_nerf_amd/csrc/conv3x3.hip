@@ -482,6 +482,10 @@ struct GemmArgs {
     // writes value * gelu(gate) as [N][M/2][P], zero for columns >= geglu_L, and collects the absolute maximum
     int geglu_L;                 // 0: plain epilogue
     unsigned *absmax_bits;
+    // split-K (gemm_f16x3_kernel only; partial != nullptr): workgroup `split` contracts stages [split*sks, (split+1)*sks)
+    // and writes raw accumulators to partial[split][n][M][P]; cv_split_reduce_kernel adds them in order
+    int splits, sks;
+    float *partial;
 #ifdef MVIP_EXPERIMENT_GEMM
     int dbg;                     // timing experiments: 1 = no epilogue stores, 2 = no MFMAs, 4 = no LDS reads either
 #endif
@@ -498,13 +502,16 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
     int id = blockIdx.x;
     const int total = gridDim.x;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int split = id % a.splits;
+    id /= a.splits;
     const int mb = id % a.MB;
     const int tile = id / a.MB;
     const int tp = tile % a.tiles;
     const int n = tile / a.tiles;
     const int64_t p0 = (int64_t)tp * GM_PIX;
     const int64_t plane = a.P * 16;
-    const char *xs_n = a.xs + (int64_t)n * a.CK * 4 * plane + (p0 + tid) * 16;
+    const int s0 = split * a.sks;                       // first stage (of GM_KC chunks) of this workgroup
+    const char *xs_n = a.xs + ((int64_t)n * a.CK + s0 * GM_KC) * 4 * plane + (p0 + tid) * 16;
 
     auto issue_input = [&](int s, int buf) {
 #pragma unroll
@@ -520,7 +527,7 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
             const int b = b0 + wave;
             if (b < GM_KC * MT * 2) {
                 const int hl = b & 1, m = (b >> 1) % MT, kc = (b >> 1) / MT;
-                glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + s * GM_KC + kc) * 2 + hl) * 1024) + lane * 16,
+                glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + (s0 + s) * GM_KC + kc) * 2 + hl) * 1024) + lane * 16,
                         lds_w + buf * WB + b * 1024);
             }
         }
@@ -534,7 +541,8 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
-    const int nstage = a.CK / GM_KC;
+    const int nall = a.CK / GM_KC;
+    const int nstage = (nall - s0 < a.sks) ? nall - s0 : a.sks;
     issue_input(0, 0);
     issue_weights(0, 0);
     for (int s = 0; s < nstage; ++s) {
@@ -608,10 +616,14 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
+                if (a.partial) {
+                    a.partial[(int64_t)split * a.N * a.M * a.P + o] = acc[m][j][r];
+                    continue;
+                }
                 float v = acc[m][j][r] * inv;
                 if (a.bias) v += a.bias[row];
                 if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
-                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
                 if (a.residual) v += a.residual[o];
                 a.y[o] = v;
             }
@@ -963,10 +975,38 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     return check_launch();
 }
 
-// cfg: 0 = choose by shape, 1 = 32/64-row kernel, 2 = 128 x 256 tile, 3 = 128 x 128, 4 = 64 x 128 (timing switch)
-extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
-                                   const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                                   float *y, int cfg, void *stream) {
+// splits for the 32/64-row kernel: only grids under 3/4 of the chip, at least 16 stages (512 k) per workgroup -- with
+// shorter contractions the second launch costs more than the idle CUs did (measured, tools/gemm_bench.py: K = 640 at
+// 160 workgroups 15.7 -> 21.2 us with splits, K = 5120 at 80 workgroups 97.6 -> 46.4 us)
+static inline int gm_splits(int64_t blocks, int64_t nstage) {
+    static const int forced = [] { const char *e = getenv("MVIP_GEMM_SPLITS"); return e ? atoi(e) : 0; }();   // tuning
+    int64_t s = forced > 0 ? forced : (blocks >= 192 ? 1 : (384 + blocks - 1) / blocks);
+    if (s > nstage / 16) s = nstage / 16;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    const int64_t sks = (nstage + s - 1) / s;
+    return (int)((nstage + sks - 1) / sks);
+}
+static inline int gm_auto_cfg(int64_t N, int64_t M, int64_t P) {
+    // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
+    // (10..40 stages) every tile shape lands within ~10 % of the 32/64-row kernel -- these launches are bound by
+    // the per-workgroup prologue / epilogue and by grid quantisation, not by operand traffic -- and the square
+    // tile only wins once M is large enough for several full waves of workgroups (the 1280-wide GEGLU projection).
+    return (M % 128 == 0 && M >= 8192 && (M / 128) * N * (P / 256) >= 128) ? 2 : 1;
+}
+
+extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, int64_t P) {
+    if (N <= 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return 0;
+    if (gm_auto_cfg(N, M, P) != 1) return 0;
+    const int64_t tiles = P / GM_PIX;
+    const int MT = cv_mt(M, N * tiles);
+    const int s = gm_splits(N * tiles * (M / (32 * MT)), K / 32);
+    return s > 1 ? (int64_t)s * N * M * P * 4 : 0;
+}
+
+static int gemm_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                       const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                       float *y, int cfg, void *workspace, void *stream) {
     if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
@@ -976,17 +1016,13 @@ extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const flo
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
     a.geglu_L = 0; a.absmax_bits = nullptr;
+    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = cfg >> 8; cfg &= 255;
 #endif
     hipStream_t st = as_stream(stream);
-    if (cfg == 0) {
-        // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
-        // (10..40 stages) every tile shape lands within ~10 % of the 32/64-row kernel -- these launches are bound by
-        // the per-workgroup prologue / epilogue and by grid quantisation, not by operand traffic -- and the square
-        // tile only wins once M is large enough for several full waves of workgroups (the 1280-wide GEGLU projection).
-        cfg = (M % 128 == 0 && M >= 8192 && (M / 128) * N * (P / 256) >= 128) ? 2 : 1;
-    }
+    const bool auto_cfg = cfg == 0;
+    if (cfg == 0) cfg = gm_auto_cfg(N, M, P);
     if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
     if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
     if (cfg == 2) {
@@ -1002,7 +1038,12 @@ extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const flo
         a.tiles = (int)(P / GM_PIX);
         const int MT = cv_mt(M, N * a.tiles);
         a.MB = (int)(M / (32 * MT));
-        const int64_t blocks = N * a.tiles * a.MB;
+        int64_t blocks = N * a.tiles * a.MB;
+        if (workspace && auto_cfg) {
+            a.splits = gm_splits(blocks, K / 32);
+            if (a.splits > 1) { a.sks = (int)((K / 32 + a.splits - 1) / a.splits); a.partial = (float *)workspace; }
+        }
+        blocks *= a.splits;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
         if (MT == 4)
             hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -1010,14 +1051,36 @@ extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const flo
             hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if (a.partial) {
+            const int64_t total = N * M * P;
+            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
+                               a.splits, total, (int)M, P, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+        }
     }
     return check_launch();
+}
+
+// cfg: 0 = choose by shape, 1 = 32/64-row kernel, 2 = 128 x 256 tile, 3 = 128 x 128, 4 = 64 x 128 (timing switch)
+extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                   const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                                   float *y, int cfg, void *stream) {
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, cfg, nullptr, stream);
 }
 
 extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                                float *y, void *stream) {
-    return mvip_gemm_f16x3_cfg(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, stream);
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, nullptr, stream);
+}
+
+// mvip_gemm_f16x3 with a caller-owned workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (null when that is 0):
+// launches with fewer than one workgroup per CU and a long contraction (the 1280-channel transformer blocks at 16 x 16:
+// 80 workgroups x 160 stages) are split over K and summed by a second launch, in index order.
+extern "C" int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                  const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                                  float *y, void *workspace, void *stream) {
+    if (!workspace && mvip_gemm_workspace_bytes(N, K, M, P) > 0) return MVIP_EINVAL;
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, workspace, stream);
 }
 
 // First projection of the transformer feed-forward with the GEGLU fused into the epilogue:
@@ -1039,6 +1102,7 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = out;
         a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
         a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word;
+        a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
         hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -52,9 +52,107 @@ __global__ void sds_grad_dev_kernel(const float *__restrict__ eu, const float *_
     grad[i] = nan_to_num(g);
 }
 
+// ---- bilinear resize, align_corners = False (the F.interpolate in front of vae.encode, DS_NeRF/guidance/sd_utils.py:282-284)
+// torch's convention: scale = in / out (float), src = scale * (dst + 0.5) - 0.5 clamped at 0, i0 = (int)src,
+// i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap resize_tap(int dst, float scale, int in) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Tap t;
+    t.i0 = (int)src;
+    if (t.i0 > in - 1) t.i0 = in - 1;
+    t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.f - t.l1;
+    return t;
+}
+
+__global__ void resize_bilinear_fwd_kernel(const float *__restrict__ x, int64_t planes, int H, int W, int OH, int OW,
+                                           float *__restrict__ y) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= planes * OH * OW) return;
+    const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH);
+    const int64_t pl = idx / ((int64_t)OW * OH);
+    const Tap ty = resize_tap(oy, (float)H / (float)OH, H), tx = resize_tap(ox, (float)W / (float)OW, W);
+    const float *xp = x + pl * H * W;
+    const float top = tx.l0 * xp[(int64_t)ty.i0 * W + tx.i0] + tx.l1 * xp[(int64_t)ty.i0 * W + tx.i1];
+    const float bot = tx.l0 * xp[(int64_t)ty.i1 * W + tx.i0] + tx.l1 * xp[(int64_t)ty.i1 * W + tx.i1];
+    y[idx] = ty.l0 * top + ty.l1 * bot;
+}
+
+// Adjoint as a GATHER (deterministic; torch scatters with atomics): input pixel (iy, ix) collects every output pixel
+// whose taps touch it.  The candidate range of output rows / columns comes from inverting src(dst) with a margin and
+// every candidate is then tested with the forward's own tap computation.
+__device__ __forceinline__ void resize_range(int i, float scale, int out, int &lo, int &hi) {
+    const float inv = 1.f / scale;
+    lo = (int)floorf(((float)i - 1.0f + 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.0f + 0.5f) * inv - 0.5f) + 1;
+    if (i == 0) lo = 0;                                  // src is clamped at 0: every dst below maps here
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+__global__ void resize_bilinear_bwd_kernel(const float *__restrict__ dy, int64_t planes, int H, int W, int OH, int OW,
+                                           float *__restrict__ dx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const int ix = (int)(idx % W), iy = (int)((idx / W) % H);
+    const int64_t pl = idx / ((int64_t)W * H);
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    int y0, y1, x0, x1;
+    resize_range(iy, sy, OH, y0, y1);
+    resize_range(ix, sx, OW, x0, x1);
+    const float *dp = dy + pl * OH * OW;
+    float acc = 0.f;
+    for (int oy = y0; oy <= y1; ++oy) {
+        const Tap ty = resize_tap(oy, sy, H);
+        float wy = 0.f;
+        if (ty.i0 == iy) wy += ty.l0;
+        if (ty.i1 == iy) wy += ty.l1;
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = x0; ox <= x1; ++ox) {
+            const Tap tx = resize_tap(ox, sx, W);
+            float wx = 0.f;
+            if (tx.i0 == ix) wx += tx.l0;
+            if (tx.i1 == ix) wx += tx.l1;
+            if (wx != 0.f) row += wx * dp[(int64_t)oy * OW + ox];
+        }
+        acc += wy * row;
+    }
+    dx[idx] = acc;
+}
+
 }  // namespace mvip
 
 using namespace mvip;
+
+extern "C" int mvip_resize_bilinear(const float *x, int64_t planes, int64_t H, int64_t W, int64_t OH, int64_t OW, float *y,
+                                    void *stream) {
+    if (planes < 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || H > (1 << 20) || W > (1 << 20) || OH > (1 << 20) ||
+        OW > (1 << 20))
+        return MVIP_EINVAL;
+    if (planes == 0) return MVIP_OK;
+    if (!x || !y) return MVIP_EINVAL;
+    const int64_t n = planes * OH * OW;
+    hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                       planes, (int)H, (int)W, (int)OH, (int)OW, y);
+    return check_launch();
+}
+
+extern "C" int mvip_resize_bilinear_backward(const float *dy, int64_t planes, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                                             float *dx, void *stream) {
+    if (planes < 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || H > (1 << 20) || W > (1 << 20) || OH > (1 << 20) ||
+        OW > (1 << 20))
+        return MVIP_EINVAL;
+    if (planes == 0) return MVIP_OK;
+    if (!dy || !dx) return MVIP_EINVAL;
+    const int64_t n = planes * H * W;
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), dy,
+                       planes, (int)H, (int)W, (int)OH, (int)OW, dx);
+    return check_launch();
+}
 
 extern "C" int mvip_sds_add_noise_dev(const float *x0, const float *noise, const float *scal, int64_t n,
                                       float *latents, void *stream) {

@@ -62,6 +62,15 @@ class _AddNoise(torch.autograd.Function):
         return g * ctx.sa, None, None, None
 
 
+def _resize_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) (DS_NeRF/guidance/sd_utils.py:282-284): the HIP
+    kernel pair for fp32 device tensors, the torch op for anything else (CPU tensors in host-side tests)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        from .. import ops
+        return ops.resize_bilinear(x, size)
+    return F.interpolate(x, size, mode='bilinear', align_corners=False)
+
+
 def sds_grad(eps_uncond, eps_cond, noise, guidance_scale, w, accumulate_into=None):
     """nan_to_num([accumulate_into +] w * (e_u + s (e_c - e_u) - noise)) in one HIP kernel."""
     eu = eps_uncond.contiguous().float()
@@ -231,13 +240,14 @@ class StableDiffusion(nn.Module):
     def _prepare(self, pred, mask, prompt, guidance_scale):
         """Steps 0-4 of the reference step methods up to (not including) prepare_latents."""
         latent_size = 512
-        pred = F.interpolate(pred, (latent_size, latent_size), mode='bilinear', align_corners=False)
-        mask = F.interpolate(torch.abs(mask), (latent_size, latent_size), mode='bilinear', align_corners=False)
+        pred = _resize_bilinear(pred, (latent_size, latent_size))
+        mask = _resize_bilinear(torch.abs(mask), (latent_size, latent_size))
         cfg = guidance_scale > 1.0
         prompt_embeds = self.networks.encode_prompt(prompt, cfg)
         masked_image = pred[:, :3, :, :] * (mask < 0.5)
         init_image = pred[:, :3, :, :]
-        mask64 = F.interpolate(mask, size=(latent_size // 8, latent_size // 8)).to(prompt_embeds.dtype)
+        # F.interpolate(mask, size=(64, 64)) is mode='nearest': source index floor(dst * 512 / 64) = 8 * dst
+        mask64 = mask[:, :, ::8, ::8].contiguous().to(prompt_embeds.dtype)
         masked_image_latents = self._encode_vae_image(masked_image)                  # randn draw 1
         if cfg:
             mask64 = torch.cat([mask64] * 2)

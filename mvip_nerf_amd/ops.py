@@ -461,6 +461,31 @@ def normal_fit(points, k=31):
 _GN_DTYPES = {torch.float32: 0, torch.float16: 1}
 
 
+class _ResizeBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        xc = _f32c(x)
+        N, C, H, W = xc.shape
+        y = torch.empty((N, C, OH, OW), device=xc.device, dtype=torch.float32)
+        call('mvip_resize_bilinear', ptr(xc), N * C, H, W, OH, OW, ptr(y), stream())
+        ctx.shape = (N, C, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW = ctx.shape
+        dyc = _f32c(dy)
+        dx = torch.empty((N, C, H, W), device=dyc.device, dtype=torch.float32)
+        call('mvip_resize_bilinear_backward', ptr(dyc), N * C, H, W, OH, OW, ptr(dx), stream())
+        return dx, None, None
+
+
+def resize_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) for [N, C, H, W] fp32 device tensors (the resize in
+    front of vae.encode, DS_NeRF/guidance/sd_utils.py:282-284), differentiable w.r.t. x."""
+    return _ResizeBilinear.apply(x, int(size[0]), int(size[1]))
+
+
 def _gn_workspace(N, C, HW, device):
     nbytes = int(_lib.load().mvip_groupnorm_workspace_bytes(N, C, HW))
     return torch.empty(max(nbytes // 8, 1), device=device, dtype=torch.float64)
@@ -790,8 +815,14 @@ GEMM_CFG = 0       # 0: tile chosen by shape; 1..4 force a workgroup tile (A/B t
 def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None):
     """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P]."""
     y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
-    call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
-         ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), stream())
+    if GEMM_CFG:
+        call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
+             ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), stream())
+        return y
+    nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))            # split-K partial sums (few shapes)
+    ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
+    call('mvip_gemm_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
+         ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), stream())
     return y
 
 

@@ -115,6 +115,30 @@ def test_sds_elementwise_kernels(cuda):
     np.testing.assert_allclose(N(x0.grad), 0.8, rtol=1e-6)
 
 
+@pytest.mark.parametrize('shape,size', [((1, 3, 378, 504), (512, 512)), ((1, 4, 567, 1008), (512, 512)),
+                                        ((2, 1, 20, 28), (512, 512)), ((1, 3, 600, 512), (512, 512)),
+                                        ((1, 2, 7, 5), (3, 11)), ((1, 1, 1, 9), (4, 4))])
+def test_resize_bilinear_vs_torch(cuda, shape, size):
+    """ops.resize_bilinear (the resize in front of vae.encode) and its gather-form adjoint vs F.interpolate and its
+    autograd on the same device tensors; fp32 with the same source-index arithmetic, so agreement is to rounding."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + size[1])
+    x = torch.randn(shape, generator=g).to(cuda)
+    dy = torch.randn(shape[:2] + size, generator=g).to(cuda)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xr, size, mode='bilinear', align_corners=False)
+    ref.backward(dy)
+    xh = x.clone().requires_grad_(True)
+    got = ops.resize_bilinear(xh, size)
+    got.backward(dy)
+    np.testing.assert_allclose(N(got), N(ref), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N(xh.grad), N(xr.grad), rtol=0, atol=2e-5 * max(1.0, float(xr.grad.abs().max())))
+    # adjoint identity <J x, dy> = <x, J^T dy> in fp64
+    lhs = float((got.detach().double() * dy.double()).sum())
+    rhs = float((x.double() * xh.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
 def test_pretrain_model_dispatch(cuda):
     """cal_loss sums the enabled terms in the reference's order and gates colla on i>0, normal on i>normal_start."""
     from mvip_nerf_amd.nerf.utils import Pretrain_Model
@@ -308,6 +332,21 @@ def test_gemm_f16x3(cuda):
     y2 = ops.gemm_f16x3(xs, ops.gemm_pack_a(At, M, K, 1, M), 1, K, M, P)
     ref2 = A.double() @ X[0].double()
     np.testing.assert_allclose(N(y2[0]), ref2.float().numpy(), rtol=0, atol=1e-3 * float(ref2.abs().max()))
+    # a long contraction on a small grid: the library splits K over workgroups (1280-channel blocks at 16 x 16)
+    M, K, P = 160, 1376, 256
+    assert ops._lib.load().mvip_gemm_workspace_bytes(2, K, M, P) > 0
+    A = torch.randn(M, K, generator=g) * 0.05
+    X = torch.randn(2, K, P, generator=g)
+    bias, ca = torch.randn(M, generator=g), torch.randn(2, M, generator=g)
+    res = torch.randn(2, M, P, generator=g)
+    ref = (torch.einsum('mk,nkp->nmp', A.double(), X.double()) + bias.double()[None, :, None] + ca.double()[:, :, None]
+           + res.double())
+    Xd = X.to(cuda)
+    s2 = ops.absmax_scale(Xd)
+    xs = ops.split_planes_strided(Xd, 2, K, P, K * P, P, 1, s2)
+    y = ops.gemm_f16x3(xs, ops.gemm_pack_a(A.to(cuda), M, K, K, 1), 2, K, M, P, bias=bias.to(cuda), chan_add=ca.to(cuda),
+                       residual=res.to(cuda), x_scale2=s2)
+    np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
 
 
 def test_vae_attention_vs_fp64(cuda):
