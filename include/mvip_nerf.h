@@ -138,6 +138,10 @@ int mvip_mlp_forward_rays_stash(const float *packed, const float *rows, const fl
                                 int S, float *raw, float *stash, int precision, void *stream);
 int mvip_mlp_forward_points_stash(const float *packed, const float *pts, const float *dirs, int64_t P,
                                   float *raw, float *stash, int precision, void *stream);
+/* mvip_mlp_forward_rays_stash (precision 0) on the two-waves-per-SIMD kernel: `packed16` from mvip_mlp_pack16, the
+ * stash layout and size are the same, so mvip_mlp_backward_stash (given the 32-point `packed` image) consumes it. */
+int mvip_mlp_forward_rays_stash16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
+                                  float *raw, float *stash, void *stream);
 int mvip_mlp_backward_stash(const float *packed, const float *stash, int64_t P, const float *d_raw,
                             float *const *grads_host, void *workspace, int64_t tile_points,
                             int precision, void *stream);

@@ -270,7 +270,7 @@ struct ConvArgs {
 // at 16 x 16 x 2 images: 80 workgroups, at 8 x 8: 40) while one layer's weights are 59-118 MB, so those layers are bound by
 // how many CUs pull weights at once; with a.partial set the channel range is divided over a.splits workgroups.
 template <int MT, int TW = CV_TW, int NW = 4>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
     constexpr int NT = NW * 64;
     constexpr int TH = NT / TW, HW = TW + 2, RPB = 32 / TW;                         // RPB: image rows per column block
     constexpr int PIX = TW == 8 ? 4 * 10 * HW : (TH + 2) * HW;
@@ -904,12 +904,17 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
     if (tw == CV_TW && wide_mode && H % 16 == 0) {
         const int64_t tiles16 = N * (W / CV_TW) * (H / 16);
-        const int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
+        int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
+        // MVIP_CONV_WIDE=2: 128 rows x 512 pixels per eight-wave workgroup (one per CU, two waves per SIMD, 128
+        // accumulator registers per wave): 12 fragment reads per 24 MFMAs instead of 16
+        if (wide_mode == 2 && Cout % 128 == 0 && tiles16 * (Cout / 128) >= 200) mtw = 4;
         if (mtw) {
             a.tilesY = (int)(H / 16); a.MB = (int)(Cout / (32 * mtw));
             const int64_t wb = tiles16 * a.MB;
             if (wb > 0x7fffffffLL) return MVIP_EINVAL;
-            if (mtw == 2)
+            if (mtw == 4)
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
+            else if (mtw == 2)
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
             else
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);

@@ -16,9 +16,12 @@
 // The packed image stores the matching A operands: block (to, ti) = 64 lanes x 4 floats, lane (m, g) holds
 // W[16 to + m][16 ti + 4g + 0..3], i.e. four consecutive input units: one ds_read_b128 feeds four MFMAs.
 // Blocks are streamed layer by layer, output tile by output tile: a 256-wide layer is 16 chunks of 16 KB.
-// Forward only (no stash): training keeps the 32-point kernels, whose stash layout the backward shares.
+// STASH = true is the training forward: every activation tile is also written to the stash the backward kernels read
+// ([row tile of 32 units][point tile of 32][32][32] fp32, mlp_device.h) -- a wave's 16 x 16 tile is four stores of four
+// 64-byte row segments, the two waves that share a point tile filling the other half of each 128-byte row.
 #include "common.h"
 #include "mlp_layout.h"
+#include "mlp_device.h"
 #include <type_traits>
 
 namespace mvip {
@@ -153,10 +156,10 @@ __device__ __forceinline__ float enc_channel(float x, float y, float z, int c) {
     return val;
 }
 
-template <bool FROM_RAYS>
+template <bool FROM_RAYS, bool STASH = false>
 __global__ void __launch_bounds__(512, 2)
 mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__ in_a, const float *__restrict__ in_b,
-                     int64_t P, int S, float *__restrict__ raw) {
+                     int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash = nullptr, int64_t n_pt = 0) {
     __shared__ __attribute__((aligned(16))) float lds[LDS16_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -192,6 +195,22 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) edir[t][i] = enc_channel<27>(vx, vy, vz, 16 * t + 4 * g + i);
 
+    // stash: 16-unit tile `t16` (two per 32-unit row tile) of this wave's 16 points -> rows 16 (t16 & 1) + 4 g + i of the
+    // block (row tile t16 >> 1, point tile 4 blockIdx + wave / 2), columns 16 (wave & 1) + n.  The block address is
+    // wave-uniform (scalar base), the lane part a constant.
+    const int64_t pt_wave = (int64_t)blockIdx.x * 4 + (wave >> 1);
+    const int stash_lane = (4 * g) * 32 + 16 * (wave & 1) + n;
+    auto stash16 = [&](int t16, const f32x4 &t) {
+        if constexpr (STASH) {
+            float *q = stash + ((int64_t)(t16 >> 1) * n_pt + pt_wave) * 1024 + (t16 & 1) * 512 + stash_lane;
+            q[0] = t[0]; q[32] = t[1]; q[64] = t[2]; q[96] = t[3];
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) stash16(2 * AT_EMB + t, emb[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) stash16(2 * AT_EDIR + t, edir[t]);
+
     __syncthreads();                                   // chunks 0, 1 and section B have landed
     const float *sb = lds + RING16_FLOATS;
     f32x4 a = st.read_block<0>();
@@ -199,21 +218,21 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
 
     // layer 0: 63(+1) -> 256
     layer16<OFF_L0, 16, NTI_L0, false>(st, a, sb + SB_BIAS, [&](auto ti) { return emb[ti.value]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); stash16(2 * AT_H + to.value, o[to.value]); });
 #pragma unroll
     for (int t = 0; t < 16; ++t) h[t] = o[t];
     // layers 1..4
     static_for<4>([&](auto li) {
         constexpr int l = 1 + decltype(li)::value;
         layer16<OFF_L1 + (l - 1) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
-            [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
+            [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); stash16(2 * (AT_H + 8 * l) + to.value, o[to.value]); });
 #pragma unroll
         for (int t = 0; t < 16; ++t) h[t] = o[t];
     });
     // layer 5: cat[encoded point (64), h4 (256)] -> 256
     layer16<OFF_L5, 16, NTI_L5, false>(st, a, sb + SB_BIAS + 5 * 256,
         [&](auto ti) { if constexpr (ti.value < 4) return emb[ti.value]; else return h[ti.value - 4]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); stash16(2 * (AT_H + 40) + to.value, o[to.value]); });
 #pragma unroll
     for (int t = 0; t < 16; ++t) h[t] = o[t];
     // layers 6, 7; sigma = alpha_linear(h7) is accumulated tile by tile in layer 7's epilogue (one weight quad
@@ -224,6 +243,7 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
         layer16<OFF_L6 + (l - 6) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
             [&](auto to, const f32x4 &acc) {
                 o[to.value] = act16<true>(acc);
+                stash16(2 * (AT_H + 8 * l) + to.value, o[to.value]);
                 if constexpr (l == 7) {
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(sb + SB_WALPHA + 16 * to.value + 4 * g);
 #pragma unroll
@@ -238,7 +258,7 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     sigma += sb[SB_BALPHA];
     // feature = feature_linear(h7), no activation
     layer16<OFF_FEAT, 16, NTI_LH, false>(st, a, sb + SB_BFEAT, [&](auto ti) { return h[ti.value]; },
-        [&](auto to, const f32x4 &acc) { o[to.value] = act16<false>(acc); });
+        [&](auto to, const f32x4 &acc) { o[to.value] = act16<false>(acc); stash16(2 * AT_FEAT + to.value, o[to.value]); });
     // view branch: cat[feature (256), encoded dir (27+5)] -> 128, relu
     // rgb = rgb_linear(v), accumulated in the view layer's epilogue
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
@@ -246,6 +266,7 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
         [&](auto ti) { if constexpr (ti.value < 16) return o[ti.value]; else return edir[ti.value - 16]; },
         [&](auto to, const f32x4 &acc) {
             const f32x4 v = act16<true>(acc);
+            stash16(2 * AT_V + to.value, v);
             const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 16 * to.value + 4 * g);
             const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 128 + 16 * to.value + 4 * g);
             const f32x4 w2 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 256 + 16 * to.value + 4 * g);
@@ -322,6 +343,20 @@ extern "C" int mvip_mlp_forward_rays16(const float *packed16, const float *rows,
     const int64_t P = B * S;
     hipLaunchKernelGGL((mlp_forward16_kernel<true>), dim3((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), dim3(512), 0,
                        as_stream(stream), packed16, rows, z, P, S, raw);
+    return check_launch();
+}
+
+// Training forward on the two-wave kernel: raw AND the activation stash of mvip_mlp_stash_floats(B*S) floats that
+// mvip_mlp_backward_stash consumes (same layout as mvip_mlp_forward_rays_stash writes; precision 0 only).
+extern "C" int mvip_mlp_forward_rays_stash16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
+                                             float *raw, float *stash, void *stream) {
+    if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!packed16 || !rows || !z || !raw || !stash) return MVIP_EINVAL;
+    const int64_t P = B * S;
+    const int64_t wgs = (P + WG_POINTS - 1) / WG_POINTS;
+    hipLaunchKernelGGL((mlp_forward16_kernel<true, true>), dim3((unsigned)wgs), dim3(512), 0, as_stream(stream), packed16,
+                       rows, z, P, S, raw, stash, wgs * 4);
     return check_launch();
 }
 

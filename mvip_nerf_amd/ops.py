@@ -220,13 +220,16 @@ class _MLPRays(torch.autograd.Function):
     """raw[B,S,4] = MLP(enc(o + d z), enc(viewdir)); gradients flow to the 24 parameters only."""
 
     @staticmethod
-    def forward(ctx, rows, z, packed, precision, *params):
-        """`packed` is the weight image of `precision` (0: fp32 image, 1: f16x3 image)."""
+    def forward(ctx, rows, z, packed, precision, packed16, *params):
+        """`packed` is the weight image of `precision` (0: fp32 image, 1: f16x3 image); `packed16` (precision 0 only,
+        optional) the image of the two-waves-per-SIMD kernel, which then runs the stash-writing forward."""
         B, S = z.shape
         raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
         stash = _take_stash(B * S, z.device)
         if stash is None:
             call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), precision, stream())
+        elif packed16 is not None and precision == 0:
+            call('mvip_mlp_forward_rays_stash16', ptr(packed16), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), stream())
         else:
             call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), precision,
                  stream())
@@ -248,7 +251,7 @@ class _MLPRays(torch.autograd.Function):
             call('mvip_mlp_backward_stash', ptr(packed), ptr(stash), B * S, ptr(_f32c(d_raw)),
                  _lib.ptr_array(grads), ptr(ws), BWD_TILE_POINTS, ctx.precision, stream())
             del stash
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class _MLPPoints(torch.autograd.Function):
@@ -271,17 +274,18 @@ class _MLPPoints(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, train16=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
     routes the gradients back to them; with no grad needed the Function is skipped.
     `packed_f16x3` selects the split-precision kernel (precision = 1) for no-grad calls,
     `train_f16x3` (the same kind of image) for calls that will be back-propagated, `packed16` the exact-fp32
-    two-waves-per-SIMD inference kernel (no-grad calls at precision 0)."""
+    two-waves-per-SIMD inference kernel (no-grad calls at precision 0), `train16` the same image for the stash-writing
+    training forward at precision 0."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
-            return _MLPRays.apply(rows, z, train_f16x3, 1, *params)
-        return _MLPRays.apply(rows, z, packed, 0, *params)
+            return _MLPRays.apply(rows, z, train_f16x3, 1, None, *params)
+        return _MLPRays.apply(rows, z, packed, 0, train16, *params)
     B, S = z.shape
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
     if packed_f16x3 is not None:

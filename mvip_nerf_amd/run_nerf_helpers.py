@@ -74,6 +74,7 @@ class NeRF(nn.Module):
         self._packed_w16 = None
         self._packed_w16_key = None
         self.two_wave_inference = True    # no-grad fp32 forwards use csrc/mlp_fwd16.hip (two waves per SIMD)
+        self.two_wave_training = True     # ... and so does the stash-writing fp32 training forward from ray rows
         # 0: exact fp32 MFMA.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative, fp32 accumulate).
         self.inference_precision = 0  # forward passes that need no gradient (rendering)
         self.train_precision = 0      # stash-writing forward, delta and weight-gradient kernels
@@ -141,6 +142,10 @@ class NeRF(nn.Module):
         no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
         return self.packed_w16() if (self.two_wave_inference and no_grad and self.inference_precision == 0) else None
 
+    def _train16(self):
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return self.packed_w16() if (self.two_wave_training and grad and self.train_precision == 0) else None
+
     def _fast_image(self):
         return self.packed_f16x3() if self.inference_precision == 1 else None
 
@@ -153,7 +158,7 @@ class NeRF(nn.Module):
 
     def query_rays(self, rows, z):
         return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
-                            self._infer16())
+                            self._infer16(), self._train16())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

@@ -487,3 +487,39 @@ def test_mlp_forward_two_waves_per_simd_kernel(golden, cuda):
         r16 = ops.mlp_rays(rows, z, packed, ps, packed16=p16)
         r32 = ops.mlp_rays(rows, z, packed, ps)
     np.testing.assert_allclose(N(r16), N(r32), rtol=2e-5, atol=2e-6)
+
+
+def test_two_wave_training_forward_stash(golden, cuda):
+    """The stash-writing training forward on the two-waves-per-SIMD kernel (mvip_mlp_forward_rays_stash16) against the
+    32-point stash-writing kernel through the C ABI: raw and EVERY stash element (same layout, so the buffers compare
+    element by element; the two kernels sum in different orders, hence a tolerance), then the 24 parameter gradients
+    through the shared backward kernels (rel-L2: single ReLU gates flip between the two forwards), at ray counts that
+    leave partly filled workgroups."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd._lib import ptr, stream, call
+    g = golden('mlp_fwd_bwd')
+    for B in (37, 130, 5):
+        ps = [p.clone().requires_grad_(True) for p in params_dev(g['seed'], cuda)]
+        packed = ops.mlp_pack(ps)
+        p16 = ops.mlp_pack16(ps, packed)
+        rows = torch.from_numpy(bench_like_rays(B, seed=3 + B)).float().to(cuda)
+        z = ops.stratified_z(rows, 64, True)
+        n_stash = int(_lib.load().mvip_mlp_stash_floats(B * 64))
+        st32 = torch.full((n_stash,), 7.0, device=cuda)
+        st16 = torch.full((n_stash,), 7.0, device=cuda)
+        raw32, raw16 = torch.empty(B, 64, 4, device=cuda), torch.empty(B, 64, 4, device=cuda)
+        call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, 64, ptr(raw32), ptr(st32), 0, stream())
+        call('mvip_mlp_forward_rays_stash16', ptr(p16), ptr(rows), ptr(z), B, 64, ptr(raw16), ptr(st16), stream())
+        np.testing.assert_allclose(N(raw16), N(raw32), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(N(st16), N(st32), rtol=2e-5, atol=2e-6)
+        d_raw = torch.randn(B, 64, 4, generator=torch.Generator().manual_seed(B)).to(cuda)
+        out = {}
+        for name, t16 in (('two_wave', p16), ('one_wave', None)):
+            for p in ps:
+                p.grad = None
+            raw = ops.mlp_rays(rows, z, packed, ps, train16=t16)
+            raw.backward(d_raw)
+            out[name] = (N(raw), [N(p.grad) for p in ps])
+        np.testing.assert_allclose(out['two_wave'][0], out['one_wave'][0], rtol=2e-5, atol=2e-6)
+        for a_, b_ in zip(out['two_wave'][1], out['one_wave'][1]):
+            assert np.linalg.norm(a_ - b_) <= 1e-2 * np.linalg.norm(b_)

@@ -2,7 +2,7 @@
 0 = four-wave 8x32 tiles) on the VAE / UNet shapes and on the whole SDS step; one process per setting."""
 import json, os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
-for wide in ('0', '1'):
+for wide in (os.environ.get('MVIP_AB_MODES', '0,1').split(',')):
     env = dict(os.environ, MVIP_CONV_WIDE=wide)
     r = subprocess.run([sys.executable, os.path.join(here, 'conv_bench.py')], env=env, capture_output=True, text=True)
     for l in r.stdout.splitlines():
