@@ -39,6 +39,11 @@ int mlp_delta_f16x3_launch(const float *image_t16, const float *secb, const floa
                            const float *act, int64_t act_n_pt, int64_t act_pt0, float *gst, int64_t n_pt,
                            void *stream);
 
+// two-waves-per-SIMD delta kernel (precision 0), mlp_bwd16.hip
+int mlp_delta16_prepare(const float *packed, float *image_t16, void *stream);
+int mlp_delta16_launch(const float *image_t16, const float *secb, const float *d_raw, int64_t p0, int64_t pc,
+                       const float *act, int64_t act_n_pt, int64_t act_pt0, float *gst, int64_t n_pt, void *stream);
+
 // ------------------------------------------------------------------------------------------------
 // transposed weight image for B1
 // stream order: views^T (feature part), feature^T, then layers 7,6,5(h4 part),4,3,2,1 transposed
@@ -637,7 +642,11 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
     float *act_ws = ws + T_FLOATS + TABLE_FLOATS;
     float *gst = act_ws + (int64_t)AT_TILES * n_pt_max * TILE_FLOATS;
     // precision 1: `packed` is the f16x3 image; the transposed image is rebuilt from it (hi+lo is exact)
+    // exact fp32: the 16-points-per-wave delta kernel with two waves per SIMD (MVIP_DELTA16=0 selects the 32-point one;
+    // A-B switch, same results up to summation order)
+    static const bool delta16 = [] { const char *e = getenv("MVIP_DELTA16"); return e ? atoi(e) != 0 : true; }();
     if (precision == 1) { int rc = mlp_delta_f16x3_prepare(packed, packed_t, stream); if (rc != MVIP_OK) return rc; }
+    else if (delta16) { int rc = mlp_delta16_prepare(packed, packed_t, stream); if (rc != MVIP_OK) return rc; }
     else hipLaunchKernelGGL(mlp_pack_transposed_kernel, dim3((T_FLOATS + 255) / 256), dim3(256), 0, s, packed, packed_t);
     const GemmTable tab = make_table(grads_host);
     hipLaunchKernelGGL(mlp_wgrad_table_kernel, dim3(1), dim3(64), 0, s, tab, tab_dev);
@@ -663,6 +672,9 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         if (precision == 1) {
             int rc = mlp_delta_f16x3_launch(packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act, act_n_pt, act_pt0, gst,
                                             n_pt, stream);
+            if (rc != MVIP_OK) return rc;
+        } else if (delta16) {
+            int rc = mlp_delta16_launch(packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act, act_n_pt, act_pt0, gst, n_pt, stream);
             if (rc != MVIP_OK) return rc;
         } else
             hipLaunchKernelGGL(mlp_delta_kernel, grid1, block, 0, s, packed_t, packed + SEC_A_FLOATS, d_raw, p0, pc, act,
