@@ -302,6 +302,19 @@ int64_t mvip_gemm_packed_bytes(int64_t M, int64_t K);
 int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t sm, int64_t sk, void *packed, void *stream);
 int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc, int64_t sp,
                               const float *scale2, void *xs, void *stream);
+/* General convolution as this GEMM -- the stride-2 down-samplers of the UNet and the VAE encoder and the layers with 3,
+ * 4, 8 or 9 channels (conv_in, conv_out, quant_conv; DS_NeRF/guidance/sd_utils.py:207, :240), which do not fit the 3x3
+ * stride-1 kernel's operand tiles:
+ *   X_col[k = ci*KH*KW + ky*KW + kx][p = oy*OW + ox] = x[n][ci][oy*stride + ky - pad_top][ox*stride + kx - pad_left]
+ * is written directly as split planes [N][KP/16][2][2][PP][8] (KP >= Cin*KH*KW a multiple of 32, PP >= OH*OW a multiple
+ * of 256, zero filled), so y = mvip_gemm_f16x3(xs, pack(weight as [Cout][Cin*KH*KW]), ...) with K = KP, P = PP.
+ * Data gradient: col[N][KP][PP] = mvip_gemm_f16x3 with the transposed weight on dY's split planes, then
+ * mvip_col2im gathers dx[n][ci][iy][ix] (deterministic). */
+int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW, int stride,
+                             int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP, int64_t PP,
+                             const float *scale2, void *xs, void *stream);
+int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW, int stride, int pad_top,
+                int pad_left, int64_t OH, int64_t OW, int64_t KP, int64_t PP, float *dx, void *stream);
 int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                     const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                     float *y, void *stream);

@@ -91,6 +91,9 @@ _SIGNATURES = {
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_im2col_split_planes': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64,
+                                        _c_f, _c_f, _c_f]),
+    'mvip_col2im': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64]),
     'mvip_gemm_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),

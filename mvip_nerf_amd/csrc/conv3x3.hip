@@ -244,6 +244,82 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- general convolution as a GEMM: the strided and the narrow-channel layers -----------------------------------
+// (the three stride-2 down-samplers of the UNet and of the VAE encoder, conv_in / conv_out with 3, 4, 8 or 9 channels,
+// quant_conv: DS_NeRF/guidance/sd_utils.py:207, :240 -- none fits the 3x3 stride-1 kernel's 16 / 32-channel operand tiles)
+//   X_col[k = ci*KH*KW + ky*KW + kx][p = oy*OW + ox] = x[ci][oy*stride + ky - pad_top][ox*stride + kx - pad_left]
+// written DIRECTLY as fp16 hi/lo split planes [N][KP/16][2][2][PP][8] (KP, PP: K and P padded to the GEMM's multiples, zero
+// filled), so the convolution is mvip_gemm_f16x3 with the natural weight [Cout][Cin*KH*KW] as the A operand; the data
+// gradient is the GEMM with A^T into col[N][KP][PP] followed by the gather below.
+// grid (ceil(PP/256), N*KP/16): thread = output pixel, 16 consecutive k.
+__global__ void __launch_bounds__(256)
+cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int KH, int KW, int stride, int pad_top,
+                       int pad_left, int OH, int OW, int KP, int64_t PP, const float *__restrict__ scale2,
+                       uint4 *__restrict__ xs) {
+    const int CKP = KP / 16;
+    const int ck = (int)(blockIdx.y % CKP);
+    const int64_t n = blockIdx.y / CKP;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= PP) return;
+    const float s = scale2 ? scale2[0] : 1.f;
+    const int taps = KH * KW, K = Cin * taps;
+    const bool inside = p < (int64_t)OH * OW;
+    const int oy = inside ? (int)(p / OW) : 0, ox = inside ? (int)(p % OW) : 0;
+    const float *xn = x + n * Cin * H * W;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = ck * 16 + c;
+        float val = 0.f;
+        if (inside && k < K) {
+            const int ci = k / taps, t = k - ci * taps;
+            const int ky = t / KW, kx = t - ky * KW;
+            const int iy = oy * stride + ky - pad_top, ix = ox * stride + kx - pad_left;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = xn[((int64_t)ci * H + iy) * W + ix] * s;
+        }
+        v[c] = val;
+    }
+    uint4 *dst = xs + ((n * CKP + ck) * 4) * PP + p;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = v[kg * 8 + j];
+        uint4 hi, lo;
+        split8(t8, hi, lo);
+        dst[(kg * 2 + 0) * PP] = hi;
+        dst[(kg * 2 + 1) * PP] = lo;
+    }
+}
+
+// dx[n][ci][iy][ix] = sum over the (ky, kx) whose output pixel exists of col[n][ci*KH*KW + ky*KW + kx][oy*OW + ox]:
+// a gather (deterministic), one thread per input element
+__global__ void __launch_bounds__(256)
+cv_col2im_kernel(const float *__restrict__ col, int64_t total, int Cin, int H, int W, int KH, int KW, int stride,
+                 int pad_top, int pad_left, int OH, int OW, int KP, int64_t PP, float *__restrict__ dx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % W), iy = (int)((idx / W) % H);
+    const int ci = (int)((idx / ((int64_t)W * H)) % Cin);
+    const int64_t n = idx / ((int64_t)W * H * Cin);
+    const float *cn = col + n * KP * PP;
+    float acc = 0.f;
+    for (int ky = 0; ky < KH; ++ky) {
+        const int ty = iy + pad_top - ky;
+        if (ty < 0 || ty % stride != 0) continue;
+        const int oy = ty / stride;
+        if (oy >= OH) continue;
+        for (int kx = 0; kx < KW; ++kx) {
+            const int tx = ix + pad_left - kx;
+            if (tx < 0 || tx % stride != 0) continue;
+            const int ox = tx / stride;
+            if (ox >= OW) continue;
+            acc += cn[(int64_t)(ci * KH * KW + ky * KW + kx) * PP + (int64_t)oy * OW + ox];
+        }
+    }
+    dx[idx] = acc;
+}
+
 // ---- the convolution -------------------------------------------------------------------------------------
 struct ConvArgs {
     const char *xs, *wp, *zero16;
@@ -822,6 +898,35 @@ extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t H
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
                        nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, C * HW, HW, (int64_t)1);
+    return check_launch();
+}
+
+extern "C" int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW,
+                                        int stride, int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP,
+                                        int64_t PP, const float *scale2, void *xs, void *stream) {
+    if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
+        OH <= 0 || OW <= 0 || KP <= 0 || KP % 16 != 0 || KP < Cin * KH * KW || PP < OH * OW || H * W > (1 << 30) ||
+        OH * OW > (1 << 30))
+        return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!x || !xs || N * (KP / 16) > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((PP + 255) / 256), (unsigned)(N * (KP / 16)));
+    hipLaunchKernelGGL(cv_im2col_split_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)Cin, (int)H, (int)W, KH, KW,
+                       stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, scale2, (uint4 *)xs);
+    return check_launch();
+}
+
+extern "C" int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW, int stride,
+                           int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP, int64_t PP, float *dx,
+                           void *stream) {
+    if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
+        OH <= 0 || OW <= 0 || KP < Cin * KH * KW || PP < OH * OW || H * W > (1 << 30) || OH * OW > (1 << 30))
+        return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!col || !dx) return MVIP_EINVAL;
+    const int64_t total = N * Cin * H * W;
+    hipLaunchKernelGGL(cv_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), col, total,
+                       (int)Cin, (int)H, (int)W, KH, KW, stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, dx);
     return check_launch();
 }
 

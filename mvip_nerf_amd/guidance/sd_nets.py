@@ -24,6 +24,21 @@ USE_MFMA_CONV1X1 = True       # 1x1 shortcut convolutions on the split-precision
 USE_MFMA_VAE_ATTENTION = True
 USE_HIP_TRANSFORMER = True    # UNet transformer blocks on csrc/attention.hip + csrc/transformer.hip (guidance/transformer_cm.py)
 USE_HIP_TIME_LINEARS = True   # timestep-embedding MLP and the ResNet blocks' time projections on mvip_linear_small
+USE_GEMM_CONV = True          # stride-2 down-samplers, conv_in / conv_out, quant_conv: im2col planes + the split-precision GEMM
+                              # (ops.conv_gemm) instead of the library convolution -- with it no library contraction is left in the step
+
+
+def conv_any(conv, x, pads=None):
+    """conv(x) for the layers outside the 3x3 stride-1 kernel's shapes.  pads = (top, left, bottom, right) replaces the
+    module's own padding (the VAE down-samplers pad bottom / right by one).  fp32 device tensors run ops.conv_gemm,
+    anything else (fp16 mode, host tensors) the library convolution."""
+    if USE_GEMM_CONV and x.is_cuda:
+        from .. import ops
+        if ops.conv_gemm_supported(conv, x):
+            return ops.conv_gemm(x, conv, pads)
+    if pads is not None:
+        x = F.pad(x, (pads[1], pads[3], pads[0], pads[2]))
+    return conv(x)
 
 
 # ---------------------------------------------------------------------------------------------- blocks
@@ -49,7 +64,7 @@ def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
         from .. import ops
         if USE_MFMA_CONV3X3 and ops.conv3x3_supported(conv, x):
             return ops.norm_act_conv3x3(x, norm, conv, True, chan_add, residual)
-    h = conv(norm(x, silu=True))
+    h = conv_any(conv, norm(x, silu=True))
     if chan_add is not None:
         h = h + chan_add[:, :, None, None]
     return h if residual is None else residual + h
@@ -84,7 +99,7 @@ class ResnetBlock2D(nn.Module):
                 if USE_MFMA_CONV1X1 and ops.conv1x1_supported(self.conv_shortcut, x):
                     sc = ops.conv1x1(x, self.conv_shortcut)
             if sc is None:
-                sc = self.conv_shortcut(x)
+                sc = conv_any(self.conv_shortcut, x)            # 8 x 8 level (64 pixels): the GEMM path pads the columns
         return norm_act_conv(self.norm2, self.conv2, h, residual=sc)
 
 
@@ -175,9 +190,7 @@ class Downsample2D(nn.Module):
         self.pad = pad
 
     def forward(self, x):
-        if self.pad == 0:
-            x = F.pad(x, (0, 1, 0, 1))
-        return self.conv(x)
+        return conv_any(self.conv, x, (0, 0, 1, 1) if self.pad == 0 else None)
 
 
 class Upsample2D(nn.Module):
@@ -191,7 +204,7 @@ class Upsample2D(nn.Module):
             from .. import ops
             if ops.conv3x3_supported(self.conv, x):            # 1280 @ 32x32 and 640 @ 64x64 in the UNet
                 return ops.conv3x3_plain(x, self.conv)
-        return self.conv(x)
+        return conv_any(self.conv, x)
 
 
 # ---------------------------------------------------------------------------------------------- UNet
@@ -294,7 +307,7 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False):
         t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
         temb = self.time_embedding(timestep_sinusoid(t, self._t_dim).to(sample.dtype))
-        x = self.conv_in(sample)
+        x = conv_any(self.conv_in, sample)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk(x, temb, encoder_hidden_states)
@@ -302,7 +315,7 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, encoder_hidden_states)
         for blk in self.up_blocks:
             x = blk(x, skips, temb, encoder_hidden_states)
-        return (self.conv_out(self.conv_norm_out(x, silu=True)),)
+        return (conv_any(self.conv_out, self.conv_norm_out(x, silu=True)),)
 
 
 # ---------------------------------------------------------------------------------------------- VAE
@@ -351,13 +364,13 @@ class Encoder(nn.Module):
         self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
 
     def forward(self, x):
-        x = self.conv_in(x)
+        x = conv_any(self.conv_in, x)
         for blk in self.down_blocks:
             for r in blk.resnets:
                 x = r(x)
             if blk.downsamplers is not None:
                 x = blk.downsamplers[0](x)
-        return self.conv_out(self.conv_norm_out(self.mid_block(x), silu=True))
+        return conv_any(self.conv_out, self.conv_norm_out(self.mid_block(x), silu=True))
 
 
 class Decoder(nn.Module):
@@ -410,7 +423,7 @@ class AutoencoderKL(nn.Module):
         self.config = self.Cfg()
 
     def encode(self, x):
-        return _EncOut(LatentDist(self.quant_conv(self.encoder(x))))
+        return _EncOut(LatentDist(conv_any(self.quant_conv, self.encoder(x))))
 
     def decode(self, z, return_dict=False):
         return (self.decoder(self.post_quant_conv(z)),)

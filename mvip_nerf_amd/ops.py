@@ -1012,6 +1012,96 @@ def conv1x1(x, conv, residual=None):
     return _Conv1x1.apply(x, residual, conv)
 
 
+# General convolution as im2col planes + the split-precision GEMM: the layers the 3x3 stride-1 kernel cannot take --------
+def conv_gemm_supported(conv, x):
+    """Stride-1 / stride-2 square kernels (1x1, 3x3), any channel counts, fp32 device tensors: the UNet's and the VAE
+    encoder's down-samplers, conv_in / conv_out (3, 4, 8, 9 channels), quant_conv."""
+    if not (isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
+        return False                                  # frozen networks only: no parameter gradients here
+    kh, kw = conv.kernel_size
+    return (kh == kw and kh in (1, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
+            and isinstance(conv.padding, tuple) and conv.padding_mode == 'zeros')
+
+
+def _up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _conv_gemm_packed(conv):
+    """(A forward [MP x KP], A transposed [KP x MP], bias padded to MP): the weight as [Cout][Cin*KH*KW], zero padded
+    to the GEMM's multiples of 32, packed once per (frozen) layer."""
+    cache = conv.__dict__.setdefault('_mvip_packed_gemm', {})
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    if cache.get('key') != key:
+        cache.clear()
+        cache['key'] = key
+        Cout, K = conv.out_channels, conv.in_channels * conv.kernel_size[0] * conv.kernel_size[1]
+        MP, KP = _up(Cout, 32), _up(K, 32)
+        w = torch.zeros((MP, KP), device=conv.weight.device, dtype=torch.float32)
+        w[:Cout, :K] = conv.weight.detach().reshape(Cout, K)
+        cache['fwd'] = gemm_pack_a(w, MP, KP, KP, 1)
+        cache['bwd'] = gemm_pack_a(w, KP, MP, 1, KP)
+        b = torch.zeros(MP, device=w.device, dtype=torch.float32)
+        if conv.bias is not None:
+            b[:Cout] = conv.bias.detach()
+        cache['bias'] = b
+    return cache['fwd'], cache['bwd'], cache['bias']
+
+
+class _ConvGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, conv, pads):
+        if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+            raise NotImplementedError('conv_gemm: parameter gradients are not implemented (frozen networks only)')
+        xc = _f32c(x)
+        N, Cin, H, W = xc.shape
+        k, st = conv.kernel_size[0], conv.stride[0]
+        pt, pl, pb, pr = pads
+        OH, OW = (H + pt + pb - k) // st + 1, (W + pl + pr - k) // st + 1
+        Cout, K = conv.out_channels, Cin * k * k
+        MP, KP, P, PP = _up(Cout, 32), _up(K, 32), OH * OW, _up(OH * OW, 256)
+        a_fwd, _, bias = _conv_gemm_packed(conv)
+        s2 = absmax_scale(xc)
+        xs = _split_buffer(N, KP, PP, xc.device)
+        call('mvip_im2col_split_planes', ptr(xc), N, Cin, H, W, k, k, st, pt, pl, OH, OW, KP, PP, ptr(s2),
+             ptr(xs, torch.float16), stream())
+        y = gemm_f16x3(xs, a_fwd, N, KP, MP, PP, bias=bias, x_scale2=s2)
+        del xs
+        ctx.conv, ctx.geom = conv, (N, Cin, H, W, k, st, pt, pl, OH, OW, Cout, MP, KP, P, PP)
+        if MP != Cout or PP != P:
+            y = y[:, :Cout, :P]
+        return y.reshape(N, Cout, OH, OW)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        N, Cin, H, W, k, st, pt, pl, OH, OW, Cout, MP, KP, P, PP = ctx.geom
+        d = _f32c(dy).reshape(N, Cout, P)
+        if MP != Cout or PP != P:
+            dp = torch.zeros((N, MP, PP), device=d.device, dtype=torch.float32)
+            dp[:, :Cout, :P] = d
+            d = dp
+        _, a_bwd, _ = _conv_gemm_packed(ctx.conv)
+        ds, s2 = _scaled_planes(d, N, MP, PP, MP * PP, PP, 1)
+        col = gemm_f16x3(ds, a_bwd, N, MP, KP, PP, x_scale2=s2)                 # [N, KP, PP]
+        del ds
+        dx = torch.empty((N, Cin, H, W), device=d.device, dtype=torch.float32)
+        call('mvip_col2im', ptr(col), N, Cin, H, W, k, k, st, pt, pl, OH, OW, KP, PP, ptr(dx), stream())
+        return dx, None, None
+
+
+def conv_gemm(x, conv, pads=None):
+    """conv(x) + bias for the layers conv_gemm_supported accepts; `pads` = (top, left, bottom, right) overrides the
+    module's symmetric padding (the VAE down-samplers pad bottom / right only).  Differentiable w.r.t. x."""
+    if pads is None:
+        pads = (conv.padding[0], conv.padding[1], conv.padding[0], conv.padding[1])
+    return _ConvGemm.apply(x, conv, tuple(int(v) for v in pads))
+
+
 def norm_conv1x1(x, norm, conv):
     """conv1x1(group_norm(x)) + bias, forward only (the UNet's transformer proj_in; runs under no_grad)."""
     xc = x.detach().contiguous()

@@ -139,6 +139,43 @@ def test_resize_bilinear_vs_torch(cuda, shape, size):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize('N_,cin,cout,H,W,k,stride,pad,pads', [
+    (2, 320, 320, 64, 64, 3, 2, 1, None),            # UNet down-sampler
+    (1, 128, 128, 64, 96, 3, 2, 0, (0, 0, 1, 1)),    # VAE down-sampler: bottom / right padding only
+    (1, 3, 128, 64, 64, 3, 1, 1, None),              # VAE conv_in (K = 27 -> 32)
+    (2, 9, 320, 32, 32, 3, 1, 1, None),              # UNet conv_in (K = 81 -> 96)
+    (2, 320, 4, 32, 32, 3, 1, 1, None),              # UNet conv_out (M = 4 -> 32)
+    (1, 8, 8, 16, 16, 1, 1, 0, None),                # quant_conv
+    (2, 160, 96, 16, 16, 3, 2, 1, None),             # 8 x 8 output: P = 64 -> 256
+    (1, 5, 7, 13, 11, 3, 2, 1, None)])               # odd everything
+def test_conv_gemm_vs_fp64(cuda, N_, cin, cout, H, W, k, stride, pad, pads):
+    """ops.conv_gemm (im2col split planes + the split-precision GEMM; data gradient = transposed GEMM + col2im gather)
+    vs F.conv2d in fp64 on the host, forward and input gradient."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import conv_any
+    gen = torch.Generator().manual_seed(cin * 7 + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (k * k * cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(N_, cin, H, W, generator=gen) * 0.7 + 0.1
+    xr = x.double().requires_grad_(True)
+    xp = xr if pads is None else torch.nn.functional.pad(xr, (pads[1], pads[3], pads[0], pads[2]))
+    yr = torch.nn.functional.conv2d(xp, conv.weight.double(), conv.bias.double(), stride=stride, padding=pad)
+    dy = torch.randn(yr.shape, generator=gen) * 1e-4
+    yr.backward(dy.double())
+    conv_d = conv.to(cuda)
+    xd = x.to(cuda).requires_grad_(True)
+    assert ops.conv_gemm_supported(conv_d, xd)
+    y = conv_any(conv_d, xd, pads)
+    assert y.shape == yr.shape
+    np.testing.assert_allclose(N(y), yr.detach().float().numpy(), rtol=0, atol=1e-5 * float(yr.abs().max()))
+    y.backward(dy.to(cuda))
+    np.testing.assert_allclose(N(xd.grad), xr.grad.float().numpy(), rtol=0, atol=1e-5 * float(xr.grad.abs().max()))
+
+
 def test_pretrain_model_dispatch(cuda):
     """cal_loss sums the enabled terms in the reference's order and gates colla on i>0, normal on i>normal_start."""
     from mvip_nerf_amd.nerf.utils import Pretrain_Model
@@ -479,6 +516,6 @@ def test_plain_conv3x3_on_mfma_kernel(cuda):
             assert ops.conv3x3_supported(up.conv, torch.empty(2, 64, 16, 32, device=cuda))
             got = up(x.to(cuda))
         np.testing.assert_allclose(N(got), ref.detach().float().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
-    # with autograd enabled on a grad-carrying input the module stays on the differentiable library path
+    # with autograd enabled on a grad-carrying input the module takes a differentiable path (ops.conv_gemm)
     xg = torch.randn(1, 64, 8, 16, device=cuda, requires_grad=True)
     assert up(xg).requires_grad
