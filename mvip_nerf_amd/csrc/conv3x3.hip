@@ -330,6 +330,9 @@ struct ConvArgs {
     // writes its raw accumulators to partial[split][n][Cout][H][W]; cv_split_reduce_kernel sums them in order
     int splits, cks;
     float *partial;
+#ifdef MVIP_EXPERIMENT_CONV
+    int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier
+#endif
 };
 
 // MT <= 2: 80 KB of LDS and 256 registers, i.e. TWO workgroups per CU = two waves per SIMD, so one wave's LDS
@@ -400,6 +403,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     const char *wp_b = a.wp + ((int64_t)mb * MT * a.CK + ck0) * 3 * WROW;
 
     auto issue_input = [&](int ck, int buf) {
+#ifdef MVIP_EXPERIMENT_CONV
+        if (a.dbg & 4) return;
+#endif
         const char *base = xs_n + (int64_t)ck * 4 * plane;
         char *dst = lds_in + buf * CV_IN_BYTES + wave * 1024;
 #pragma unroll
@@ -407,6 +413,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
             if (in_off[r] != -2) glds16b(in_off[r] >= 0 ? base + in_off[r] : a.zero16, dst + r * (NT * 16));
     };
     auto issue_weights = [&](int t, int buf) {
+#ifdef MVIP_EXPERIMENT_CONV
+        if (a.dbg & 8) return;
+#endif
         const char *src = wp_b + (int64_t)t * WROW + lane * 16;
         char *dst = lds_w + buf * WB;
 #pragma unroll
@@ -465,6 +474,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     for (int t = 0; t < nstage; ++t) {
         const int ck = t / 3, ky = t - ck * 3;
         if (t > 0) {
+#ifdef MVIP_EXPERIMENT_CONV
+            if (!(a.dbg & 16))
+#endif
             __syncthreads();                   // stage t+1 landed (vmcnt(0)); every wave is done with stage t-1
             if (t + 2 < nstage) issue_weights(t + 2, (t + 2) % 3);
             if (ky == 0 && ck + 1 < nck) issue_input(ck + 1, (ck + 1) & 1);
@@ -476,6 +488,16 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int kx = g / MT, m = g % MT, set = g % 3;
+#ifdef MVIP_EXPERIMENT_CONV
+            if (a.dbg & 2) {
+                acc[m][0][0] += (float)Ah[set][0] + (float)Bh[kx][0][0] + (float)Bl[kx][1][0];
+                acc[m][1][0] += (float)Al[set][0] + (float)Bh[kx][1][0] + (float)Bl[kx][0][0];
+                const int g2 = g + 2;
+                if (g2 < NG) { load_a(wb, g2, g2 % 3); if (g2 % MT == 0) load_b(inb, ky, g2 / MT); }
+                else if (more) { load_a(wb_n, g2 - NG, g2 % 3); if ((g2 - NG) % MT == 0) load_b(inb_n, ky_n, (g2 - NG) / MT); }
+                continue;
+            }
+#endif
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][0], acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][1], acc[m][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -501,6 +523,14 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     const int gx = x0 + l32 % TW;
     const int n_out = TW == 8 ? n + wave : n;
     if (TW == 8 && n_out >= a.N) return;
+#ifdef MVIP_EXPERIMENT_CONV
+    if (a.dbg & 1) {
+        float t = 0.f;
+        for (int m = 0; m < MT; ++m) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[m][j][r];
+        if (t == 123.456f) a.y[0] = t;
+        return;
+    }
+#endif
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1003,6 +1033,9 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
     if (tw == 8) { a.tilesX = 1; a.tilesY = 1; }
     a.splits = 1; a.cks = a.CK; a.partial = nullptr;
+#ifdef MVIP_EXPERIMENT_CONV
+    { const char *e = getenv("MVIP_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     hipStream_t st = as_stream(stream);
     // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
     // four-wave tile on every VAE / UNet shape and on the whole step, 7.56 vs 7.65 ms -- tools/conv_wide_ab.py)

@@ -1,0 +1,79 @@
+// How many ds_read_b128 per v_mfma_f32_32x32x16_f16 can a CU sustain before the matrix pipe starves?  (The split-precision
+// convolution / GEMM kernels read 0.5-0.67 fragments per MFMA.)  NW waves per workgroup (4 = one wave per SIMD, 8 = two),
+// one workgroup per CU, all CUs busy; per step: R fragment reads (1 KB each, conflict-free, from a 32 KB LDS window) and
+// 6 MFMAs on two accumulator chains that consume the fragments read two steps earlier.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+template <int R, int NW>
+__global__ void __launch_bounds__(NW * 64) k(unsigned long long *out, const float *w, int iters) {
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16384; i += NW * 64) reinterpret_cast<float *>(lds)[i] = w[i] * 1e-3f;
+    __syncthreads();
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    h16x8 f[3][6];
+    for (int s = 0; s < 3; ++s)
+        for (int q = 0; q < 6; ++q) f[s][q] = *reinterpret_cast<const h16x8 *>(lds + ((s * 6 + q) % 32) * 1024 + lane * 16);
+    const char *base = lds + (wave & 3) * 8192 + lane * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int step = 0; step < 12; ++step) {
+            const int cur = step % 3, nxt = (step + 2) % 3;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][0], f[cur][1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][2], f[cur][3], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                f[nxt][q] = *reinterpret_cast<const h16x8 *>(base + ((step * 6 + q) % 8) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][4], f[cur][1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][5], f[cur][3], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][0], f[cur][3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cur][2], f[cur][1], acc1, 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) out[0] = 1;
+    if (lane == 0) out[1 + blockIdx.x * NW + wave] = t1 - t0;
+}
+
+template <int R, int NW>
+void run(unsigned long long *d, const float *w, int blocks) {
+    const int iters = 400;
+    hipLaunchKernelGGL((k<R, NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, w, iters);
+    hipLaunchKernelGGL((k<R, NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, w, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(1 + blocks * NW);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> c;
+    // cycles of SIMD time per MFMA: a SIMD runs NW/4 waves, each issuing iters*72 MFMAs in (t1 - t0) cycles
+    for (int i = 0; i < blocks * NW; ++i) c.push_back((double)h[1 + i] / (iters * 72.0) / (NW / 4));
+    std::sort(c.begin(), c.end());
+    printf("{\"reads_per_6_mfma\": %d, \"waves_per_simd\": %d, \"simd_cycles_per_mfma_median\": %.2f, \"p90\": %.2f, "
+           "\"lds_bytes_per_clk_per_cu\": %.1f}\n", R, NW / 4, c[c.size() / 2], c[c.size() * 9 / 10],
+           R * 1024.0 * NW / (6.0 * c[c.size() / 2] * (NW / 4)));
+}
+
+int main() {
+    unsigned long long *d;
+    float *w;
+    const int blocks = 256;
+    hipMalloc(&d, (1 + blocks * 8) * 8);
+    hipMemset(d, 0, (1 + blocks * 8) * 8);
+    std::vector<float> hw(1 << 16);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
+    hipMalloc(&w, hw.size() * 4);
+    hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    run<0, 4>(d, w, blocks); run<2, 4>(d, w, blocks); run<3, 4>(d, w, blocks); run<4, 4>(d, w, blocks); run<6, 4>(d, w, blocks);
+    run<0, 8>(d, w, blocks); run<2, 8>(d, w, blocks); run<3, 8>(d, w, blocks); run<4, 8>(d, w, blocks); run<6, 8>(d, w, blocks);
+    return 0;
+}
