@@ -157,10 +157,12 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
     tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
     traffic, src = None, None
-    pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_mlp_forward.json')     # separate --pmc passes of this launch
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-        src = 'profiles/r1_pmc_mlp_forward.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
+    for name in ('r2_pmc_mlp_forward.json', 'r1_pmc_mlp_forward.json'):     # separate --pmc passes of this launch
+        pmc = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            src = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
+            break
     return {'bound': 'mfma', 'kernel': 'mlp_forward16_kernel<rays> (csrc/mlp_fwd16.hip)', 'achieved': round(tflops, 2),
             'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / PEAK_F32_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
@@ -538,10 +540,13 @@ def main():
                         'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
                         'peak': round(PEAK_F16_TFLOPS / 3, 1),
                         'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / 3 products: the split-precision kernels (3x3 convolutions, GEMMs, '
-                                   'attention) carry the step\'s contractions except the strided, 8x8-level and stem convolutions (library fp32)',
+                                   'attention) carry every contraction of the step.  Under dense fp16 MFMA load the shader clock of '
+                                   'this part settles at ~1.67 GHz (tools/micro/mfma_clock.hip, profiles/r2_micro_mfma_clock_and_lds.json), '
+                                   'i.e. a sustained peak of ~580 TFLOP/s fp32-equivalent',
+                        'frac_of_sustained_f16x3_peak': round(ach / (PEAK_F16_TFLOPS / 3 * 1.67 / 2.4), 4),
                         'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
-                             'dtype': 'f32 tensors; 3x3 convolutions, linear layers and attention on fp16 MFMA in split precision (f16x3, ~1e-6 relative), strided / 8x8 / stem convolutions library fp32',
+                             'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 relative)',
                              'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
                              'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
                              'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '

@@ -361,7 +361,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kg = lane >> 5;
-
     // XCD-aware order: each of the 8 XCDs walks a contiguous range of (tile, channel-block) pairs, the
     // channel blocks of one pixel tile adjacent in time, so the tile's planes are served by that XCD's L2.
     int id = blockIdx.x;
