@@ -596,6 +596,66 @@ struct GemmArgs {
 #endif
 };
 
+// epilogue shared by the 32/64-row GEMM kernels: acc[m][j] = 32 x 32 tile (row tile mb*MT + m, columns p0 + (2 wave + j)*32 ..)
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MT][2], int n, int mb, int64_t p0, int split,
+                                              int wave, int lane) {
+    const int l32 = lane & 31, kg = lane >> 5;
+    const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+#ifdef MVIP_EXPERIMENT_GEMM
+    if (a.dbg & 1) {
+        float t = 0.f;
+        for (int m = 0; m < MT; ++m) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[m][j][r];
+        if (t == 123.456f) a.y[0] = t;
+        return;
+    }
+#endif
+    if (MT == 2 && a.geglu_L > 0) {
+        // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
+        // two row tiles; the [N][8C][P] intermediate never exists
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
+                float av = acc[0][j][r] * inv, gv = acc[MT - 1][j][r] * inv;
+                if (a.bias) { av += a.bias[(mb * 2 + 0) * 32 + r32]; gv += a.bias[(mb * 2 + 1) * 32 + r32]; }
+                float v = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+                if (px >= a.geglu_L) v = 0.f;
+                const float w = fabsf(v);
+                mx = (w == w && w < 3.0e38f) ? fmaxf(mx, w) : mx;
+                a.y[((int64_t)n * (a.M / 2) + mb * 32 + r32) * a.P + px] = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) atomicMax(a.absmax_bits, __float_as_uint(mx));
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
+                if (a.partial) {
+                    a.partial[(int64_t)split * a.N * a.M * a.P + o] = acc[m][j][r];
+                    continue;
+                }
+                float v = acc[m][j][r] * inv;
+                if (a.bias) v += a.bias[row];
+                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
+                if (a.residual) v += a.residual[o];
+                a.y[o] = v;
+            }
+        }
+}
+
 template <int MT>
 __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(const GemmArgs a) {
     constexpr int WB = GM_KC * MT * 2 * 1024;
@@ -680,59 +740,141 @@ __global__ void __launch_bounds__(256, (MT <= 2 ? 2 : 1)) gemm_f16x3_kernel(cons
             }
         }
     }
-    const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
-#ifdef MVIP_EXPERIMENT_GEMM
-    if (a.dbg & 1) {
-        float t = 0.f;
-        for (int m = 0; m < MT; ++m) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[m][j][r];
-        if (t == 123.456f) a.y[0] = t;
-        return;
-    }
-#endif
-    if (MT == 2 && a.geglu_L > 0) {
-        // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
-        // two row tiles; the [N][8C][P] intermediate never exists
-        float mx = 0.f;
+    gemm_epilogue<MT>(a, acc, n, mb, p0, split, wave, lane);
+}
+
+// ---- the same GEMM with the B operand streamed straight into registers ----------------------------------------------
+// The kernel above is bound by operand delivery: 36 KB of DMA per 12 MFMAs and workgroup (94 B/clk/CU at the matrix rate)
+// with ONE stage in flight, where L2 -> CU delivery needs ~64 KB in flight per CU to reach its ~57 B/clk
+// (tools/micro/l2_load_bw.hip) -- PMC: matrix pipe 12 % busy, 54 % of the wave time in s_waitcnt.  Here
+//  * the B operand (activations: no reuse between the four waves, each owns 64 columns) never touches LDS: a lane's
+//    fragment is 16 contiguous bytes of a split plane, so the MFMA operand registers are loaded directly
+//    (global_load_dwordx4, 512 B contiguous per half-wave), SIX 16-k chunks (24 loads, 24 KB per wave) ahead of their use;
+//  * the A operand (weights, shared by the four waves) streams through a three-slot LDS ring of 64-k chunks by LDS-DMA,
+//    two chunks ahead; the only synchronisation is one s_barrier per chunk WITHOUT a vmcnt(0) drain: loads return in
+//    order, and the wave has by then waited for B fragments that were issued after the chunk's DMA (DB <= 7), so its
+//    share of that DMA has landed.
+// Same grid, operand formats, split-K and epilogue as gemm_f16x3_kernel.
+template <int V> struct cic { static constexpr int value = V; };
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void cv_static_for(F &&f) {
+    if constexpr (I < N) { f(cic<I>{}); cv_static_for<N, F, I + 1>(static_cast<F &&>(f)); }
+}
+constexpr int G5_DB = 6;        // B prefetch depth in 16-k chunks
+constexpr int G5_CA = 4;        // 16-k chunks per A ring slot
+template <int MT>
+__global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const GemmArgs a) {
+    constexpr int SLOT = G5_CA * MT * 2 * 1024;            // bytes of a ring slot: [u][m][hl][lane][16 B]
+    // three separate arrays, not one: the compiler's wait-count pass then knows that an LDS-DMA into one slot cannot
+    // alias the fragment reads of another and puts no vmcnt(0) in front of them
+    __shared__ __attribute__((aligned(16))) char ring0[SLOT];
+    __shared__ __attribute__((aligned(16))) char ring1[SLOT];
+    __shared__ __attribute__((aligned(16))) char ring2[SLOT];
+    auto ring = [&](auto slot_) -> char * {
+        constexpr int slot = decltype(slot_)::value;
+        if constexpr (slot == 0) return ring0;
+        else if constexpr (slot == 1) return ring1;
+        else return ring2;
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, kg = lane >> 5;
+    int id = blockIdx.x;
+    const int total = gridDim.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int split = id % a.splits;
+    id /= a.splits;
+    const int mb = id % a.MB;
+    const int tile = id / a.MB;
+    const int tp = tile % a.tiles;
+    const int n = tile / a.tiles;
+    const int64_t p0 = (int64_t)tp * GM_PIX;
+    const int64_t plane = a.P * 16;
+    const int ck0 = split * a.sks * GM_KC;                 // first 16-k chunk of this workgroup
+    const int nall = a.CK - ck0;
+    const int nck = nall < a.sks * GM_KC ? nall : a.sks * GM_KC;
+    const int nchunk = (nck + G5_CA - 1) / G5_CA;
+
+    // B: this lane's fragment of column block j, hi / lo, for chunk ck: bsrc[j] + (ck*4 + hl) * plane
+    const char *bsrc[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+    for (int j = 0; j < 2; ++j)
+        bsrc[j] = a.xs + (((int64_t)n * a.CK + ck0) * 4 + kg * 2) * plane + (p0 + (2 * wave + j) * 32 + l32) * 16;
+    h16x8 Bq[G5_DB][2][2];
+    auto load_b = [&](int ck, auto slot_) {
+        constexpr int slot = decltype(slot_)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
-                float av = acc[0][j][r] * inv, gv = acc[MT - 1][j][r] * inv;
-                if (a.bias) { av += a.bias[(mb * 2 + 0) * 32 + r32]; gv += a.bias[(mb * 2 + 1) * 32 + r32]; }
-                float v = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
-                if (px >= a.geglu_L) v = 0.f;
-                const float w = fabsf(v);
-                mx = (w == w && w < 3.0e38f) ? fmaxf(mx, w) : mx;
-                a.y[((int64_t)n * (a.M / 2) + mb * 32 + r32) * a.P + px] = v;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                Bq[slot][j][hl] = *reinterpret_cast<const h16x8 *>(bsrc[j] + ((int64_t)ck * 4 + hl) * plane);
+    };
+    // A: ring slot `slot` <- 16-k chunks c*CA .. c*CA+CA-1 of the MT row blocks; piece q = (u*MT + m)*2 + hl.  The slot
+    // is a compile-time constant so that the DMA provably does not alias the fragment reads of the other slots.
+    auto issue_a = [&](int c, auto slot_, bool always = false) {
+        constexpr int slot = decltype(slot_)::value;
+        if (always || c < nchunk) {
+#pragma unroll
+            for (int q0 = 0; q0 < G5_CA * MT * 2; q0 += 4) {
+                const int q = q0 + wave;
+                const int hl = q & 1, m = (q >> 1) % MT, u = (q >> 1) / MT;
+                int ck = c * G5_CA + u;
+                if (ck >= nck) ck = nck - 1;                 // partial last chunk: a valid address, never multiplied
+                glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + ck0 + ck) * 2 + hl) * 1024) + lane * 16,
+                        ring(slot_) + q * 1024);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) atomicMax(a.absmax_bits, __float_as_uint(mx));
-        return;
-    }
+    };
+
+    f32x16 acc[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
-                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
-                if (a.partial) {
-                    a.partial[(int64_t)split * a.N * a.M * a.P + o] = acc[m][j][r];
-                    continue;
-                }
-                float v = acc[m][j][r] * inv;
-                if (a.bias) v += a.bias[row];
-                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
-                if (a.residual) v += a.residual[o];
-                a.y[o] = v;
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    issue_a(0, cic<0>{});
+    issue_a(1, cic<1>{});
+    cv_static_for<G5_DB>([&](auto d) { if (d.value < nck) load_b(d.value, d); });
+    // ring slots 0 and 1 are in LDS once this wave's loads issued before B(0) have returned and every wave says so
+    if (nck >= G5_DB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (G5_DB - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+
+    // 12 chunks of 16 k = 3 ring slots = 2 rounds of the B registers per trip, everything indexed statically.  The main
+    // loop has NO branches (every trip issues all of its loads and DMAs): the compiler's wait-count pass then keeps exact
+    // counts (s_waitcnt vmcnt(20): the 20 younger B loads stay in flight); with a branch in the body it merges the
+    // pending-load states into vmcnt(0) and drains the queue.  The last trips run the guarded copy of the same steps.
+    auto step = [&](int base, auto t_, auto guarded_) {
+        constexpr int t = decltype(t_)::value;
+        constexpr bool guarded = decltype(guarded_)::value != 0;
+        constexpr int slot = t / G5_CA, u = t % G5_CA, bs = t % G5_DB;
+        const int ck = base + t;
+        if (guarded && ck >= nck) return;
+        if constexpr (u == 0) issue_a(ck / G5_CA + 2, cic<(slot + 2) % 3>{}, !guarded);   // main loop: chunk +2 exists
+        const char *ab = ring(cic<slot>{}) + lane * 16;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const h16x8 ah = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 0) * 1024);
+            const h16x8 al = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 1) * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][1], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bq[bs][j][0], acc[m][j], 0, 0, 0);
             }
         }
+        // the scheduler otherwise gathers the loads of several steps into one cluster late in the chunk, which shortens
+        // the prefetch distance and turns the counted waits into vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!guarded || ck + G5_DB < nck) load_b(ck + G5_DB, cic<bs>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (u == G5_CA - 1) asm volatile("s_barrier" ::: "memory");   // slot free for chunk +3, chunk +1 landed
+    };
+    int base = 0;
+    for (; base + 12 + G5_DB <= nck; base += 12) cv_static_for<12>([&](auto t_) { step(base, t_, cic<0>{}); });
+    for (; base < nck; base += 12) cv_static_for<12>([&](auto t_) { step(base, t_, cic<1>{}); });
+    gemm_epilogue<MT>(a, acc, n, mb, p0, split, wave, lane);
 }
 
 // scale2 = {2^k, 2^-k} from the maximum collected in *bits, which is left zero (caller-owned scratch word)
@@ -1165,6 +1307,7 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     hipStream_t st = as_stream(stream);
     const bool auto_cfg = cfg == 0;
     if (cfg == 0) cfg = gm_auto_cfg(N, M, P);
+    if (cfg < 0 || cfg > 5) return MVIP_EINVAL;
     if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
     if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
     if (cfg == 2) {
@@ -1187,10 +1330,17 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
         }
         blocks *= a.splits;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+        // cfg 5 (and the automatic choice unless MVIP_GEMM_STREAM=0): the B-in-registers kernel
+        static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
+        const bool stream = cfg == 5 || (auto_cfg && stream_env);
         if (MT == 4)
             hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (MT == 2 && stream)
+            hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else if (MT == 2)
             hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (stream)
+            hipLaunchKernelGGL((gemm5_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         if (a.partial) {
@@ -1202,7 +1352,8 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     return check_launch();
 }
 
-// cfg: 0 = choose by shape, 1 = 32/64-row kernel, 2 = 128 x 256 tile, 3 = 128 x 128, 4 = 64 x 128 (timing switch)
+// cfg: 0 = choose by shape, 1 = 32/64-row kernel (operands through LDS), 2 = 128 x 256 tile, 3 = 128 x 128, 4 = 64 x 128,
+// 5 = 32/64-row kernel with the B operand streamed into registers (timing switch)
 extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                    const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                                    float *y, int cfg, void *stream) {
@@ -1247,7 +1398,9 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-        hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
+        if (stream_env) hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(gm_scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2, (unsigned *)zero_word);
     return check_launch();

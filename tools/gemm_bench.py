@@ -36,7 +36,7 @@ def main():
         xs, s2 = ops._scaled_planes(x, Nb, K, L, K * L, L, 1)
         pk = ops.gemm_pack_a(W, M, K, K, 1)
         row = {}
-        for cfg in (1, 2, 3, 4, 0):
+        for cfg in (1, 2, 3, 4, 5, 0):
             if (cfg in (2, 3) and M % 128) or (cfg == 4 and M % 64):
                 continue
             ops.GEMM_CFG = cfg
