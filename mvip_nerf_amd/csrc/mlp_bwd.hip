@@ -3,20 +3,21 @@
 //  DS_NeRF/run_nerf_helpers.py:104-127; the reference needs no gradient w.r.t. points.)
 //
 // Per tile of `tile_points` points, three kernels:
-//   R  mlp_forward_kernel<STASH>  re-encodes the inputs and recomputes every activation, written
-//      once to a tile-blocked stash ([row_tile][point_tile][32][32], 4 KB blocks);
-//   B1 mlp_delta_kernel           back-propagates pre-activation gradients G_l = relu'(h_l) .
-//      W_{l+1}^T G_{l+1}.  Same structure as the forward: each wave owns 32 points, a
-//      [256 x 32] gradient matrix lives in accumulator registers and is fed straight back as the
-//      B operand of the next v_mfma_f32_32x32x2_f32 chain; the TRANSPOSED weights stream
-//      through the LDS ring from a second packed image;
-//   B2 mlp_wgrad_kernel           dW_l = G_l . Act_{l-1}^T: MFMA with the POINT index as the K
-//      dimension.  A workgroup owns a slab of points and a whole 256x256 (or 256x64 / 128x288)
-//      gradient: 4 waves x (2 x 8) accumulator tiles; [32 x 32] operand blocks arrive by LDS-DMA
-//      with a source-side XOR swizzle so the per-lane ds_read_b128 of 4 consecutive points is
-//      bank-conflict free; results leave as fp32 atomics shaped as two 128-B row segments per
-//      wave instruction, directly into the natural [out][in] gradient tensors.  Bias, sigma-row
-//      and rgb-row gradients ride along on the VALU from the operands already in registers.
+//   R  the stash-writing forward re-encodes the inputs and recomputes every activation, written once to a tile-blocked
+//      stash ([row_tile][point_tile][32][32], 4 KB blocks).  Training keeps the stash of its own forward
+//      (mlp_forward16_kernel<rays, STASH>, mlp_fwd16.hip; mvip_mlp_backward_stash) and skips R; the recompute path
+//      runs the 32-point mlp_forward_kernel<STASH> of mlp_fwd.hip;
+//   B1 delta propagation G_l = relu'(h_l) . W_{l+1}^T G_{l+1}: mlp_delta16_kernel (mlp_bwd16.hip: 16 points per wave, two
+//      waves per SIMD; MVIP_DELTA16=0 selects mlp_delta_kernel below, the 32-point kernel with the same structure as the
+//      32-point forward: a [256 x 32] gradient matrix in accumulator registers fed straight back as the B operand of the
+//      next v_mfma_f32_32x32x2_f32 chain, TRANSPOSED weights through the LDS ring from a second packed image);
+//   B2 mlp_wgrad_kernel           dW_l = G_l . Act_{l-1}^T: MFMA with the POINT index as the K dimension.  A workgroup
+//      owns a slab of points and half of a 256x256 (or a 256x64 / 128x288) gradient: 4 waves x 8 accumulator tiles;
+//      [32 x 32] operand blocks arrive by LDS-DMA in stages of 16 points (exact fp32: two workgroups per CU) or 32
+//      points (split precision) with a source-side XOR swizzle so the per-lane ds_read_b128 of 4 consecutive points is
+//      bank-conflict free; the stage loop is a PAIR of stages with a single exit (see wgrad_body); results leave as
+//      fp32 atomics shaped as two 128-B row segments per wave instruction, directly into the natural [out][in] gradient
+//      tensors.  Bias, sigma-row and rgb-row gradients ride along on the VALU from the operands already in registers.
 // FLOPs: R + B1 + B2 ~= 2.9x the forward.  HBM: ~20 KB/point of stash traffic each way, i.e.
 // ~90 FLOP/B -- still MFMA-bound at fp32 rates.
 #include "common.h"
@@ -536,7 +537,7 @@ __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
 
 // blockIdx.y: 0..15 the eight 256x256 products as two 128-row halves each, 16..17 the two 256x64
 // products with the encoding, 18..19 the view branch in two column groups.  No wave holds more than
-// 128 accumulator registers: with 256 hipcc shuttles tiles between AGPRs and VGPRs every stage.
+// 128 accumulator registers.
 // SP = 16 (half stages, 56 KB of LDS, <= 128 + 128 registers): TWO workgroups per CU, so the barrier / LDS-latency bubble
 // at every stage boundary of one workgroup runs under the other's MFMAs.
 template <int PREC, int SP>
