@@ -442,8 +442,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     const int nstage = nck * 3;
     const int jrow0 = 2 * wave;
     const int img_rows = TW == 8 ? 2 * wave : 0;        // TW = 8: every image in front of this wave's adds two halo rows
-    h16x8 Ah[3], Al[3];                                 // set = group % 3  (NG % 3 == 0: the rotation survives stages)
-    h16x8 Bh[3][2], Bl[3][2];                           // set = kx
+    // PD = groups between a fragment's LDS read and its use (NS sets of A fragments, set = group % NS, NG % NS == 0 so the
+    // rotation survives stages).  Two groups; four (PD = 4, NS = 6 at MT = 2: ~770 cycles of cover, 203 registers)
+    // measured the same on every VAE / UNet shape -- the LDS read latency is not what the waves wait for.
+    constexpr int PD = 2;
+    constexpr int NS = 3;
+    h16x8 Ah[NS], Al[NS];
+    h16x8 Bh[3][2], Bl[3][2];                           // set = kx: the tap PD groups ahead is always the one just finished
     auto load_a = [&](const char *wb, int g, int set) {
         const int kx = g / MT, m = g % MT;
         Ah[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
@@ -466,10 +471,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     __syncthreads();                                    // stages 0 and 1 (and input chunk 0) have landed
     if (nstage > 2) issue_weights(2, 2);
     if (nck > 1) issue_input(1, 1);
-    load_b(in_base(0), 0, 0);
-    load_a(w_base(0), 0, 0);
-    if (NG > 1) load_a(w_base(0), 1, 1);
-    if (MT == 1) load_b(in_base(0), 0, 1);
+#pragma unroll
+    for (int g = 0; g < PD; ++g) {                      // PD < NG: the first PD groups are all of stage 0
+        load_a(w_base(0), g, g % NS);
+        if (g % MT == 0) load_b(in_base(0), 0, g / MT);
+    }
     for (int t = 0; t < nstage; ++t) {
         const int ck = t / 3, ky = t - ck * 3;
         if (t > 0) {
@@ -486,27 +492,27 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         const bool more = t + 1 < nstage;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int kx = g / MT, m = g % MT, set = g % 3;
+            const int kx = g / MT, m = g % MT, set = g % NS;
 #ifdef MVIP_EXPERIMENT_CONV
             if (a.dbg & 2) {
                 acc[m][0][0] += (float)Ah[set][0] + (float)Bh[kx][0][0] + (float)Bl[kx][1][0];
                 acc[m][1][0] += (float)Al[set][0] + (float)Bh[kx][1][0] + (float)Bl[kx][0][0];
-                const int g2 = g + 2;
-                if (g2 < NG) { load_a(wb, g2, g2 % 3); if (g2 % MT == 0) load_b(inb, ky, g2 / MT); }
-                else if (more) { load_a(wb_n, g2 - NG, g2 % 3); if ((g2 - NG) % MT == 0) load_b(inb_n, ky_n, (g2 - NG) / MT); }
+                const int g2 = g + PD;
+                if (g2 < NG) { load_a(wb, g2, g2 % NS); if (g2 % MT == 0) load_b(inb, ky, g2 / MT); }
+                else if (more) { load_a(wb_n, g2 - NG, g2 % NS); if ((g2 - NG) % MT == 0) load_b(inb_n, ky_n, (g2 - NG) / MT); }
                 continue;
             }
 #endif
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][0], acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][1], acc[m][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            {   // fragments of group g+2 (this stage or the next one)
-                const int g2 = g + 2;
+            {   // fragments of group g+PD (this stage or the next one)
+                const int g2 = g + PD;
                 if (g2 < NG) {
-                    load_a(wb, g2, g2 % 3);
+                    load_a(wb, g2, g2 % NS);
                     if (g2 % MT == 0) load_b(inb, ky, g2 / MT);
                 } else if (more) {
-                    load_a(wb_n, g2 - NG, g2 % 3);
+                    load_a(wb_n, g2 - NG, g2 % NS);
                     if ((g2 - NG) % MT == 0) load_b(inb_n, ky_n, (g2 - NG) / MT);
                 }
             }
@@ -1143,6 +1149,11 @@ static inline void cv_geometry(int64_t N, int64_t Cout, int64_t H, int64_t W, in
     tw = (W % CV_TW == 0 && H % CV_TH == 0) ? CV_TW : (H == 8 && W == 8 ? 8 : 16);
     const int th = 256 / tw;
     MT = tw != CV_TW ? 1 : cv_mt(Cout, N * (W / tw) * (H / th));
+    // 64-row workgroups also on small grids (the fragment reads and the input DMA of a stage serve twice the MFMAs); the
+    // channel splits fill the chip instead of the row blocks: 12.0 -> 11.3 ms of convolutions per SDS step, +0.3 ms of
+    // split reduction.  MVIP_CONV_MT2=0 restores the 32-row choice (A-B switch).
+    static const int mt2_env = [] { const char *e = getenv("MVIP_CONV_MT2"); return e ? atoi(e) : 1; }();
+    if (mt2_env && tw == CV_TW && MT == 1 && Cout % 64 == 0) MT = 2;
     blocks = (tw == 8 ? (N + 3) / 4 : N * (W / tw) * (H / th)) * (Cout / (32 * MT));
 }
 
