@@ -332,6 +332,7 @@ struct ConvArgs {
     float *partial;
 #ifdef MVIP_EXPERIMENT_CONV
     int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier
+    unsigned long long *probe;   // per workgroup: {shader cycles total, 100 MHz ticks total, prologue, sync + DMA issue, compute, epilogue}
 #endif
 };
 
@@ -361,6 +362,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kg = lane >> 5;
+#ifdef MVIP_EXPERIMENT_CONV
+    unsigned long long pc0 = 0, pr0 = 0, p_sync = 0, p_comp = 0, p_pro = 0, p_mark = 0;
+    if (a.probe) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+#define CV_MARK(acc_) do { if (a.probe) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - p_mark; p_mark = now_; } } while (0)
+#else
+#define CV_MARK(acc_) do { } while (0)
+#endif
     // XCD-aware order: each of the 8 XCDs walks a contiguous range of (tile, channel-block) pairs, the
     // channel blocks of one pixel tile adjacent in time, so the tile's planes are served by that XCD's L2.
     int id = blockIdx.x;
@@ -476,8 +484,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         load_a(w_base(0), g, g % NS);
         if (g % MT == 0) load_b(in_base(0), 0, g / MT);
     }
+#ifdef MVIP_EXPERIMENT_CONV
+    if (a.probe) { p_mark = __builtin_amdgcn_s_memtime(); p_pro = p_mark - pc0; }
+#endif
     for (int t = 0; t < nstage; ++t) {
         const int ck = t / 3, ky = t - ck * 3;
+        CV_MARK(p_comp);
         if (t > 0) {
 #ifdef MVIP_EXPERIMENT_CONV
             if (!(a.dbg & 16))
@@ -486,6 +498,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
             if (t + 2 < nstage) issue_weights(t + 2, (t + 2) % 3);
             if (ky == 0 && ck + 1 < nck) issue_input(ck + 1, (ck + 1) & 1);
         }
+        CV_MARK(p_sync);
         const char *wb = w_base(t), *inb = in_base(t);
         const char *wb_n = w_base(t + 1), *inb_n = in_base(t + 1);
         const int ky_n = (ky == 2) ? 0 : ky + 1;
@@ -524,6 +537,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         }
     }
 
+    CV_MARK(p_comp);
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
     const int gx = x0 + l32 % TW;
     const int n_out = TW == 8 ? n + wave : n;
@@ -536,26 +550,66 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         return;
     }
 #endif
+    // The epilogue's loads are issued TOGETHER, ahead of the arithmetic: written element by element (`if (bias) v +=
+    // bias[co]; if (chan_add) ...; if (residual) v += residual[o]; y[o] = v`) every load sits behind its own branch and
+    // is followed by s_waitcnt vmcnt(0) -- up to 3 x 64 exposed memory latencies per wave, 122 k of the 211 k cycles of a
+    // 128-channel 512 x 512 workgroup (tools/conv_probe.py).
+    auto out_index = [&](int m, int j, int r, int &co) -> int64_t {
+        const int gy = TW == 8 ? j * RPB + l32 / TW : y0 + (jrow0 + j) * RPB + l32 / TW;
+        co = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+        return (((int64_t)n_out * a.Cout + co) * H + gy) * W + gx;
+    };
+    if (a.partial) {
+        float *pp = a.partial + (int64_t)split * a.N * a.Cout * H * W;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gy = TW == 8 ? j * RPB + l32 / TW : y0 + (jrow0 + j) * RPB + l32 / TW;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { int co; pp[out_index(m, j, r, co)] = acc[m][j][r]; }
+    } else {
+        const bool hb = a.bias != nullptr, hc = a.chan_add != nullptr, hr = a.residual != nullptr;
+        float bv[MT][16], cv[MT][16];
+        f32x16 rv[MT][2];
+        if (hr) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { int co; rv[m][j][r] = a.residual[out_index(m, j, r, co)]; }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
-                const int64_t o = (((int64_t)n_out * a.Cout + co) * H + gy) * W + gx;
-                if (a.partial) {
-                    a.partial[(int64_t)split * a.N * a.Cout * H * W + o] = acc[m][j][r];
-                    continue;
-                }
-                float v = acc[m][j][r] * inv;
-                if (a.bias) v += a.bias[co];
-                if (a.chan_add) v += a.chan_add[(int64_t)n_out * a.Cout + co];
-                if (a.residual) v += a.residual[o];
-                a.y[o] = v;
+                bv[m][r] = hb ? a.bias[co] : 0.f;
+                cv[m][r] = hc ? a.chan_add[(int64_t)n_out * a.Cout + co] : 0.f;
             }
-        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co;
+                    const int64_t o = out_index(m, j, r, co);
+                    float v = acc[m][j][r] * inv;
+                    if (hb) v += bv[m][r];
+                    if (hc) v += cv[m][r];
+                    if (hr) v += rv[m][j][r];
+                    a.y[o] = v;
+                }
+    }
+#ifdef MVIP_EXPERIMENT_CONV
+    if (a.probe && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *o = a.probe + 6 * (unsigned long long)blockIdx.x;
+        o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark;
+    }
+#endif
 }
 
 // y = (sum_s partial[s]) / (s_w s_x) + bias + chan_add + residual, the splits added in index order (deterministic)
@@ -616,9 +670,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
         return;
     }
 #endif
+    // all loads of the epilogue are issued together, ahead of the arithmetic (see the convolution's epilogue)
+    const bool hb = a.bias != nullptr, hc = a.chan_add != nullptr, hr = a.residual != nullptr;
     if (MT == 2 && a.geglu_L > 0) {
         // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
         // two row tiles; the [N][8C][P] intermediate never exists
+        float ba[16], bg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
+            ba[r] = hb ? a.bias[(mb * 2 + 0) * 32 + r32] : 0.f;
+            bg[r] = hb ? a.bias[(mb * 2 + 1) * 32 + r32] : 0.f;
+        }
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -627,7 +690,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
             for (int r = 0; r < 16; ++r) {
                 const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
                 float av = acc[0][j][r] * inv, gv = acc[MT - 1][j][r] * inv;
-                if (a.bias) { av += a.bias[(mb * 2 + 0) * 32 + r32]; gv += a.bias[(mb * 2 + 1) * 32 + r32]; }
+                if (hb) { av += ba[r]; gv += bg[r]; }
                 float v = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
                 if (px >= a.geglu_L) v = 0.f;
                 const float w = fabsf(v);
@@ -640,26 +703,52 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
         if (lane == 0) atomicMax(a.absmax_bits, __float_as_uint(mx));
         return;
     }
+    auto out_index = [&](int m, int j, int r, int &row) -> int64_t {
+        row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+        return ((int64_t)n * a.M + row) * a.P + p0 + (2 * wave + j) * 32 + l32;
+    };
+    if (a.partial) {
+        float *pp = a.partial + (int64_t)split * a.N * a.M * a.P;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { int row; pp[out_index(m, j, r, row)] = acc[m][j][r]; }
+        return;
+    }
+    float bv[MT][16], cv[MT][16];
+    f32x16 rv[MT][2];
+    if (hr) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { int row; rv[m][j][r] = a.residual[out_index(m, j, r, row)]; }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+            bv[m][r] = hb ? a.bias[row] : 0.f;
+            cv[m][r] = hc ? a.chan_add[(int64_t)n * a.M + row] : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (mb * MT + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
-                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
-                if (a.partial) {
-                    a.partial[(int64_t)split * a.N * a.M * a.P + o] = acc[m][j][r];
-                    continue;
-                }
+                int row;
+                const int64_t o = out_index(m, j, r, row);
                 float v = acc[m][j][r] * inv;
-                if (a.bias) v += a.bias[row];
-                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
-                if (a.residual) v += a.residual[o];
+                if (hb) v += bv[m][r];
+                if (hc) v += cv[m][r];
+                if (hr) v += rv[m][j][r];
                 a.y[o] = v;
             }
-        }
 }
 
 template <int MT>
@@ -994,22 +1083,44 @@ __global__ void __launch_bounds__(WGM * WGP * 64) gemm2_f16x3_kernel(const GemmA
         }
     }
     const float inv = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f);
+    // loads of the epilogue issued together, ahead of the arithmetic (see the convolution's epilogue)
+    const bool hb = a.bias != nullptr, hc = a.chan_add != nullptr, hr = a.residual != nullptr;
+    auto out_index = [&](int m, int j, int r, int &row) -> int64_t {
+        row = ((mb * WGM + wm) * 2 + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+        return ((int64_t)n * a.M + row) * a.P + p0 + (wp * 2 + j) * 32 + l32;
+    };
+    float bv[2][16], cv[2][16];
+    f32x16 rv[2][2];
+    if (hr) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { int row; rv[m][j][r] = a.residual[out_index(m, j, r, row)]; }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t px = p0 + (wp * 2 + j) * 32 + l32;
+        for (int r = 0; r < 16; ++r) {
+            const int row = ((mb * WGM + wm) * 2 + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+            bv[m][r] = hb ? a.bias[row] : 0.f;
+            cv[m][r] = hc ? a.chan_add[(int64_t)n * a.M + row] : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = ((mb * WGM + wm) * 2 + m) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                int row;
+                const int64_t o = out_index(m, j, r, row);
                 float v = acc[m][j][r] * inv;
-                if (a.bias) v += a.bias[row];
-                if (a.chan_add) v += a.chan_add[(int64_t)n * a.M + row];
-                const int64_t o = ((int64_t)n * a.M + row) * a.P + px;
-                if (a.residual) v += a.residual[o];
+                if (hb) v += bv[m][r];
+                if (hc) v += cv[m][r];
+                if (hr) v += rv[m][j][r];
                 a.y[o] = v;
             }
-        }
 }
 
 // largest MT in {4, 2, 1} dividing Cout/32 whose grid still has >= 256 workgroups (else the smallest)
@@ -1187,6 +1298,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     a.splits = 1; a.cks = a.CK; a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_CONV
     { const char *e = getenv("MVIP_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+    { const char *e = getenv("MVIP_CONV_PROBE"); a.probe = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     hipStream_t st = as_stream(stream);
     // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
