@@ -332,7 +332,7 @@ struct ConvArgs {
     float *partial;
 #ifdef MVIP_EXPERIMENT_CONV
     int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier
-    unsigned long long *probe;   // per workgroup: {shader cycles total, 100 MHz ticks total, prologue, sync + DMA issue, compute, epilogue}
+    unsigned long long *probe;   // per workgroup (8 words): {shader cycles total, 100 MHz ticks total, prologue, DMA issue, compute, epilogue, barrier wait}
 #endif
 };
 
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, kg = lane >> 5;
 #ifdef MVIP_EXPERIMENT_CONV
-    unsigned long long pc0 = 0, pr0 = 0, p_sync = 0, p_comp = 0, p_pro = 0, p_mark = 0;
+    unsigned long long pc0 = 0, pr0 = 0, p_sync = 0, p_comp = 0, p_pro = 0, p_mark = 0, p_bar = 0;
     if (a.probe) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
 #define CV_MARK(acc_) do { if (a.probe) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - p_mark; p_mark = now_; } } while (0)
 #else
@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
             if (!(a.dbg & 16))
 #endif
             __syncthreads();                   // stage t+1 landed (vmcnt(0)); every wave is done with stage t-1
+            CV_MARK(p_bar);
             if (t + 2 < nstage) issue_weights(t + 2, (t + 2) % 3);
             if (ky == 0 && ck + 1 < nck) issue_input(ck + 1, (ck + 1) & 1);
         }
@@ -606,8 +607,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     if (a.probe && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *o = a.probe + 6 * (unsigned long long)blockIdx.x;
-        o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark;
+        unsigned long long *o = a.probe + 8 * (unsigned long long)blockIdx.x;
+        o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark; o[6] = p_bar;
     }
 #endif
 }

@@ -1,5 +1,5 @@
 """In-kernel clock probe of the 3x3 convolution (library built with -DMVIP_EXPERIMENT_CONV): per workgroup, shader
-cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of the whole kernel, the prologue, the per-stage barrier + DMA-issue
+cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of the whole kernel, the prologue, the per-stage barrier wait, the per-stage DMA-issue
 section, the per-stage MFMA / fragment-read section and the epilogue -> sustained clock and cycles per stage."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,17 +19,17 @@ for (N, cin, cout, H, W) in [(1, 128, 128, 512, 512), (1, 512, 512, 128, 128), (
     for _ in range(3):
         ops._conv3x3_launch(xs, pk, bias, None, rs, s2, N, cin, cout, H, W, y)
     torch.cuda.synchronize()
-    buf = torch.zeros(6 * 65536, device=dev, dtype=torch.int64)
+    buf = torch.zeros(8 * 65536, device=dev, dtype=torch.int64)
     os.environ['MVIP_CONV_PROBE'] = str(buf.data_ptr())
     ops._conv3x3_launch(xs, pk, bias, None, rs, s2, N, cin, cout, H, W, y)
     torch.cuda.synchronize()
     os.environ.pop('MVIP_CONV_PROBE')
-    b = buf.view(-1, 6).cpu().double()
+    b = buf.view(-1, 8).cpu().double()
     b = b[b[:, 0] > 0]
     med = b.median(0).values
     nstage = (cin // 16) * 3
     print(json.dumps({'shape': f'{N}x{cin}->{cout}@{H}x{W}', 'workgroups': int(b.shape[0]), 'stages_unsplit': nstage,
                       'cycles_total': med[0].item(), 'MHz': round(med[0].item() / (med[1].item() / 100.0), 0),
-                      'prologue': med[2].item(), 'sync_and_dma_issue': med[3].item(), 'compute': med[4].item(),
+                      'prologue': med[2].item(), 'barrier_wait': med[6].item(), 'dma_issue': med[3].item(), 'compute': med[4].item(),
                       'epilogue': med[5].item(),
                       'mfma_cycles_ideal': 'stages_of_this_workgroup x 36 x 32 (MT = 2)'}))
