@@ -266,19 +266,25 @@ cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int K
     const bool inside = p < (int64_t)OH * OW;
     const int oy = inside ? (int)(p / OW) : 0, ox = inside ? (int)(p % OW) : 0;
     const float *xn = x + n * Cin * H * W;
+    // all 16 gathers are issued before any is used: a load under its own `if` is followed by s_waitcnt vmcnt(0), i.e. 16
+    // exposed memory latencies per thread (invalid taps read element 0 and are zeroed afterwards)
     float v[16];
+    int64_t src[16];
+    bool ok[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int k = ck * 16 + c;
-        float val = 0.f;
-        if (inside && k < K) {
-            const int ci = k / taps, t = k - ci * taps;
-            const int ky = t / KW, kx = t - ky * KW;
-            const int iy = oy * stride + ky - pad_top, ix = ox * stride + kx - pad_left;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = xn[((int64_t)ci * H + iy) * W + ix] * s;
-        }
-        v[c] = val;
+        const int kk = k < K ? k : 0;
+        const int ci = kk / taps, t = kk - ci * taps;
+        const int ky = t / KW, kx = t - ky * KW;
+        const int iy = oy * stride + ky - pad_top, ix = ox * stride + kx - pad_left;
+        ok[c] = inside && k < K && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        src[c] = ok[c] ? ((int64_t)ci * H + iy) * W + ix : 0;
     }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = xn[src[c]];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = ok[c] ? v[c] * s : 0.f;
     uint4 *dst = xs + ((n * CKP + ck) * 4) * PP + p;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
