@@ -426,6 +426,12 @@ int mvip_hashgrid_nerf_forward(const float *x, const float *dirs, const float *t
  * index order is dW. */
 int64_t mvip_skinny_wgrad_slabs(int64_t P);
 int mvip_skinny_wgrad(const float *dY, const float *X, int64_t M, int64_t N, int64_t P, float *slabs, void *stream);
+/* Forward / data gradient of the same layers: Y[M][P] = act(W X), W[m][n] = w[m*w_sm + n*w_sn] (the data gradient passes
+ * the same weight with the two strides swapped), X [N][P] channel-major, 1 <= M, N <= 64, P % 4 == 0, X / Y 16-byte
+ * aligned; relu != 0 applies max(., 0) (the activation of tcnn's hidden layers).  Exact fp32 on the matrix pipe, one
+ * streaming pass: (N + M) x 4 bytes per point. */
+int mvip_skinny_linear(const float *w, int64_t w_sm, int64_t w_sn, const float *X, int64_t M, int64_t N, int64_t P,
+                       int relu, float *Y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ _SIGNATURES = {
     'mvip_hashgrid_nerf_forward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_skinny_wgrad_slabs': (_i64, [_i64]),
     'mvip_skinny_wgrad': (_int, [_c_f, _c_f, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_skinny_linear': (_int, [_c_f, _i64, _i64, _c_f, _i64, _i64, _i64, _int, _c_f, _c_f]),
     'mvip_gemm_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_gemm_pack_a': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),

@@ -116,9 +116,101 @@ skinny_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ B, in
     }
 }
 
+// ---- forward / data gradient of the same layers:  Y[M][P] = act(W[M][N] X[N][P])  --------------------------------
+// (the tcnn FullyFusedMLP forward, DS_NeRF/run_nerf_helpers_tcnn.py:88-112; dX = W^T dY is the same kernel with the
+// transposed weight).  A streaming product: (N + M) x 4 B per point against 2 M N flops, HBM-bound for M, N <= 64.
+// A wavefront owns 128 consecutive points: lane (n, kh) loads X[2s + kh][p0 + 4n .. 4n + 3] as ONE float4 (512 B
+// contiguous per half-wave), component j of that quad is its B operand (k-slot kh, column n) of the K = 2 step s of
+// accumulator tile j, so tile j holds the columns p0 + 4n + j and a lane's registers r of the four tiles are again four
+// consecutive points of one output row: float4 stores, 512 B contiguous per half-wave.  The weights (<= 16 KB) are the
+// same for every wave: lane (m, kh) keeps W[32t + m][2s + kh] of all steps in registers (N/2 per row tile).
+// Exact fp32 (v_mfma_f32_32x32x2_f32, k-ordered accumulation).  RELU fuses the activation that follows the hidden layers.
+template <int TM, int NS, bool RELU>          // TM row tiles of 32, NS = N / 2 steps (N padded to 2 NS with zero weights)
+__global__ void __launch_bounds__(256, TM == 2 ? 1 : 2)
+skinny_fwd_kernel(const float *__restrict__ Wt, int64_t w_sm, int64_t w_sn, const float *__restrict__ X, int M, int N,
+                  int64_t P, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;          // global wave index
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float a[TM][NS];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int m = 32 * t + n, k = 2 * s + kh;
+            a[t][s] = (m < M && k < N) ? Wt[m * w_sm + k * w_sn] : 0.f;
+        }
+    for (int64_t p0 = gw * 128; p0 < P; p0 += nw * 128) {
+        const int64_t pc = p0 + 4 * n;                         // P % 4 == 0: a quad is inside or outside as a whole
+        const bool in = pc < P;
+        sg_f32x16 acc[TM][4];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+        sg_f32x4 x[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {                         // all loads of the tile in flight before the first MFMA
+            const int k = 2 * s + kh;
+            x[s] = (in && k < N) ? *reinterpret_cast<const sg_f32x4 *>(X + (int64_t)k * P + pc) : sg_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], x[s].x, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], x[s].y, acc[t][1], 0, 0, 0);
+                acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], x[s].z, acc[t][2], 0, 0, 0);
+                acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], x[s].w, acc[t][3], 0, 0, 0);
+            }
+        if (in) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * t + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    if (row < M) {
+                        sg_f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+                        if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                        *reinterpret_cast<sg_f32x4 *>(Y + (int64_t)row * P + pc) = v;
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace mvip
 
 using namespace mvip;
+
+// Y [M][P] = act(W X) with W[m][n] = w[m*w_sm + n*w_sn] (so the data gradient passes the same weight with the strides
+// swapped), X [N][P], 1 <= M, N <= 64, P % 4 == 0, 16-byte aligned X / Y; relu != 0 applies max(., 0).
+extern "C" int mvip_skinny_linear(const float *w, int64_t w_sm, int64_t w_sn, const float *X, int64_t M, int64_t N, int64_t P,
+                                  int relu, float *Y, void *stream) {
+    if (M < 1 || M > 64 || N < 1 || N > 64 || P < 0 || P % 4 != 0) return MVIP_EINVAL;
+    if (P == 0) return MVIP_OK;
+    if (!w || !X || !Y || (((uintptr_t)X | (uintptr_t)Y) & 15)) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    int64_t waves = (P + 127) / 128;
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(256);
+    const int tm = M > 32 ? 2 : 1, ns = N > 32 ? 32 : (N > 16 ? 16 : 8);
+#define SKL(TM_, NS_) do { \
+        if (relu) hipLaunchKernelGGL((skinny_fwd_kernel<TM_, NS_, true>), grid, block, 0, st, w, w_sm, w_sn, X, (int)M, (int)N, P, Y); \
+        else hipLaunchKernelGGL((skinny_fwd_kernel<TM_, NS_, false>), grid, block, 0, st, w, w_sm, w_sn, X, (int)M, (int)N, P, Y); \
+    } while (0)
+    if (tm == 2 && ns == 32) SKL(2, 32);
+    else if (tm == 2 && ns == 16) SKL(2, 16);
+    else if (tm == 2) SKL(2, 8);
+    else if (ns == 32) SKL(1, 32);
+    else if (ns == 16) SKL(1, 16);
+    else SKL(1, 8);
+#undef SKL
+    return check_launch();
+}
 
 // number of [M][N] slabs mvip_skinny_wgrad writes for P points (the caller allocates slabs[count][M][N] and sums)
 extern "C" int64_t mvip_skinny_wgrad_slabs(int64_t P) {

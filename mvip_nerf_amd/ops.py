@@ -3,8 +3,9 @@
 Every function of the NeRF render / training path here launches HIP kernels from libmvipnerf.so on the
 current torch stream; inputs must be dense fp32 tensors on the GPU and nothing computes on the CPU.
 Two places still call stock torch GPU ops and say so where they do: the hash-grid model's training
-forward / data-gradient products (`_LinearCM`: plain `W @ X`; only its weight gradient is a HIP kernel)
-and a few reductions / softmaxes inside the VAE mid-block attention (`_VAEAttention`).
+forward / data-gradient products (`_LinearCM`: `W @ X` by default -- measured faster than this repo's streaming kernel,
+which is opt-in; its weight gradient is a HIP kernel) and a few reductions / softmaxes inside the VAE mid-block
+attention (`_VAEAttention`).
 """
 import weakref
 
@@ -753,33 +754,66 @@ def skinny_wgrad(dY, X):
     return slabs.sum(0)
 
 
+# Opt-in (MVIP_SKINNY_LINEAR=1): forward / data gradient of the hash-grid model's small layers on skinny_fwd_kernel instead
+# of torch matmuls.  Measured on the training iteration (tools/hashgrid_train_profile.py, same box, alternating): 15.6 ms
+# with the kernel, 15.2 ms with the library -- its 16-row MFMA tiles do half the matrix work of this kernel's 32-row tiles
+# on the 16-row layers -- so the library stays the default and the kernel a tested alternative.
+SKINNY_LINEAR = bool(int(_os.environ.get('MVIP_SKINNY_LINEAR', '0')))
+
+
+def _skinny_ok(W, X):
+    return (SKINNY_LINEAR and X.is_cuda and X.dtype == torch.float32 and W.dtype == torch.float32 and W.shape[0] <= 64 and W.shape[1] <= 64
+            and X.shape[1] % 4 == 0 and X.shape[1] > 0)
+
+
+def skinny_linear(W, X, relu=False, transpose=False):
+    """act(W X) (or act(W^T X) with transpose) for the hash-grid model's small layers: X [N, P] channel-major,
+    csrc/skinny_gemm.hip::skinny_fwd_kernel (exact fp32, one streaming pass)."""
+    Wc, Xc = _f32c(W), _f32c(X)
+    M, N = (Wc.shape[1], Wc.shape[0]) if transpose else (Wc.shape[0], Wc.shape[1])
+    P = Xc.shape[1]
+    Y = torch.empty((M, P), device=Xc.device, dtype=torch.float32)
+    sm, sn = (1, Wc.shape[1]) if transpose else (Wc.shape[1], 1)
+    call('mvip_skinny_linear', ptr(Wc), sm, sn, ptr(Xc), M, N, P, int(bool(relu)), ptr(Y), stream())
+    return Y
+
+
 class _LinearCM(torch.autograd.Function):
-    """Y [M, P] = W [M, N] @ X [N, P] (channel-major activations).  Forward and data gradient are streaming library
-    matmuls; the weight gradient (a [M, N] result contracted over millions of points, which the BLAS library runs
-    on a handful of workgroups) is csrc/skinny_gemm.hip."""
+    """Y [M, P] = act(W [M, N] @ X [N, P]) (channel-major activations, act = ReLU or identity).  Forward and data gradient
+    are library matmuls (or, opt-in, csrc/skinny_gemm.hip::skinny_fwd_kernel: see SKINNY_LINEAR); the weight gradient -- a
+    [M, N] result contracted over millions of points, which the BLAS library runs on a handful of workgroups -- is
+    skinny_wgrad_kernel."""
 
     @staticmethod
-    def forward(ctx, W, X):
-        ctx.save_for_backward(W, X)
-        return W @ X
+    def forward(ctx, W, X, relu):
+        if _skinny_ok(W, X):
+            Y = skinny_linear(W, X, relu)
+        else:
+            Y = W @ X
+            if relu:
+                Y = torch.relu(Y)
+        ctx.save_for_backward(W, X, Y if relu else None)
+        ctx.relu = relu
+        return Y
 
     @staticmethod
     def backward(ctx, dY):
-        W, X = ctx.saved_tensors
+        W, X, Y = ctx.saved_tensors
+        dZ = dY * (Y > 0) if ctx.relu else dY
         dW = dX = None
         if ctx.needs_input_grad[1]:
-            dX = W.t() @ dY
+            dX = skinny_linear(W, dZ, False, transpose=True) if _skinny_ok(W.t(), dZ) else W.t() @ dZ
         if ctx.needs_input_grad[0]:
             P = X.shape[1]
             if P % 64 == 0 and P >= 4096 and W.shape[0] <= 64 and W.shape[1] <= 64:
-                dW = skinny_wgrad(dY, X)
+                dW = skinny_wgrad(dZ, X)
             else:
-                dW = dY @ X.t()
-        return dW, dX
+                dW = dZ @ X.t()
+        return dW, dX, None
 
 
-def linear_cm(W, X):
-    return _LinearCM.apply(W, X)
+def linear_cm(W, X, relu=False):
+    return _LinearCM.apply(W, X, bool(relu))
 
 
 # Split-precision GEMM building blocks and the VAE mid-block attention built from them ------------------------

@@ -94,10 +94,10 @@ class NeRF_TCNN(nn.Module):
         W1, W2, C1, C2, C3 = self.mlp_matrices()
         feats = ops.hashgrid_encode(x, self.encoder.params, self.levels, float(self.bound),
                                     self.table_grad_atomics == 'half2')      # [32, N]
-        h = ops.linear_cm(W2, torch.relu(ops.linear_cm(W1, feats)))                               # [16, N]
+        h = ops.linear_cm(W2, ops.linear_cm(W1, feats, relu=True))                                # [16, N]
         sh = ops.sh4(d)                                                                           # [16, N]
         # the colour network's 31 inputs are padded to 32 with ones (tiny-cuda-nn pads network inputs to a
         # multiple of 16 with 1.0)
         cin = torch.cat([sh, h[1:16], torch.ones_like(h[:1])], 0)
-        c = ops.linear_cm(C3, torch.relu(ops.linear_cm(C2, torch.relu(ops.linear_cm(C1, cin)))))
+        c = ops.linear_cm(C3, ops.linear_cm(C2, ops.linear_cm(C1, cin, relu=True), relu=True))
         return torch.stack([c[0], c[1], c[2], h[0]], -1)

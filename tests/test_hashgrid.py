@@ -186,6 +186,44 @@ def test_skinny_weight_gradient_kernel(cuda):
 
 
 @pytest.mark.gpu
+def test_skinny_linear_kernel(cuda):
+    """csrc/skinny_gemm.hip::skinny_fwd_kernel: act(W X) and W^T dY for the model's layer shapes (and ragged ones) against
+    the same products in fp64; through autograd with the fused ReLU against torch's relu(W @ X)."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for M, Nn, P in ((64, 32, 65536), (16, 64, 8192), (64, 64, 200000), (3, 17, 4100), (16, 64, 4), (33, 64, 131076)):
+        W = torch.randn(M, Nn, generator=g) / Nn ** 0.5
+        X = torch.randn(Nn, P, generator=g)
+        for relu in (False, True):
+            ref = W.double() @ X.double()
+            if relu:
+                ref = torch.relu(ref)
+            got = ops.skinny_linear(W.to(cuda), X.to(cuda), relu)
+            np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+        dY = torch.randn(M, P, generator=g)
+        got = ops.skinny_linear(W.to(cuda), dY.to(cuda), False, transpose=True)
+        ref = W.double().t() @ dY.double()
+        np.testing.assert_allclose(N(got), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+    W = (torch.randn(64, 32, generator=g) / 6).to(cuda).requires_grad_(True)
+    X = torch.randn(32, 16384, generator=g).to(cuda).requires_grad_(True)
+    dY = torch.randn(64, 16384, generator=g).to(cuda)
+    saved = ops.SKINNY_LINEAR
+    ops.SKINNY_LINEAR = True
+    try:
+        y = ops.linear_cm(W, X, relu=True)
+        y.backward(dY)
+    finally:
+        ops.SKINNY_LINEAR = saved
+    gw, gx = W.grad.clone(), X.grad.clone()
+    W.grad = X.grad = None
+    yr = torch.relu(W @ X)
+    yr.backward(dY)
+    np.testing.assert_allclose(N(y), N(yr), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(gw), N(W.grad), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(N(gx), N(X.grad), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_half2_table_gradient_option(cuda):
     """Opt-in half-pair atomics for the scattered table-gradient contributions (tiny-cuda-nn's arithmetic) against
     the default fp32 atomics: same gradient to fp16 accumulation accuracy, nothing lost to under/overflow for
