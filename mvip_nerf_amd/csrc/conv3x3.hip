@@ -1401,6 +1401,12 @@ static inline int gm_splits(int64_t blocks, int64_t nstage) {
     const int64_t sks = (nstage + s - 1) / s;
     return (int)((nstage + sks - 1) / sks);
 }
+// row tiles per workgroup of the 32/64-row kernels: cv_mt's choice, or (MVIP_GEMM_MT2=1, experiment) 64 rows whenever M allows
+static inline int gm_mt(int64_t M, int64_t tiles) {
+    static const int mt2_env = [] { const char *e = getenv("MVIP_GEMM_MT2"); return e ? atoi(e) : 0; }();
+    const int mt = cv_mt(M, tiles);
+    return (mt2_env && mt == 1 && M % 64 == 0) ? 2 : mt;
+}
 static inline int gm_auto_cfg(int64_t N, int64_t M, int64_t P) {
     // Measured on the UNet's linear layers (tools/gemm_bench.py, profiles/r2_gemm_tiles.json): with K = 320..1280
     // (10..40 stages) every tile shape lands within ~10 % of the 32/64-row kernel -- these launches are bound by
@@ -1413,7 +1419,7 @@ extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, in
     if (N <= 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return 0;
     if (gm_auto_cfg(N, M, P) != 1) return 0;
     const int64_t tiles = P / GM_PIX;
-    const int MT = cv_mt(M, N * tiles);
+    const int MT = gm_mt(M, N * tiles);
     const int s = gm_splits(N * tiles * (M / (32 * MT)), K / 32);
     return s > 1 ? (int64_t)s * N * M * P * 4 : 0;
 }
@@ -1451,7 +1457,7 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
         hipLaunchKernelGGL((gemm2_f16x3_kernel<1, 2, 3>), dim3((unsigned)(N * a.tiles * a.MB)), dim3(128), 0, st, a);
     } else {
         a.tiles = (int)(P / GM_PIX);
-        const int MT = cv_mt(M, N * a.tiles);
+        const int MT = gm_mt(M, N * a.tiles);
         a.MB = (int)(M / (32 * MT));
         int64_t blocks = N * a.tiles * a.MB;
         if (workspace && auto_cfg) {
