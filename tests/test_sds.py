@@ -497,6 +497,35 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
         assert 0.5 < float(x.abs().max() / z.abs().max()) < 2.0
 
 
+def test_sds_step_launches_no_library_contraction(cuda):
+    """One full-size train_step_sd (forward + backward to the image) under the profiler: no library convolution, GEMM,
+    attention or layout-transpose kernel is launched -- every contraction of the step is a kernel of this repository
+    (MIOpen: `igemm`, `miopen`, `naive_conv`, `Im2d2Col`, `Col2Im`, `batched_transpose`; hipBLASLt / rocBLAS: `Cijk_`;
+    AOTriton: `attn_fwd`)."""
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False)
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    pred = torch.rand(1, 3, 378, 504, device=cuda, generator=gen).requires_grad_(True)
+    mask = torch.zeros(1, 1, 378, 504, device=cuda)
+    mask[:, :, 137:241, 196:307] = 1
+
+    def step(i):
+        pred.grad = None
+        (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
+    step(1000)                                               # packs weights, caches the prompt embedding
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        step(1001)
+        torch.cuda.synchronize()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
+    names = [e.key for e in prof.key_averages()]
+    banned = ('igemm', 'miopen', 'naive_conv', 'Im2d2Col', 'Col2Im', 'batched_transpose', 'Cijk_', 'attn_fwd')
+    assert not [n for n in names if any(b in n for b in banned)], [n for n in names if any(b in n for b in banned)]
+    for must in ('conv3x3_f16x3_kernel', 'gemm5_f16x3_kernel', 'attn_f16x3_kernel', 'cv_im2col_split_kernel',
+                 'resize_bilinear_fwd_kernel', 'resize_bilinear_bwd_kernel'):
+        assert any(must in n for n in names), must
+
+
 def test_plain_conv3x3_on_mfma_kernel(cuda):
     """ops.conv3x3_plain (no GroupNorm in front: the UNet's up-sampling convolutions) vs the same convolution in fp64;
     inputs of very different magnitude exercise the power-of-two input scale."""

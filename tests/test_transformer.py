@@ -227,7 +227,7 @@ def test_unet_forward_has_no_library_attention_or_gemm(cuda):
     assert not [n for n in names if 'attn_fwd' in n or 'Cijk_' in n], names        # no library attention, no library GEMM
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5])
 def test_gemm_tile_configs_vs_fp64(cuda, cfg):
     """Every workgroup-tile variant of the split-precision GEMM (csrc/conv3x3.hip) against W X in fp64, with bias,
     per-sample channel addend and residual, K from one to many 32-deep stages (pipeline prologue / tail)."""
