@@ -337,8 +337,8 @@ struct ConvArgs {
     int splits, cks;
     float *partial;
 #ifdef MVIP_EXPERIMENT_CONV
-    int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier
-    unsigned long long *probe;   // per workgroup (8 words): {shader cycles total, 100 MHz ticks total, prologue, DMA issue, compute, epilogue, barrier wait}
+    int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier, 32 = linear B reads
+    unsigned long long *probe;   // per workgroup (8 words): {shader cycles total, 100 MHz ticks total, prologue, DMA issue, compute, epilogue, barrier wait, start tick}
 #endif
 };
 
@@ -471,7 +471,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     auto load_b = [&](const char *inb, int ky, int kx) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = ((jrow0 + j) * RPB + img_rows + l32 / TW + ky) * HW + l32 % TW + kx;
+            int p = ((jrow0 + j) * RPB + img_rows + l32 / TW + ky) * HW + l32 % TW + kx;
+#ifdef MVIP_EXPERIMENT_CONV
+            if (a.dbg & 32) p = (j * 3 + kx) * 64 + lane - (kg * 2) * PIX;          // timing only: wave-linear 1-KB fragment reads
+#endif
             Bh[kx][j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
             Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + PIX * 16 + p * 16);
         }
@@ -554,6 +557,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         float t = 0.f;
         for (int m = 0; m < MT; ++m) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[m][j][r];
         if (t == 123.456f) a.y[0] = t;
+        if (a.probe && tid == 0) {
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long *o = a.probe + 8 * (unsigned long long)blockIdx.x;
+            o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark; o[6] = p_bar; o[7] = pr0;
+        }
         return;
     }
 #endif
@@ -614,7 +622,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long *o = a.probe + 8 * (unsigned long long)blockIdx.x;
-        o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark; o[6] = p_bar;
+        o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark; o[6] = p_bar; o[7] = pr0;
     }
 #endif
 }
@@ -1256,7 +1264,9 @@ extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, c
 // least 4 channel chunks (12 stages) per workgroup so the pipeline prologue stays small.
 static inline int cv_splits(int64_t blocks, int64_t CK) {
     static const int forced = [] { const char *e = getenv("MVIP_CONV_SPLITS"); return e ? atoi(e) : 0; }();   // tuning
-    int64_t s = forced > 0 ? forced : (blocks >= 256 ? 1 : (512 + blocks - 1) / blocks);
+    // the chip holds 512 of these workgroups at a time: as many splits as keep the launch within ONE round (the probe of
+    // tools/conv_probe.py on 640 channels at 32 x 32: 560 workgroups = 1.09 rounds took 72 us, the median workgroup 42)
+    int64_t s = forced > 0 ? forced : (blocks >= 256 ? 1 : 512 / blocks);
     if (s > CK / 4) s = CK / 4;
     if (s > 32) s = 32;
     if (s < 1) s = 1;

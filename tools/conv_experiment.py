@@ -1,7 +1,7 @@
 """Timing-only experiment on the 3x3 convolution kernel: which part of a launch is epilogue traffic, matrix work, operand
 staging?  Needs a library built with -DMVIP_EXPERIMENT_CONV (results are WRONG in every mode but 0):
   MVIP_EXTRA_FLAGS=-DMVIP_EXPERIMENT_CONV python -m mvip_nerf_amd.csrc.build -f
-MVIP_CONV_DBG bits: 1 no epilogue, 2 no MFMAs, 4 no input DMA, 8 no weight DMA, 16 no barrier.  One process per mode (the switch is read
+MVIP_CONV_DBG bits: 1 no epilogue, 2 no MFMAs, 4 no input DMA, 8 no weight DMA, 16 no barrier, 32 wave-linear B fragment reads.  One process per mode (the switch is read
 once)."""
 import json, os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
@@ -36,7 +36,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 else:
     for mode, tag in ((0, 'full'), (1, 'no_epilogue'), (2, 'no_mfma'), (3, 'no_mfma_no_epilogue'), (12, 'no_dma'),
                       (13, 'no_dma_no_epilogue'), (14, 'no_dma_no_mfma'), (15, 'loop_skeleton_only'),
-                      (31, 'skeleton_no_barrier'), (29, 'mfma_lds_only_no_barrier'), (16, 'full_no_barrier'), (17, 'no_barrier_no_epilogue')):
+                      (31, 'skeleton_no_barrier'), (29, 'mfma_lds_only_no_barrier'), (16, 'full_no_barrier'), (17, 'no_barrier_no_epilogue'),
+                      (29 + 32, 'mfma_lds_only_linear_b_reads'), (32, 'full_linear_b_reads')):
         r = subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, MVIP_CONV_DBG=str(mode)),
                            capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]

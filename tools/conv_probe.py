@@ -27,9 +27,13 @@ for (N, cin, cout, H, W) in [(1, 128, 128, 512, 512), (1, 512, 512, 128, 128), (
     b = buf.view(-1, 8).cpu().double()
     b = b[b[:, 0] > 0]
     med = b.median(0).values
+    start, dur = b[:, 7], b[:, 1]
+    span_us = float((start + dur).max() - start.min()) / 100.0
+    late_us = float(start.max() - start.min()) / 100.0
     nstage = (cin // 16) * 3
     print(json.dumps({'shape': f'{N}x{cin}->{cout}@{H}x{W}', 'workgroups': int(b.shape[0]), 'stages_unsplit': nstage,
                       'cycles_total': med[0].item(), 'MHz': round(med[0].item() / (med[1].item() / 100.0), 0),
                       'prologue': med[2].item(), 'barrier_wait': med[6].item(), 'dma_issue': med[3].item(), 'compute': med[4].item(),
-                      'epilogue': med[5].item(),
+                      'epilogue': med[5].item(), 'wg_us_min_med_max': [round(float(dur.min()) / 100, 1), round(float(dur.median()) / 100, 1), round(float(dur.max()) / 100, 1)],
+                      'first_start_to_last_end_us': round(span_us, 1), 'last_start_after_first_us': round(late_us, 1),
                       'mfma_cycles_ideal': 'stages_of_this_workgroup x 36 x 32 (MT = 2)'}))
