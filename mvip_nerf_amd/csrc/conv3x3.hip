@@ -60,8 +60,16 @@ __global__ void __launch_bounds__(256) cv_absmax_kernel(const float *__restrict_
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
-        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) take(x[i]);
+        // four independent 16-byte loads per thread and trip: one in flight per thread (2 MB over the whole grid) held this
+        // streaming read to ~1 TB/s
+        int64_t i = tid;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            take(a.x); take(a.y); take(a.z); take(a.w); take(b.x); take(b.y); take(b.z); take(b.w);
+            take(c.x); take(c.y); take(c.z); take(c.w); take(d.x); take(d.y); take(d.z); take(d.w);
+        }
+        for (; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
+        for (int64_t k = (n4 << 2) + tid; k < n; k += stride) take(x[k]);
     } else {
         for (int64_t i = tid; i < n; i += stride) take(x[i]);
     }
@@ -85,8 +93,14 @@ __global__ void __launch_bounds__(256) cv_absmax_scale_kernel(const float *__res
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
-        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) take(x[i]);
+        int64_t i = tid;                               // four independent 16-byte loads per thread and trip (see cv_absmax_kernel)
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            take(a.x); take(a.y); take(a.z); take(a.w); take(b.x); take(b.y); take(b.z); take(b.w);
+            take(c.x); take(c.y); take(c.z); take(c.w); take(d.x); take(d.y); take(d.z); take(d.w);
+        }
+        for (; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
+        for (int64_t k = (n4 << 2) + tid; k < n; k += stride) take(x[k]);
     } else {
         for (int64_t i = tid; i < n; i += stride) take(x[i]);
     }
@@ -116,9 +130,11 @@ __global__ void __launch_bounds__(256) cv_absmax_scale_kernel(const float *__res
     }
 }
 
+// one workgroup per 64 K elements, at most one per CU: every workgroup ends with two atomics on the same pair of words,
+// which serialise in L2 (512 workgroups: 1.54 ms over the 94 calls of an SDS step, 256: see profiles)
 static inline unsigned absmax_blocks(int64_t n) {
-    int64_t b = (n + 256 * 32 - 1) / (256 * 32);
-    return (unsigned)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    int64_t b = (n + 256 * 256 - 1) / (256 * 256);
+    return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
 // scale2 = {s, 1/s} with s a power of two such that absmax*s lies in [2^9, 2^10)
@@ -636,7 +652,15 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
     if (i4 >= total) return;
     const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
     f32x4 sum = *reinterpret_cast<const f32x4 *>(partial + i4);
-    for (int s = 1; s < splits; ++s) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)s * total + i4);
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {                   // four loads in flight, added in index order
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(partial + (int64_t)s * total + i4);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(partial + (int64_t)(s + 1) * total + i4);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(partial + (int64_t)(s + 2) * total + i4);
+        const f32x4 p3 = *reinterpret_cast<const f32x4 *>(partial + (int64_t)(s + 3) * total + i4);
+        sum += p0; sum += p1; sum += p2; sum += p3;
+    }
+    for (; s < splits; ++s) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)s * total + i4);
     const int64_t nc = i4 / HW;                        // n * Cout + co
     f32x4 v = sum * inv;                               // same order of roundings as the unsplit epilogue
     if (bias) v += bias[nc % Cout];
