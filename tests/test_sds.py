@@ -497,6 +497,44 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
         assert 0.5 < float(x.abs().max() / z.abs().max()) < 2.0
 
 
+@pytest.mark.parametrize('N_,cin,cout,H,W', [(2, 320, 64, 8, 8), (2, 640, 64, 16, 16), (1, 256, 32, 8, 32)])
+def test_conv3x3_with_and_without_workspace(cuda, N_, cin, cout, H, W):
+    """mvip_conv3x3_f16x3 (no workspace: one workgroup contracts all input channels) and mvip_conv3x3_f16x3_ws (channel
+    splits + ordered reduction) through the C ABI on the same operands: equal up to fp32 summation order, and the split
+    path is bit-reproducible."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd._lib import ptr, stream, call
+    g = torch.Generator().manual_seed(N_ + cin + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(cuda)
+    for p_ in conv.parameters():
+        p_.requires_grad_(False)
+    x = torch.randn(N_, cin, H, W, generator=g).to(cuda)
+    rs = torch.randn(N_, cout, H, W, generator=g).to(cuda)
+    ca = torch.randn(N_, cout, generator=g).to(cuda)
+    s2 = ops.absmax_scale(x)
+    xs = ops._split_buffer(N_, cin, H * W, cuda)
+    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), stream())
+    pk = ops._conv_packed(conv, False)
+    bias = conv.bias.detach()
+    nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N_, cin, cout, H, W))
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device=cuda)
+    y0, y1, y2 = (torch.empty(N_, cout, H, W, device=cuda) for _ in range(3))
+    call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_, cin, cout,
+         H, W, ptr(y0), stream())
+    for y in (y1, y2):
+        call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_,
+             cin, cout, H, W, ptr(y), ptr(ws), stream())
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + ca.double()[:, :, None, None] + rs.double()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(N(y0), ref.float().cpu().numpy(), rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(N(y1), N(y0), rtol=0, atol=2e-6 * scale)
+    assert torch.equal(y1, y2)
+    with pytest.raises(Exception):                           # the library refuses a missing workspace where it needs one
+        call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_,
+             cin, cout, H, W, ptr(y1), ptr(None), stream())
+
+
 def test_sds_step_launches_no_library_contraction(cuda):
     """One full-size train_step_sd (forward + backward to the image) under the profiler: no library convolution, GEMM,
     attention or layout-transpose kernel is launched -- every contraction of the step is a kernel of this repository
