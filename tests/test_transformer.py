@@ -249,3 +249,36 @@ def test_gemm_tile_configs_vs_fp64(cuda, cfg):
                                        err_msg=f'cfg {cfg} shape {(Nb, M, K, P)}')
     finally:
         ops.GEMM_CFG = old
+
+
+def test_gemm_random_shapes_vs_fp64(cuda):
+    """The library's own choice of GEMM kernel (register-streaming kernel, split-K where it applies) on 40 random shapes
+    -- every prologue / tail length of the 16-k pipeline, one and two row tiles, with and without the epilogue terms --
+    against W X in fp64."""
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(11)
+    gen = torch.Generator().manual_seed(11)
+    for case in range(40):
+        Nb = int(rs.choice([1, 2, 3]))
+        M = 32 * int(rs.randint(1, 17))
+        K = 32 * int(rs.randint(1, 49))
+        P = 256 * int(rs.choice([1, 2, 3]))
+        W = torch.randn(M, K, generator=gen) / K ** 0.5
+        x = torch.randn(Nb, K, P, generator=gen) * float(rs.choice([1e-3, 1.0, 40.0]))
+        bias = torch.randn(M, generator=gen) if rs.rand() < 0.5 else None
+        ca = torch.randn(Nb, M, generator=gen) if rs.rand() < 0.3 else None
+        res = torch.randn(Nb, M, P, generator=gen) if rs.rand() < 0.5 else None
+        ref = torch.einsum('mk,nkp->nmp', W.double(), x.double())
+        if bias is not None:
+            ref = ref + bias.double()[None, :, None]
+        if ca is not None:
+            ref = ref + ca.double()[:, :, None]
+        if res is not None:
+            ref = ref + res.double()
+        xd = x.to(cuda)
+        xs, s2 = ops._scaled_planes(xd, Nb, K, P, K * P, P, 1)
+        y = ops.gemm_f16x3(xs, ops.gemm_pack_a(W.to(cuda), M, K, K, 1), Nb, K, M, P,
+                           bias=None if bias is None else bias.to(cuda), chan_add=None if ca is None else ca.to(cuda),
+                           residual=None if res is None else res.to(cuda), x_scale2=s2)
+        np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=4e-6 * float(ref.abs().max()),
+                                   err_msg=f'case {case}: N={Nb} M={M} K={K} P={P}')
