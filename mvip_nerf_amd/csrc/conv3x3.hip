@@ -352,6 +352,7 @@ struct ConvArgs {
     // writes its raw accumulators to partial[split][n][Cout][H][W]; cv_split_reduce_kernel sums them in order
     int splits, cks;
     float *partial;
+    int prio;                    // 1: the co-resident workgroups alternate their wave priority stage by stage
 #ifdef MVIP_EXPERIMENT_CONV
     int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier, 32 = linear B reads
     unsigned long long *probe;   // per workgroup (8 words): {shader cycles total, 100 MHz ticks total, prologue, DMA issue, compute, epilogue, barrier wait, start tick}
@@ -512,8 +513,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 #ifdef MVIP_EXPERIMENT_CONV
     if (a.probe) { p_mark = __builtin_amdgcn_s_memtime(); p_pro = p_mark - pc0; }
 #endif
+    // The two workgroups that share a CU sit in hardware wave slots 0 and 1 of each SIMD, and at equal priority the
+    // arbiter serves the older slot first: the slot-0 workgroup of a one-round launch finished in 203 us, its partner in
+    // 238 us (tools/conv_stragglers.py), the last 35 us with one wave per SIMD.  Alternating the priority stage by stage
+    // (s_setprio; MVIP_CONV_PRIO=1) makes the pair finish together (226 / 232 us) and the launch 3 % shorter, which the
+    // whole SDS step does not show (9.95 vs 10.0 ms of convolutions) -- off by default.
+    const int prio_phase = a.prio ? (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u) : -1;
     for (int t = 0; t < nstage; ++t) {
         const int ck = t / 3, ky = t - ck * 3;
+        if (prio_phase >= 0) { if ((t + prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         CV_MARK(p_comp);
         if (t > 0) {
 #ifdef MVIP_EXPERIMENT_CONV
@@ -639,6 +647,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long *o = a.probe + 8 * (unsigned long long)blockIdx.x;
         o[0] = c1 - pc0; o[1] = r1 - pr0; o[2] = p_pro; o[3] = p_sync; o[4] = p_comp; o[5] = c1 - p_mark; o[6] = p_bar; o[7] = pr0;
+        if (a.dbg & 64) o[5] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32);   // HW_ID, XCC_ID
     }
 #endif
 }
@@ -1337,6 +1346,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
     if (tw == 8) { a.tilesX = 1; a.tilesY = 1; }
     a.splits = 1; a.cks = a.CK; a.partial = nullptr;
+    { static const int pr = [] { const char *e = getenv("MVIP_CONV_PRIO"); return e ? atoi(e) : 0; }(); a.prio = pr; }
 #ifdef MVIP_EXPERIMENT_CONV
     { const char *e = getenv("MVIP_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
     { const char *e = getenv("MVIP_CONV_PROBE"); a.probe = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
