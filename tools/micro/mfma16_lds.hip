@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(NW * 64) k(unsigned long long *out, const floa
 }
 
 template <int R, int NW>
-void run(unsigned long long *d, const float *w, int blocks) {
+void run(unsigned long long *d, const float *w, int blocks, int wg_per_cu = 1) {
+    blocks *= wg_per_cu;
     const int iters = 400;
     hipLaunchKernelGGL((k<R, NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, w, iters);
     hipLaunchKernelGGL((k<R, NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, w, iters);
@@ -56,24 +57,26 @@ void run(unsigned long long *d, const float *w, int blocks) {
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> c;
     // cycles of SIMD time per MFMA: a SIMD runs NW/4 waves, each issuing iters*72 MFMAs in (t1 - t0) cycles
-    for (int i = 0; i < blocks * NW; ++i) c.push_back((double)h[1 + i] / (iters * 72.0) / (NW / 4));
+    for (int i = 0; i < blocks * NW; ++i) c.push_back((double)h[1 + i] / (iters * 72.0) / (NW * wg_per_cu / 4));
     std::sort(c.begin(), c.end());
     printf("{\"reads_per_6_mfma\": %d, \"waves_per_simd\": %d, \"simd_cycles_per_mfma_median\": %.2f, \"p90\": %.2f, "
-           "\"lds_bytes_per_clk_per_cu\": %.1f}\n", R, NW / 4, c[c.size() / 2], c[c.size() * 9 / 10],
-           R * 1024.0 * NW / (6.0 * c[c.size() / 2] * (NW / 4)));
+           "\"lds_bytes_per_clk_per_cu\": %.1f, \"workgroups_per_cu\": %d}\n", R, NW * wg_per_cu / 4, c[c.size() / 2], c[c.size() * 9 / 10],
+           R * 1024.0 * NW * wg_per_cu / (6.0 * c[c.size() / 2] * (NW * wg_per_cu / 4)), wg_per_cu);
 }
 
 int main() {
     unsigned long long *d;
     float *w;
     const int blocks = 256;
-    hipMalloc(&d, (1 + blocks * 8) * 8);
-    hipMemset(d, 0, (1 + blocks * 8) * 8);
+    hipMalloc(&d, (1 + blocks * 16) * 8);
+    hipMemset(d, 0, (1 + blocks * 16) * 8);
     std::vector<float> hw(1 << 16);
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
     hipMalloc(&w, hw.size() * 4);
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     run<0, 4>(d, w, blocks); run<2, 4>(d, w, blocks); run<3, 4>(d, w, blocks); run<4, 4>(d, w, blocks); run<6, 4>(d, w, blocks);
     run<0, 8>(d, w, blocks); run<2, 8>(d, w, blocks); run<3, 8>(d, w, blocks); run<4, 8>(d, w, blocks); run<6, 8>(d, w, blocks);
+    // two four-wave workgroups per CU (the convolution's residency) instead of one eight-wave workgroup
+    run<0, 4>(d, w, blocks, 2); run<2, 4>(d, w, blocks, 2); run<4, 4>(d, w, blocks, 2); run<6, 4>(d, w, blocks, 2);
     return 0;
 }
