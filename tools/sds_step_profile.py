@@ -37,8 +37,9 @@ def main():
         torch.cuda.synchronize()
     ev = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
     total = sum(e.device_time_total for e in ev) / 1e3
-    n = sum(e.count for e in ev)
-    print(f'== train_step_sd: median wall {sorted(ts)[len(ts) // 2]:.2f} ms {[round(t, 1) for t in ts]}, device-busy {total:.2f} ms, {n} kernels')
+    n = sum(e.count for e in ev if e.device_time_total > 0)        # device activities only (the averages also list the launch calls)
+    n_all = sum(e.count for e in ev)
+    print(f'== train_step_sd: median wall {sorted(ts)[len(ts) // 2]:.2f} ms {[round(t, 1) for t in ts]}, device-busy {total:.2f} ms, {n} kernels / copies ({n_all} profiler events)')
     rows = []
     for e in ev[:40]:
         print(f'  {e.device_time_total / 1e3:8.3f} ms  x{e.count:4d}  {e.key[:120]}')
