@@ -558,8 +558,8 @@ def main():
                                    'attention) carry every contraction of the step.  Under dense fp16 MFMA load the shader clock of '
                                    'this part settles at ~1.67 GHz (tools/micro/mfma_clock.hip, profiles/r2_micro_mfma_clock_and_lds.json), '
                                    'i.e. a sustained peak of ~580 TFLOP/s fp32-equivalent; with operands that change from one MFMA '
-                                   'to the next, as in a real contraction, the power limit holds the part at ~25 ns per 32x32x16 MFMA '
-                                   'per SIMD (tools/micro/conv_loop.hip: ~1.3 GHz at 33 cycles), i.e. ~450 TFLOP/s fp32-equivalent',
+                                   'to the next, as in a real contraction, the power limit holds the part at ~23 ns per 32x32x16 MFMA '
+                                   'per SIMD (tools/micro/conv_loop.hip: ~1.44 GHz at 33 cycles, sustained), i.e. ~490 TFLOP/s fp32-equivalent',
                         'frac_of_sustained_f16x3_peak': round(ach / (PEAK_F16_TFLOPS / 3 * 1.67 / 2.4), 4),
                         'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,

@@ -5,6 +5,8 @@
 // (A: two 1-KB blocks per group; B: four per tap, pixel-indexed with the haloed row stride).
 //   F & 1: per-stage workgroup barrier          F & 2: per-stage LDS-DMA of the next stage's operands (19.5 KB)
 //   F & 4: B fragments at the kernel's pixel addresses (else wave-linear)
+//   F & 16: all six MFMAs of a group take the SAME two operand registers (how much of the power is operand delivery?)
+//   F & 32: the MFMAs of a group walk B first (each A fragment stays for ONE MFMA instead of four: the opposite order)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -66,8 +68,15 @@ __global__ void __launch_bounds__(256, 2) k(unsigned long long *out, const float
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
             const int kx = g / 2, m = g % 2, set = g % 3;
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bh[kx][1], acc[m][1], 0, 0, 0);
+            const h16x8 a0 = Ah[set], a1 = (F & 16) ? Ah[set] : Al[set];
+            const h16x8 b0 = Bh[kx][0], b1 = (F & 16) ? b0 : Bh[kx][1], b2 = (F & 16) ? b0 : Bl[kx][0], b3 = (F & 16) ? b0 : Bl[kx][1];
+            if (F & 32) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[m][1], 0, 0, 0);
+            } else {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[m][1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             {
                 const int g2 = g + 2;
@@ -75,10 +84,17 @@ __global__ void __launch_bounds__(256, 2) k(unsigned long long *out, const float
                 else { load_a(wb_n, g2 - 6, g2 % 3); if ((g2 - 6) % 2 == 0) load_b(inb_n, ky_n, (g2 - 6) / 2); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][1], acc[m][1], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][1], acc[m][1], 0, 0, 0);
+            if (F & 32) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b2, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b3, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[m][1], 0, 0, 0);
+            } else {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b2, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b3, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[m][1], 0, 0, 0);
+            }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -89,9 +105,10 @@ __global__ void __launch_bounds__(256, 2) k(unsigned long long *out, const float
 }
 
 template <int F>
-void run(unsigned long long *d, const float *w, const char *src) {
+void run(unsigned long long *d, const float *w, const char *src, int reps = 2) {
     const int blocks = 512, stages = 960;
-    hipLaunchKernelGGL((k<F>), dim3(blocks), dim3(256), 0, 0, d, w, src, stages);
+    // `reps` launches back to back (~1.6 ms each); the LAST one is timed: the clock needs tens of milliseconds to settle
+    for (int r = 0; r + 1 < reps; ++r) hipLaunchKernelGGL((k<F>), dim3(blocks), dim3(256), 0, 0, d, w, src, stages);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
@@ -108,8 +125,8 @@ void run(unsigned long long *d, const float *w, const char *src) {
     // wall: 512 workgroups x 4 waves x stages x 36 MFMAs over 1024 SIMDs
     const double mfma_per_simd = 2.0 * stages * 36.0;
     printf("{\"barrier\": %d, \"dma\": %d, \"pixel_b_addresses\": %d, \"simd_cycles_per_mfma_median\": %.2f, \"p90\": %.2f, "
-           "\"launch_ms\": %.3f, \"ns_per_mfma_slot\": %.2f, \"implied_MHz\": %.0f}\n", F & 1, (F >> 1) & 1, (F >> 2) & 1, c[c.size() / 2],
-           c[c.size() * 9 / 10], ms, ms * 1e6 / mfma_per_simd, c[c.size() / 2] / (ms * 1e6 / mfma_per_simd) * 1e3);
+           "\"launch_ms\": %.3f, \"ns_per_mfma_slot\": %.2f, \"implied_MHz\": %.0f, \"same_operands\": %d, \"a_changes_every_mfma\": %d, \"launches_back_to_back\": %d}\n", F & 1, (F >> 1) & 1, (F >> 2) & 1, c[c.size() / 2],
+           c[c.size() * 9 / 10], ms, ms * 1e6 / mfma_per_simd, c[c.size() / 2] / (ms * 1e6 / mfma_per_simd) * 1e3, (F >> 4) & 1, (F >> 5) & 1, reps);
 }
 
 int main() {
@@ -129,5 +146,8 @@ int main() {
         hipMemcpy(src, hs.data(), hs.size() * 2, hipMemcpyHostToDevice);
     }
     run<0>(d, w, src); run<4>(d, w, src); run<1>(d, w, src); run<5>(d, w, src); run<2>(d, w, src); run<3>(d, w, src); run<7>(d, w, src);
+    run<16>(d, w, src); run<32>(d, w, src); run<0>(d, w, src); run<16 + 7>(d, w, src); run<32 + 7>(d, w, src); run<7>(d, w, src);
+    // sustained: 100 launches (~160 ms) of the bare and of the full loop, twice
+    run<0>(d, w, src, 100); run<7>(d, w, src, 100); run<16>(d, w, src, 100); run<0>(d, w, src, 100); run<7>(d, w, src, 100);
     return 0;
 }
