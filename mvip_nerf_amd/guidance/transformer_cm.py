@@ -82,6 +82,7 @@ class _Packed:
             self.ln.append((ln.weight.detach().contiguous(), ln.bias.detach().contiguous(), float(ln.eps), s,
                             _scale_tensor(s, dev)))
         self.ctx_cache = {}
+        self.ctx_alive = None
 
     @staticmethod
     def version_key(mod):
@@ -141,6 +142,7 @@ def _prompt_kv(pk, ctx):
     hit = (ks, vp, sc[0:4], sc[4:8], T, TP)
     pk.ctx_cache.clear()                                                             # one prompt set at a time
     pk.ctx_cache[key] = hit
+    pk.ctx_alive = ctx             # the key holds an address: keep the tensor alive so that no other one can take it
     return hit
 
 
