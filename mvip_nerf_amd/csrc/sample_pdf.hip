@@ -202,8 +202,10 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
         b_key = v[0];
     }
     if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
-    const int pa = l + count_below<true>(b_key, a_key);
-    const int pb = l + count_below<false>(a_key, b_key);
+    // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
+    // +inf padding lanes of the other list and land beyond the ray's own row
+    const int pa = l + min(count_below<true>(b_key, a_key), nb);
+    const int pb = l + min(count_below<false>(a_key, b_key), na);
     if (l < na) out_row[pa] = a_key;
     if (l < nb) out_row[pb] = b_key;
     return true;

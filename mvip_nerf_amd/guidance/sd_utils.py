@@ -152,6 +152,10 @@ class _GraphedStep:
             self.graph.register_generator_state(sd.generator)
         with torch.cuda.graph(self.graph):
             self.d_pred = self._body()
+        # everything the capture read from per-prompt caches (the cross-attention's key / value planes, filled by the
+        # warm-up above) lives as long as this graph, whatever another prompt does to those caches afterwards
+        from . import transformer_cm
+        self.pinned = transformer_cm.prompt_entries(sd.unet) if isinstance(sd.unet, nn.Module) else []
 
     def _body(self):
         sd = self.sd

@@ -81,8 +81,7 @@ class _Packed:
             s = _ln_scale(ln, C)
             self.ln.append((ln.weight.detach().contiguous(), ln.bias.detach().contiguous(), float(ln.eps), s,
                             _scale_tensor(s, dev)))
-        self.ctx_cache = {}
-        self.ctx_alive = None
+        self.ctx_cache = {}             # (ptr, version, shape) -> (ctx, planes ...): one entry PER PROMPT, never cleared
 
     @staticmethod
     def version_key(mod):
@@ -92,6 +91,19 @@ class _Packed:
 def supported(mod, x):
     """fp32 device tensors, one transformer block, a head size the attention kernel is built for."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and len(mod.transformer_blocks) == 1):
+        return False
+    blk = mod.transformer_blocks[0]
+    # _Packed packs the q / k / v WEIGHTS only and addresses the feed-forward by position: anything else (biased
+    # projections, another feed-forward layout) takes the module's own forward
+    for a in (blk.attn1, blk.attn2):
+        if any(getattr(lin, 'bias', None) is not None for lin in (a.to_q, a.to_k, a.to_v)):
+            return False
+        if not isinstance(a.to_out[0], torch.nn.Linear):
+            return False
+    net = blk.ff.net
+    if not (len(net) == 3 and hasattr(net[0], 'proj') and isinstance(net[0].proj, torch.nn.Linear)
+            and type(net[0]).__name__ == 'GEGLU' and isinstance(net[2], torch.nn.Linear)
+            and net[0].proj.bias is not None and net[2].bias is not None):
         return False
     C = mod.proj_in.in_channels
     heads = mod.transformer_blocks[0].attn1.heads
@@ -122,12 +134,25 @@ def _scales(x, outer, sections, length):
     return ops.absmax_scale_sections(x, outer, sections, length)
 
 
+MAX_PROMPTS = 16
+
+
+def prompt_entries(unet):
+    """Every cached prompt entry of every transformer of `unet` (what a captured graph must keep alive)."""
+    out = []
+    for m in unet.modules():
+        pk = m.__dict__.get('_mvip_cm')
+        if pk is not None:
+            out.extend(pk.ctx_cache.values())
+    return out
+
+
 def _prompt_kv(pk, ctx):
     """Key planes / value fragments of the prompt tokens for the cross-attention (constant per prompt)."""
     key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
     hit = pk.ctx_cache.get(key)
     if hit is not None:
-        return hit
+        return hit[1:]
     N, T, E = ctx.shape
     TP, GP = 128, 256                          # key padding of the attention kernel / column padding of the GEMM
     assert T <= TP and E == pk.ctx_dim
@@ -140,9 +165,15 @@ def _prompt_kv(pk, ctx):
     ks = ops.split_planes_strided(flat, N, pk.R, TP, 2 * pk.R * GP, GP, 1, sc[0:4])
     vp = ops.attention_pack_v(flat[pk.R * GP:], N, pk.heads, pk.D, pk.DP, T, TP, 2 * pk.R * GP, GP, 1, sc[4:8])
     hit = (ks, vp, sc[0:4], sc[4:8], T, TP)
-    pk.ctx_cache.clear()                                                             # one prompt set at a time
-    pk.ctx_cache[key] = hit
-    pk.ctx_alive = ctx             # the key holds an address: keep the tensor alive so that no other one can take it
+    # One entry per prompt, kept for the life of the module: a captured hipGraph replays against the addresses of the
+    # entry it was captured with, so an entry must never be freed while another prompt runs (RGB text / text_normal
+    # alternate inside one iteration).  The entry holds `ctx` itself: the key is an address, and a live tensor keeps it
+    # from being handed to another one.  Callers that build a fresh embedding tensor per call (not this repo's
+    # SDNetworks.encode_prompt, which caches) are bounded by dropping the oldest entry; a graph keeps its own
+    # references (sd_utils._GraphedStep.pinned), so eviction never frees memory a graph replays against.
+    while len(pk.ctx_cache) >= MAX_PROMPTS:
+        pk.ctx_cache.pop(next(iter(pk.ctx_cache)))
+    pk.ctx_cache[key] = (ctx,) + hit
     return hit
 
 

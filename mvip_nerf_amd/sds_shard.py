@@ -70,7 +70,13 @@ def evaluate(terms, rank, world, dist, device):
         if terms[k].needs_latent_sum and work is not None:
             work.wait()
             work = None
-        grads[k] = terms[k].run(latent_sum if terms[k].needs_latent_sum else None).detach()
+        share = None
+        if terms[k].needs_latent_sum:
+            # no phase-1 term at all (the collaborative term with ONE neighbour view): the other views' shares sum to
+            # zero, which is what the single-process loop starts from (DS_NeRF/guidance/sd_utils.py:442)
+            share = latent_sum if latent_sum is not None else torch.zeros(terms[k].latent_shape, device=device,
+                                                                           dtype=torch.float32)
+        grads[k] = terms[k].run(share).detach()
     if work is not None:
         work.wait()
     loss = None

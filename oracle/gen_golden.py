@@ -193,6 +193,37 @@ def main():
              samples_det=npy(samples_det), samples_pytest=npy(samples_py), inds_det=npy(i_det),
              inds_pytest=npy(i_py), cdf=npy(cdf))
 
+    # ------------------------------------------------------------------ inverse-CDF sampling, tie-free
+    # A fixture on which integer parity is UNCONDITIONAL: every draw u keeps >= 8 ulp (at 1.0) from every knot of the
+    # reference's cdf, so no 1-2 ulp difference between two correct summation orders of the pdf normaliser can move an
+    # index.  (det=True is not representable this way: its last draw u = 1.0 ties with cdf[-1] = 1 +- 1 ulp by
+    # construction -- tests/test_hip_kernels.py counts those in the fixture above instead.)  The reference draws u itself
+    # under pytest=True (np.random.seed(0)); weight sets are drawn until its own draws are tie-free.
+    if want('sample_pdf_tiefree'):
+        B, Nb, Ns = 96, 63, 128
+        gap_min = 8 * 1.1920929e-07
+        for attempt in range(1000):
+            rs = np.random.RandomState(1400 + attempt)
+            bins = np.sort(rs.uniform(1.2, 7.74, size=(B, Nb)), -1).astype(np.float32)
+            w = (rs.uniform(0, 1, size=(B, Nb - 1)).astype(np.float32) ** rs.choice([1, 2, 4, 8], size=(B, 1))).astype(np.float32)
+            w[0] = 0.0; w[0, 40] = 3.0         # a spike
+            w[1] = 1.0                         # uniform weights
+            w[2, :31] = 0.0                    # mass only in the second half
+            np.random.seed(0)
+            u = np.random.rand(B, Ns).astype(np.float32)
+            ww = torch.from_numpy(w) + 1e-5
+            pdf = ww / torch.sum(ww, -1, keepdim=True)
+            cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+            gap = np.abs(cdf.numpy()[:, None, :].astype(np.float64) - u[:, :, None].astype(np.float64)).min()
+            if gap >= gap_min:
+                break
+        else:
+            raise RuntimeError('no tie-free weight set found')
+        samples = H.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ns, det=False, pytest=True)
+        inds = torch.searchsorted(cdf, torch.from_numpy(u), right=True)
+        save('sample_pdf_tiefree', bins=bins, weights=w, u=u, samples=npy(samples), inds=npy(inds), cdf=npy(cdf),
+             min_gap=np.float64(gap), weight_seed=1400 + attempt)
+
     # ------------------------------------------------------------------ render_rays
     if want('render_rays'):
         mc, mf = ref_nerf(201), ref_nerf(202)

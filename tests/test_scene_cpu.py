@@ -61,9 +61,10 @@ def _free_port():
     return p
 
 
-def _toy_terms(w, x):
+def _toy_terms(w, x, n_latent=3):
     """Frames rendered from parameters w (each rank holds the full frames here; the test is about ownership and
-    result exchange), three image terms (one needing the latent sum) and three latent terms."""
+    result exchange), three image terms (one needing the latent sum) and `n_latent` latent terms (0: the collaborative
+    term with a single neighbour view, whose last-view term still asks for the -- then all-zero -- latent sum)."""
     from mvip_nerf_amd.sds_shard import Term
     frames = [torch.tanh(x[k] @ w).reshape(1, 3, 4, 5) for k in range(3)]
     g = torch.Generator().manual_seed(0)
@@ -74,17 +75,17 @@ def _toy_terms(w, x):
         f = frames[k].detach().clone().requires_grad_(True)
         loss = (f * K[k]).sum() + (f ** 2).sum() * 0.5
         if share is not None:
-            loss = loss + f.mean() * share.sum()
+            loss = loss + f.mean() * (share.sum() + 1.0)
         loss.backward()
         return f.grad
     terms = [Term('rgb', 2, lambda s: image_term(0, None), image=frames[0]),
              Term('normal', 2, lambda s: image_term(1, None), image=frames[1]),
              Term('colla_last', 2, lambda s: image_term(2, s), image=frames[2], latent_shape=(1, 4, 8, 8), needs_latent_sum=True)]
-    terms += [Term(f'colla_{k}', 1, lambda k=k: Lt[k] * (k + 1), latent_shape=(1, 4, 8, 8)) for k in range(3)]
+    terms += [Term(f'colla_{k}', 1, lambda k=k: Lt[k] * (k + 1), latent_shape=(1, 4, 8, 8)) for k in range(n_latent)]
     return terms
 
 
-def _shard_worker(rank, world, port, out):
+def _shard_worker(rank, world, port, out, n_latent=3):
     from mvip_nerf_amd import sds_shard
     d = None
     if world > 1:
@@ -96,7 +97,7 @@ def _shard_worker(rank, world, port, out):
         w = torch.randn(6, 60, generator=g).requires_grad_(True)
         x = torch.randn(3, 1, 6, generator=g)
         calls = []
-        terms = _toy_terms(w, x)
+        terms = _toy_terms(w, x, n_latent)
         for t in terms:
             t.run = (lambda f, name: (lambda *a: (calls.append(name), f(*a))[1]))(t.run, t.name)
         loss = sds_shard.evaluate(terms, rank, world, d, torch.device('cpu'))
@@ -120,3 +121,15 @@ def test_view_sharded_terms_equal_single_process(tmp_path, world):
         np.testing.assert_allclose(got['grad'].numpy(), ref['grad'].numpy(), rtol=1e-5, atol=1e-6)
         owned += got['calls']
     assert sorted(owned) == sorted(ref['calls'])          # every term evaluated exactly once across the ranks
+
+
+def test_view_sharded_terms_single_neighbour_view(tmp_path):
+    """V == 1: no phase-1 term exists, the last-view term still needs the latent sum -> zeros, not None (it raised
+    AttributeError in share_sum.detach()); world 1 and world 2 agree."""
+    _shard_worker(0, 1, 0, str(tmp_path), 0)
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path), 0), nprocs=2, join=True)
+    ref = torch.load(os.path.join(str(tmp_path), 'w1r0.pt'))
+    assert sorted(ref['calls']) == ['colla_last', 'normal', 'rgb']
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f'w2r{r}.pt'))
+        np.testing.assert_allclose(got['grad'].numpy(), ref['grad'].numpy(), rtol=1e-5, atol=1e-6)

@@ -497,6 +497,51 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
         assert 0.5 < float(x.abs().max() / z.abs().max()) < 2.0
 
 
+def test_graphed_steps_with_two_alternating_prompts(cuda):
+    """configs[2]/[3] alternate the RGB prompt and `text_normal` inside one iteration.  Each prompt's cross-attention
+    key / value planes are cached per transformer (guidance/transformer_cm.py::_prompt_kv) and a captured hipGraph
+    replays against the addresses of the entry it was captured with: the cache must keep BOTH prompts' entries alive
+    (it once held one prompt and freed the other's planes under the other graph).  Graph replays of A, B, A, B must
+    equal the eager steps of the same prompts with the same draws, and the cache must hold both prompts."""
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    from mvip_nerf_amd.guidance import transformer_cm
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False)
+    gen = torch.Generator(device=cuda).manual_seed(4)
+    pred = torch.rand(1, 3, 96, 128, device=cuda, generator=gen).requires_grad_(True)
+    mask = torch.zeros(1, 1, 96, 128, device=cuda)
+    mask[:, :, 30:70, 40:90] = 1
+    prompts = ('a stone bench in a park', 'a normal map of a stone bench in a park')
+
+    def series(graphs):
+        sd.use_graphs = graphs
+        out = []
+        for k in range(6):
+            torch.cuda.manual_seed(100 + k)
+            pred.grad = None
+            (1e-4 * sd.train_step_sd(1000 + 37 * k, mask, prompts[k % 2], pred, guidance_scale=7.5)).sum().backward()
+            out.append(pred.grad.clone())
+            if graphs and k == 1:                   # between replays: churn the allocator so that freed planes WOULD be reused
+                junk = [torch.randn(1 << 18, device=cuda) for _ in range(64)]
+                del junk
+        return out
+
+    eager = series(False)
+    series(True)                                    # captures one graph per prompt
+    assert len(sd._graphs) == 2
+    graphed = series(True)
+    for k, (a, b) in enumerate(zip(eager, graphed)):
+        assert torch.isfinite(b).all()
+        assert float((a - b).norm() / a.norm()) < 2e-2, k        # one low-weight draw is ordered differently under capture
+    assert float((eager[0] - eager[1]).norm() / eager[0].norm()) > 1e-3        # the prompts really differ
+    for m in sd.unet.modules():
+        pk = m.__dict__.get('_mvip_cm')
+        if pk is not None:
+            assert len(pk.ctx_cache) == 2
+    assert all(len(g.pinned) >= 16 for g in sd._graphs.values())
+    assert len(transformer_cm.prompt_entries(sd.unet)) == 32
+
+
 @pytest.mark.parametrize('N_,cin,cout,H,W', [(2, 320, 64, 8, 8), (2, 640, 64, 16, 16), (1, 256, 32, 8, 32)])
 def test_conv3x3_with_and_without_workspace(cuda, N_, cin, cout, H, W):
     """mvip_conv3x3_f16x3 (no workspace: one workgroup contracts all input channels) and mvip_conv3x3_f16x3_ws (channel
