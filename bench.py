@@ -13,6 +13,13 @@ Launch: with N > 1 and no WORLD_SIZE in the environment this process only SPAWNS
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py`, rendezvous on 127.0.0.1) before touching any
 GPU, relays rank 0's JSON line and exits with the children's status; under an external launcher (WORLD_SIZE set)
 --gpus must equal the world size.  Rank 0 prints ONE JSON line.
+
+Exit status: 0 only if every leg ran.  The legs after the headline measurement exercise the collectives (sharded
+training iteration, view-sharded SDS terms, the gradient all-reduce); they run under a watchdog whose deadline lies well
+below the RCCL timeout.  If one of them raises or the deadline passes, rank 0 still prints the line -- with what was
+measured so far and an `extra_legs_error` -- and every rank leaves with status 3 (a plain exit of the rank process).
+The line's `multi_gpu` object records what the process group really was (`rccl_world`, `backend`) and the legs that
+do NOT scale by construction: the gradient bucket's all-reduce alone, the sharded iterations' times.
 """
 import argparse
 import json
@@ -63,13 +70,13 @@ def _median_time(fn, warmup, reps):
     return float(np.median(ts)), ts
 
 
-def cpu_baseline(warmup=3, reps=5, threads=None, sds_flops_full=None):
+def cpu_baseline(warmup=3, reps=5, threads=None):
     """The oracle (a torch-CPU restatement of the reference: oracle/nerf_oracle.py, oracle/sds_oracle.py) timed on the
     host cores over BOUNDED samples of the same workloads (>= 3 warm-ups, median of >= 5):
       render : n rays of frame 0 through render_rays, no_grad (metric: rays/s);
       train  : one second-stage iteration without the prior on a reduced batch: forward + backward + Adam (rays/s);
-      sds    : train_step_sd forward + backward with the SD-1.5-shaped networks at 256^2 (latents 32^2) -- a quarter
-               of the pixels -- scaled to 512^2 by the counted FLOP ratio (steps/s)."""
+      sds    : train_step_sd forward + backward with the SD-1.5-shaped networks at the real 512^2 (latents 64^2, CFG
+               batch 2): 1 warm-up, median of 3 (steps/s)."""
     from oracle import nerf_oracle as O
     from oracle import sds_oracle as S
     cores = threads or min(os.cpu_count() or 1, 32)   # more threads than this only adds sync overhead here
@@ -113,22 +120,18 @@ def cpu_baseline(warmup=3, reps=5, threads=None, sds_flops_full=None):
                       'seconds': [round(t, 3) for t in all_t]}}
     try:
         from mvip_nerf_amd.guidance.sd_nets import SDNetworks
-        from mvip_nerf_amd.guidance.flops import sds_step_flops
         nets = SDNetworks(torch.device('cpu'), torch.float32)
-        size = 256
-        pred = torch.rand(1, 3, 94, 126, generator=g).requires_grad_(True)
-        mask = torch.zeros(1, 1, 94, 126)
-        mask[:, :, 34:60, 49:77] = 1
+        pred = torch.rand(1, 3, H, W, generator=g).requires_grad_(True)
+        mask = torch.zeros(1, 1, H, W)
+        mask[:, :, (H - 104) // 2:(H - 104) // 2 + 104, (W - 111) // 2:(W - 111) // 2 + 111] = 1
 
         def sds():
             pred.grad = None
-            (1e-4 * S.train_step_sd(nets, 1000, mask, 'a stone bench in a park', pred, guidance_scale=7.5, size=size)).sum().backward()
-        t_s, all_s = _median_time(sds, min(warmup, 1), max(3, min(reps, 3)))
-        f_small = sds_step_flops(size)['per_step']
-        f_full = sds_flops_full or sds_step_flops(512)['per_step']
-        legs['sds'] = {'value': 1.0 / (t_s * f_full / f_small), 'unit': 'steps/s',
-                       'sample': f'train_step_sd forward + backward at {size}^2 ({f_small / 1e12:.2f} TFLOP), scaled to 512^2 '
-                                 f'({f_full / 1e12:.2f} TFLOP) by the counted FLOP ratio; 1 warm-up, median of 3',
+            (1e-4 * S.train_step_sd(nets, 1000, mask, 'a stone bench in a park', pred, guidance_scale=7.5, size=512)).sum().backward()
+        t_s, all_s = _median_time(sds, 1, 3)
+        legs['sds'] = {'value': 1.0 / t_s, 'unit': 'steps/s',
+                       'sample': 'train_step_sd forward + backward at the real size (504x378 -> 512^2, latents 64^2, CFG batch 2), '
+                                 'measured, not modelled; 1 warm-up, median of 3',
                        'seconds': [round(t, 3) for t in all_s]}
         del nets
     except Exception as e:                                  # a reported baseline, never fatal for the bench line
@@ -198,17 +201,119 @@ def spawn_ranks(n, argv):
     return 0 if line is not None else 1
 
 
+EXIT_LEG_FAILED = 3
+RCCL_TIMEOUT_S = 1800            # far above the extra-leg deadline: the watchdog below must fire first
+
+
+class Reporter:
+    """Owns the ONE JSON line and the exit status.  `guarded(fn)` runs the legs that follow the headline measurement:
+    under a watchdog THREAD when there is more than one rank (a rank stuck inside a collective sits in a C call that
+    never returns to the interpreter, so a signal handler would not run).  Whatever happens, rank 0 prints the line
+    exactly once; a failed or timed-out leg makes every rank leave with EXIT_LEG_FAILED.
+
+    A rank that fails tells the others out of band -- a flag file named after the rendezvous port (the ranks share one
+    node) -- instead of just exiting: the launcher answers a dead rank by terminating the rest at once, which would
+    take rank 0 down inside its collective before it printed.  Rank 0 prints and leaves as soon as it sees the flag (or
+    its own failure / deadline); the other ranks leave a few seconds later."""
+    GRACE_S = 5.0
+
+    def __init__(self, result, rank, world, before_print=None):
+        import tempfile
+        import threading
+        self.result, self.rank, self.world = result, rank, world
+        self.printed = False
+        self.before_print = before_print
+        self.lock = threading.Lock()
+        self.done = threading.Event()
+        self.flag = os.path.join(tempfile.gettempdir(), f"mvip_bench_failed_{os.environ.get('MASTER_PORT', 'single')}")
+        if rank == 0 and os.path.exists(self.flag):        # a stale flag of an earlier job on this port; every rank passes
+            os.remove(self.flag)                            # a barrier after this point before it looks at the flag
+
+    def print_line(self, ok):
+        if self.rank != 0 or self.printed:
+            return
+        self.printed = True
+        if ok and self.before_print is not None:
+            self.before_print(self.result)
+        line = None
+        for _ in range(3):
+            try:
+                line = json.dumps(dict(self.result))
+                break
+            except RuntimeError:                # the main thread added a key while the watchdog was serialising
+                time.sleep(0.05)
+        print(line, flush=True)
+
+    def fail(self, why, tell_others=True):
+        self.lock.acquire()                     # first caller wins (main thread vs watchdog); it never releases
+        self.result['extra_legs_error'] = why
+        print(f'[bench] rank {self.rank}: {why}', file=sys.stderr, flush=True)
+        if tell_others and self.world > 1:
+            try:
+                with open(self.flag, 'w') as f:
+                    f.write(f'rank {self.rank}: {why}')
+            except OSError:
+                pass
+        if self.rank == 0:
+            self.print_line(ok=False)
+            sys.stdout.flush()
+        else:
+            time.sleep(self.GRACE_S)            # rank 0 prints before the launcher tears the job down
+        os._exit(EXIT_LEG_FAILED)               # not sys.exit: a stuck collective / other threads must not be joined
+
+    def _watch(self, deadline):
+        t_end = time.monotonic() + deadline
+        while not self.done.wait(0.5):
+            if os.path.exists(self.flag):
+                try:
+                    who = open(self.flag).read()
+                except OSError:
+                    who = 'another rank'
+                self.fail(f'a leg failed elsewhere ({who}); legs reported so far are complete', tell_others=False)
+            if time.monotonic() > t_end:
+                self.fail(f'deadline ({deadline:.0f} s): a multi-rank leg did not finish; legs reported so far are complete')
+
+    def guarded(self, fn):
+        if self.world > 1:
+            import threading
+            deadline = float(os.environ.get('MVIP_BENCH_EXTRA_DEADLINE_S', 600))
+            threading.Thread(target=self._watch, args=(deadline,), daemon=True).start()
+        try:
+            fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            self.fail(f'{type(e).__name__}: {e}')
+        self.done.set()
+        self.print_line(ok=True)
+
+
 def dry_run(world, rank, args):
-    """MVIP_BENCH_DRYRUN=1: the launch / rendezvous path without GPU work (CPU test of the launcher)."""
+    """MVIP_BENCH_DRYRUN=1: the launch / rendezvous / watchdog path without GPU work (CPU tests of the launcher).
+    MVIP_BENCH_DRYRUN_HANG_RANK=r makes rank r sleep instead of joining the extra leg's collective."""
     import torch.distributed as dist
+    result = {}
+    rep = Reporter(result, rank, world)          # clears a stale failure flag BEFORE the first collective
     if world > 1:
         dist.init_process_group('gloo')
         t = torch.tensor([float(rank)])
         dist.all_reduce(t)
         assert float(t) == world * (world - 1) / 2
-    if rank == 0:
-        print(json.dumps({'metric': 'dry-run (launcher only)', 'value': 0.0, 'unit': 'rays/s', 'n_gpus': world,
-                          'steps': args.steps, 'warmup': args.warmup}), flush=True)
+    result.update({'metric': 'dry-run (launcher only)', 'value': 0.0, 'unit': 'rays/s', 'n_gpus': world,
+              'steps': args.steps, 'warmup': args.warmup,
+              'multi_gpu': {'rccl_world': dist.get_world_size() if world > 1 else 1,
+                            'backend': dist.get_backend() if world > 1 else None}})
+
+    def extra():
+        if os.environ.get('MVIP_BENCH_DRYRUN_HANG_RANK') == str(rank):
+            time.sleep(3600)
+        if os.environ.get('MVIP_BENCH_DRYRUN_RAISE_RANK') == str(rank):
+            raise RuntimeError('simulated leg failure')
+        if world > 1:
+            t = torch.tensor([1.0])
+            dist.all_reduce(t)
+        result['extra_leg'] = 'done'
+    rep.guarded(extra)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -245,13 +350,15 @@ def main():
     backend = os.environ.get('MVIP_DIST_BACKEND', 'gloo' if single else 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    result = {}
+    rep = Reporter(result, rank, world)          # clears a stale failure flag BEFORE the first collective / barrier
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             import datetime
-            dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=300))   # RCCL over xGMI
+            dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=RCCL_TIMEOUT_S))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
 
@@ -284,7 +391,7 @@ def main():
         dt = float(t.item())
 
     rays_per_step = H * W * world
-    result = {
+    result.update({
         'metric': 'rays_per_sec (coarse+fine, 64+128 samples, 504x378)', 'value': rays_per_step * args.steps / dt,
         'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -293,40 +400,35 @@ def main():
                                'white_bkgd, test-mode kwargs (BASELINE configs[1] geometry at the metric resolution)',
                    'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
                    'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
-    }
-    # The further legs exercise collectives (sharded training iteration, view-sharded SDS terms).  With more than one
-    # rank they run under a deadline and a guard, so that the headline line above is printed even if one of them fails
-    # or stalls on a machine this code has not been run on (RCCL paths cannot be exercised on the 1-GPU build boxes).
-    printed = [False]
+    })
+    mg = {'rccl_world': dist.get_world_size() if dist is not None else 1,
+          'backend': dist.get_backend() if dist is not None else None}
+    result['multi_gpu'] = mg
     if rank == 0:
         result['roofline'] = kernel_roofline(run, te, device)          # local to rank 0: no collective
 
-    def finish(code=None):
-        if rank == 0 and not printed[0]:
-            printed[0] = True
-            if code is None and world == 1 and not args.no_cpu_baseline:
-                result['cpu_baseline'] = cpu_baseline(args.cpu_warmup, args.cpu_reps,
-                                                      sds_flops_full=result.get('sds', {}).get('roofline', {}).get('flops_per_step'))
-            line = None
-            for _ in range(3):
-                try:
-                    line = json.dumps(dict(result))
-                    break
-                except RuntimeError:                # the main thread added a key while the watchdog was serialising
-                    time.sleep(0.05)
-            print(line, flush=True)
-        if code is not None:
-            os._exit(code)
-
-    def on_deadline():
-        # Runs on a watchdog THREAD: a rank stuck inside a collective sits in a C call that never returns to the
-        # interpreter, where a signal handler would not run.  The headline measurement above is complete, so the line goes
-        # out with what the extra legs delivered so far and the process leaves with status 0.
-        result['extra_legs_error'] = 'deadline: a multi-rank leg did not finish; legs reported so far are complete'
-        print(f'[bench] rank {rank}: extra-leg deadline reached', file=sys.stderr, flush=True)
-        finish(0)
+    def add_cpu_baseline(res):
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.cpu_warmup, args.cpu_reps)
+    rep.before_print = add_cpu_baseline
 
     def extra_legs():
+        # ---- the gradient bucket's all-reduce ALONE (1,191,688 floats = 4.77 MB, the only per-iteration data-path
+        #      collective of the ray-sharded training step), 20 repetitions between barriers
+        if dist is not None:
+            bucket = torch.zeros(sum(p.numel() for p in grad_vars), device=device, dtype=torch.float32)
+            for _ in range(3):
+                dist.all_reduce(bucket)
+            barrier()
+            ta = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(bucket)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - ta) / 20], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mg['allreduce_ms'] = float(t.item()) * 1e3
+            mg['allreduce_bytes'] = bucket.numel() * 4
+            del bucket
         # ---- extra leg: the reference's second model (hash grid + tiny MLPs, the shipped config's `no_tcnn = False`),
         # same frames / same training iteration; SURVEY.md 8(f) row 4
         if args.hashgrid:
@@ -430,6 +532,7 @@ def main():
                 dt_tr16 = float(t.item())
             result['train_f16x3'] = {'rays_per_sec': n_rays * world / dt_tr16, 'ms_per_step': dt_tr16 / args.train_steps * 1e3,
                                      'what': 'the same iteration with train_precision=1 (split-precision MFMA kernels)'}
+            mg['train_ms'] = dt_tr / args.train_steps * 1e3
             result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
                                'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
                                'what': 'second-stage iteration without the diffusion prior: masked-set render '
@@ -539,6 +642,7 @@ def main():
                     t = torch.tensor([dt5], device=device, dtype=torch.float64)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     dt5 = float(t.item())
+                mg['config3_ms' if colla else 'config2_ms'] = dt5 / nsteps * 1e3
                 result[name] = {'ms_per_step': dt5 / nsteps * 1e3, 'rays_with_grad_per_step_per_gpu': rays // nsteps,
                                 'sds_evaluations_per_step': 2 + (5 if colla else 0)}
                 del tr2
@@ -568,32 +672,20 @@ def main():
                              'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
                              'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
                              '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
+            mg['train_with_sds_ms'] = dt_full / args.sds_steps * 1e3
+            mg['what'] = ('STRONG-scaling legs (fixed work, rays and SDS terms sharded over the ranks): train_ms = second-stage '
+                          'iteration without the prior, train_with_sds_ms = configs[1] iteration, config2_ms / config3_ms = '
+                          'configs[2] / configs[3] iterations at the metric resolution; allreduce_ms = the 4.77 MB gradient '
+                          'bucket alone.  The headline `value` is weak scaling (one frame per rank, no collective)')
             result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
                                         'iterations_per_sec': args.sds_steps / dt_full,
                                         'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
                                                 '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}
 
-    timer = None
-    if world > 1:
-        import threading
-        timer = threading.Timer(float(os.environ.get('MVIP_BENCH_EXTRA_DEADLINE_S', 600)), on_deadline)
-        timer.daemon = True
-        timer.start()
-    try:
-        extra_legs()
-    except Exception as e:
-        if world == 1:
-            raise
-        result['extra_legs_error'] = f'{type(e).__name__}: {e}'
-        print(f'[bench] rank {rank}: extra legs stopped: {type(e).__name__}: {e}', file=sys.stderr, flush=True)
-        finish(0)                      # the other ranks may be waiting in a collective: leave without joining them (they
-                                       # leave at their own deadline; rank 0 prints the line first, here or there)
-    finish()
+    rep.guarded(extra_legs)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if timer is not None:
-        timer.cancel()
 
 
 if __name__ == '__main__':

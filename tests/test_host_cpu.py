@@ -5,6 +5,7 @@ import types
 import zlib
 
 import numpy as np
+import pytest
 import torch
 
 
@@ -114,6 +115,36 @@ def test_bench_launcher_spawns_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3'], env=dict(env, WORLD_SIZE='2', RANK='0'),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr
+
+
+@pytest.mark.parametrize('fault', ['HANG', 'RAISE'])
+def test_bench_exit_status_reflects_a_failed_multi_rank_leg(fault):
+    """A rank that hangs in (or raises before) a collective of the legs after the headline measurement: rank 0 still
+    prints exactly ONE JSON line -- carrying `extra_legs_error` and what the process group really was -- and the
+    launcher's exit status is NOT zero (a broken multi-GPU path once passed as a good scaling run with rc 0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(MVIP_BENCH_DRYRUN='1', MVIP_BENCH_EXTRA_DEADLINE_S='6')
+    env[f'MVIP_BENCH_DRYRUN_{fault}_RANK'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and 'extra_legs_error' in rec and 'extra_leg' not in rec
+    assert rec['multi_gpu'] == {'rccl_world': 2, 'backend': 'gloo'}
+    # and the healthy run reports the same fields with status 0
+    env.pop(f'MVIP_BENCH_DRYRUN_{fault}_RANK')
+    ok = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    rec = json.loads([l for l in ok.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert rec['extra_leg'] == 'done' and 'extra_legs_error' not in rec and rec['multi_gpu']['rccl_world'] == 2
 
 
 def test_clip_text_tower_matches_transformers(golden):
