@@ -375,6 +375,35 @@ int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, 
 int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
                          const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
                          int64_t Lk, int64_t LkP, float softmax_scale, int flags, float *out, void *stream);
+/* Contractions that hand each other OPERANDS (round 3; same call sites: the unet(...) call of
+ * DS_NeRF/guidance/sd_utils.py:390-403 / :240).  Between two contractions of a transformer block the reference
+ * materialises an fp32 tensor; rounds 1-2 of this library followed it with an absolute-maximum pass and a split pass.
+ * Here the PRODUCER's epilogue writes the consumer's operand format, scaled by a power of two that the caller fixes
+ * BEFORE the launch from a rigorous bound of the result (|W x| <= |x|max * max_row ||W||_1; |LayerNorm(x)| <=
+ * sqrt(C) |gamma|max + |beta|max; |softmax(..) V| <= |V|max; |a gelu(g)| <= |a| |g|): no overflow by construction, and the
+ * fp16 hi + lo pair keeps ~2^-25 of the scaled range, i.e. fp32-grade accuracy relative to the tensor's maximum for
+ * bounds up to ~2^15 too wide.
+ * mvip_gemm_f16x3_sinks: Y = W X + bias with the M rows cut into nsec <= 3 consecutive sections of sec_rows[i] rows
+ *   (multiples of 64).  Section i leaves as (Y * sec_scale[i]) in format sec_kind[i]:
+ *     1  split planes [N][sec_rows/16][2][2][P][8 halves] -- the B operand of mvip_gemm_f16x3 / the Q or K operand of
+ *        mvip_attention_f16x3_sink;
+ *     2  attention V fragments [N][heads][v_dt][P/16][2][64][8 halves], sec_rows = heads * v_dt * 32 (head h's rows at
+ *        h * v_dt * 32 .., zero rows beyond its D channels); only as the LAST section (computed with the MFMA operands
+ *        swapped, i.e. transposed, in a launch of its own).
+ * mvip_gemm_geglu_f16x3_sink: mvip_gemm_geglu_f16x3 whose product leaves as planes [N][(M2/2)/16][2][2][P][8] * out_scale.
+ * mvip_attention_f16x3_sink: mvip_attention_f16x3 on operands written by mvip_gemm_f16x3_sinks (q_stride / k_stride tokens
+ *   per plane, v_groups 16-key groups per V block) whose result leaves as the output projection's operand planes
+ *   [N][heads*D/16][2][2][LqP][8 halves] scaled by v_scale2[0]; columns >= Lq are not written. */
+int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
+                          int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
+                          void *const *sec_ptr, const float *sec_scale, int v_dt, void *stream);
+int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
+                               int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes, float out_scale,
+                               void *stream);
+int mvip_attention_f16x3_sink(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
+                              const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
+                              int64_t Lk, int64_t LkP, int64_t q_stride, int64_t k_stride, int64_t v_groups,
+                              float softmax_scale, int flags, void *out_planes, void *stream);
 /* LayerNorm over the channel axis of x [N][C][LP] for tokens < L, times out_scale (a power of two), written as
  * split planes [N][C/16][2][2][LP][8] (zero for tokens >= L).  C % 64 == 0, LP % 256 == 0; workspace of
  * mvip_layernorm_workspace_bytes(N, C, LP) bytes (fp64 partial moments), 8-byte aligned. */

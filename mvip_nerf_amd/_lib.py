@@ -104,6 +104,11 @@ _SIGNATURES = {
     'mvip_absmax_scale_sections': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_attention_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _flt, _int,
                                     _c_f, _c_f]),
+    'mvip_gemm_f16x3_sinks': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _int, ctypes.POINTER(_i64),
+                                     ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_flt), _int, _c_f]),
+    'mvip_gemm_geglu_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f]),
+    'mvip_attention_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                         _i64, _i64, _flt, _int, _c_f, _c_f]),
     'mvip_layernorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f, _c_f]),
     'mvip_geglu': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),

@@ -29,6 +29,7 @@
 // tile; 124 registers and 28 KB of LDS for the 40-channel heads (32-key tiles) so that four waves share a SIMD and
 // one wave's softmax (VALU) runs under the others' MFMAs.
 #include "common.h"
+#include "plane_sink.h"
 
 namespace mvip {
 namespace attn {
@@ -48,6 +49,14 @@ struct AttnArgs {
     float *o;
     int N, heads, Lq, LqP, Lk, LkP, D, qblocks;
     float softmax_scale;
+    // operand strides: tokens per Q plane / per K plane, 16-key groups per (head, row tile) block of V.  The packers
+    // of this file write compact operands (Lq, LkP, LkP / 16); a GEMM epilogue (mvip_gemm_f16x3_sinks) writes them at
+    // its own column count P.
+    int q_stride, k_stride, v_groups;
+    // op != nullptr: the result leaves as the output projection's operand planes [N][heads*D/16][2][2][LqP][8 halves],
+    // still multiplied by V's scale (|softmax(..) V| <= |V|max, so V's power of two fits) -- no fp32 tensor, no
+    // absolute-maximum pass, no split pass between attention and its output projection
+    char *op;
 };
 
 constexpr float P_SHIFT = 10.0f;          // probabilities travel as p * 2^10 so that their fp16 lo terms stay normal
@@ -84,12 +93,12 @@ attn_f16x3_kernel(const AttnArgs a) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int64_t plane = ((int64_t)(n * QC + head * NCH + c) * 2 + h) * 2;
-        qh[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 0) * a.Lq + q) * 16);
-        ql[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 1) * a.Lq + q) * 16);
+        qh[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 0) * a.q_stride + q) * 16);
+        ql[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 1) * a.q_stride + q) * 16);
     }
 
-    const char *k_base = a.ks + (int64_t)(n * QC + head * NCH) * 4 * a.LkP * 16;
-    const char *v_base = a.vp + (int64_t)(n * a.heads + head) * DT * (a.LkP / 16) * 2048;
+    const char *k_base = a.ks + (int64_t)(n * QC + head * NCH) * 4 * a.k_stride * 16;
+    const char *v_base = a.vp + (int64_t)(n * a.heads + head) * DT * a.v_groups * 2048;
     auto issue_tile = [&](int t, int buf) {
         char *kd = lds + buf * (KB + VB), *vd = kd + KB;
         const int k0 = t * KT;
@@ -98,9 +107,9 @@ attn_f16x3_kernel(const AttnArgs a) {
             const int p = p0 + wave;
             if (p < NKP) {
                 if (KT == 64) {            // piece = (chunk, kg, hl): 64 keys x 16 B, contiguous in the plane
-                    glds16b(k_base + ((int64_t)p * a.LkP + k0 + lane) * 16, kd + p * 1024);
+                    glds16b(k_base + ((int64_t)p * a.k_stride + k0 + lane) * 16, kd + p * 1024);
                 } else {                   // KT == 32: piece = (chunk, kg), lanes 0..31 -> hi plane, 32..63 -> lo plane
-                    glds16b(k_base + ((int64_t)(p * 2 + h) * a.LkP + k0 + l32) * 16, kd + p * 1024);
+                    glds16b(k_base + ((int64_t)(p * 2 + h) * a.k_stride + k0 + l32) * 16, kd + p * 1024);
                 }
             }
         }
@@ -109,7 +118,7 @@ attn_f16x3_kernel(const AttnArgs a) {
             const int p = p0 + wave;
             if (p < NVP) {
                 const int dt = p / ((KT / 16) * 2), r = p % ((KT / 16) * 2);
-                glds16b(v_base + ((int64_t)dt * (a.LkP / 16) * 2 + (k0 / 16) * 2 + r) * 1024 + lane * 16, vd + p * 1024);
+                glds16b(v_base + ((int64_t)dt * a.v_groups * 2 + (k0 / 16) * 2 + r) * 1024 + lane * 16, vd + p * 1024);
             }
         }
     };
@@ -199,6 +208,22 @@ attn_f16x3_kernel(const AttnArgs a) {
 
     // ---- epilogue: O / (l s_v), fp32 channel-major ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (a.op) {
+        // operand planes for the output projection: O / l, still carrying V's power-of-two scale
+        const float il = 1.0f / l_tot;
+        const int n8 = a.heads * a.D / 8;                     // 8-channel blocks of a sample's plane set
+        char *pn = a.op + (int64_t)n * (n8 / 2) * 4 * a.LqP * 16;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = o[d][r] * il;
+            // blocks of this head beyond its D channels (head dim padded to DT * 32 rows) are not written
+            const int head_blk = head * (a.D / 8), last = head_blk + a.D / 8;
+            sink_store_planes(pn, a.LqP, head_blk + d * 4, last < n8 ? last : n8, q, h, v, q_ok);
+        }
+        return;
+    }
     const float inv = a.v_scale2[1] / l_tot;
     if (q_ok) {
         float *op = a.o + ((int64_t)n * a.heads * a.D + (int64_t)head * a.D) * a.LqP + q;
@@ -360,19 +385,22 @@ extern "C" int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t
     return check_launch();
 }
 
-extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2,
-                                    const float *k_scale2, const float *v_scale2, int64_t N, int64_t heads, int64_t D,
-                                    int64_t Lq, int64_t LqP, int64_t Lk, int64_t LkP, float softmax_scale, int flags,
-                                    float *out, void *stream) {
-    if (N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0)
+static int attention_launch(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
+                            const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP, int64_t Lk,
+                            int64_t LkP, int64_t q_stride, int64_t k_stride, int64_t v_groups, float softmax_scale, int flags,
+                            float *out, void *out_planes, void *stream) {
+    if (N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0 ||
+        q_stride < Lq || k_stride < LkP || v_groups < LkP / 16)
         return MVIP_EINVAL;
     if (!mvip_attention_supported(D)) return MVIP_EUNSUP;
     if (N == 0) return MVIP_OK;
-    if (!qs || !ks || !vp || !q_scale2 || !k_scale2 || !v_scale2 || !out) return MVIP_EINVAL;
+    if (!qs || !ks || !vp || !q_scale2 || !k_scale2 || !v_scale2 || (!out && !out_planes)) return MVIP_EINVAL;
+    if (out_planes && (heads * D) % 16 != 0) return MVIP_EINVAL;
     AttnArgs a;
     a.qs = (const char *)qs; a.ks = (const char *)ks; a.vp = (const char *)vp;
-    a.q_scale2 = q_scale2; a.k_scale2 = k_scale2; a.v_scale2 = v_scale2; a.o = out;
+    a.q_scale2 = q_scale2; a.k_scale2 = k_scale2; a.v_scale2 = v_scale2; a.o = out; a.op = (char *)out_planes;
     a.N = (int)N; a.heads = (int)heads; a.Lq = (int)Lq; a.LqP = (int)LqP; a.Lk = (int)Lk; a.LkP = (int)LkP; a.D = (int)D;
+    a.q_stride = (int)q_stride; a.k_stride = (int)k_stride; a.v_groups = (int)v_groups;
     // 256 queries per workgroup (8 waves) once that still gives every CU a workgroup; flags bit 1 forces 128
     const bool wide = D == 40 && !(flags & 2) && N * heads * ((Lq + 255) / 256) >= 256;
     a.qblocks = (int)(wide ? (Lq + 255) / 256 : (Lq + 127) / 128);
@@ -391,4 +419,25 @@ extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *
     else
         hipLaunchKernelGGL((attn_f16x3_kernel<10, 5, 32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     return check_launch();
+}
+
+extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2,
+                                    const float *k_scale2, const float *v_scale2, int64_t N, int64_t heads, int64_t D,
+                                    int64_t Lq, int64_t LqP, int64_t Lk, int64_t LkP, float softmax_scale, int flags,
+                                    float *out, void *stream) {
+    return attention_launch(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, Lq, LkP, LkP / 16,
+                            softmax_scale, flags, out, nullptr, stream);
+}
+
+// The same attention between two GEMMs that exchange OPERANDS: qs / ks / vp as written by mvip_gemm_f16x3_sinks (planes of
+// q_stride / k_stride tokens, v_groups 16-key groups per V block: the producing GEMM's column count P and P / 16), and
+// the result as the output projection's operand planes [N][heads*D/16][2][2][LqP][8 halves], still scaled by V's scale
+// v_scale2[0] (pass v_scale2 as that GEMM's x_scale2).  Columns >= Lq of out_planes are not written.
+extern "C" int mvip_attention_f16x3_sink(const void *qs, const void *ks, const void *vp, const float *q_scale2,
+                                         const float *k_scale2, const float *v_scale2, int64_t N, int64_t heads, int64_t D,
+                                         int64_t Lq, int64_t LqP, int64_t Lk, int64_t LkP, int64_t q_stride, int64_t k_stride,
+                                         int64_t v_groups, float softmax_scale, int flags, void *out_planes, void *stream) {
+    if (!out_planes) return MVIP_EINVAL;
+    return attention_launch(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, q_stride, k_stride,
+                            v_groups, softmax_scale, flags, nullptr, out_planes, stream);
 }

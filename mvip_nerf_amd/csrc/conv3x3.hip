@@ -21,6 +21,7 @@
 //     and the input tile double-buffered in LDS, one barrier per stage.
 //   * epilogue: x 1/scale, + bias, + per-(sample, channel) addend (time embedding), + residual, NCHW fp32.
 #include "common.h"
+#include "plane_sink.h"
 #include <stdlib.h>
 
 namespace mvip {
@@ -699,10 +700,43 @@ struct GemmArgs {
     // and writes raw accumulators to partial[split][n][M][P]; cv_split_reduce_kernel adds them in order
     int splits, sks;
     float *partial;
+    // Operand sinks (nsec > 0; gemm5_f16x3_kernel only): the M rows are cut into <= 3 consecutive sections (multiples of
+    // 64 rows), each written in the operand format of the contraction that consumes it, scaled by a power of two fixed
+    // before the launch: kind 1 = split planes [N][rows/16][2][2][P][8] (also the GEGLU product when geglu_L > 0, rows =
+    // M/2), kind 2 = attention V fragments [N][heads][DT][P/16][2][64][8] -- that section is computed TRANSPOSED (the MFMA
+    // operands swapped: lane = output row, registers = tokens), which is the fragment order of csrc/attention.hip.
+    // y is not written for these rows.
+    struct Sec { char *ptr; float scale; int row_end, kind; } sec[3];
+    int nsec, v_dt;              // v_dt: 32-row tiles per head in a kind-2 section
 #ifdef MVIP_EXPERIMENT_GEMM
     int dbg;                     // timing experiments: 1 = no epilogue stores, 2 = no MFMAs, 4 = no LDS reads either
 #endif
 };
+
+// epilogue of the SWAP instantiation: the accumulators are transposed (lane = row of the weight tile, registers = the 32
+// tokens of column block j) and leave as attention V fragments [N][heads][v_dt][P/16][2][64][8 halves]; the launch's M
+// rows are the heads * v_dt * 32 rows of ONE section (a.sec[0])
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue_vfrag(const GemmArgs &a, f32x16 (&acc)[MT][2], int n, int mb, int64_t p0, int wave,
+                                                    int lane) {
+    const int l32 = lane & 31;
+    const float sc = a.sec[0].scale;
+    const float mul = a.w_scale2[1] * (a.x_scale2 ? a.x_scale2[1] : 1.f) * sc;
+    const bool hb = a.bias != nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int lt = mb * MT + m;                            // (head, dt) block of this row tile: lt = head * v_dt + dt
+        const float bs = hb ? a.bias[lt * 32 + l32] * sc : 0.f;
+        char *vt = a.sec[0].ptr + ((int64_t)n * (a.M / 32) + lt) * (a.P / 16) * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[m][j][r] * mul + bs;
+            sink_store_vfrag(vt, (int)((p0 + (2 * wave + j) * 32) / 16), lane, v);
+        }
+    }
+}
 
 // epilogue shared by the 32/64-row GEMM kernels: acc[m][j] = 32 x 32 tile (row tile mb*MT + m, columns p0 + (2 wave + j)*32 ..)
 template <int MT>
@@ -720,6 +754,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
 #endif
     // all loads of the epilogue are issued together, ahead of the arithmetic (see the convolution's epilogue)
     const bool hb = a.bias != nullptr, hc = a.chan_add != nullptr, hr = a.residual != nullptr;
+    if (a.nsec > 0 && a.geglu_L == 0) {
+        // ---- operand sinks: this workgroup's MT row tiles lie in ONE section (sections are multiples of 64 rows) ----
+        const int row0 = mb * MT * 32;
+        GemmArgs::Sec sc = a.sec[0];                 // static indices only: a dynamically indexed kernel argument goes to scratch
+        int sec_row0 = 0;
+        if (a.nsec > 1 && row0 >= a.sec[0].row_end) { sc = a.sec[1]; sec_row0 = a.sec[0].row_end; }
+        if (a.nsec > 2 && row0 >= a.sec[1].row_end) { sc = a.sec[2]; sec_row0 = a.sec[1].row_end; }
+        const float mul = inv * sc.scale;
+        {
+            const int n_blk8 = (sc.row_end - sec_row0) / 8;
+            char *pn = sc.ptr + (int64_t)n * (n_blk8 / 2) * 4 * a.P * 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = hb ? a.bias[row0 + m * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] * sc.scale : 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[m][j][r] * mul + bv[r];
+                    sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v);
+                }
+            }
+        }
+        return;
+    }
     if (MT == 2 && a.geglu_L > 0) {
         // feed-forward first projection: out = value * gelu(gate) (erf form), the two halves sit in this workgroup's
         // two row tiles; the [N][8C][P] intermediate never exists
@@ -729,6 +790,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
             const int r32 = 8 * (r >> 2) + 4 * kg + (r & 3);
             ba[r] = hb ? a.bias[(mb * 2 + 0) * 32 + r32] : 0.f;
             bg[r] = hb ? a.bias[(mb * 2 + 1) * 32 + r32] : 0.f;
+        }
+        if (a.nsec > 0) {
+            // the product goes out as the second projection's operand planes, scaled by a power of two fixed before the
+            // launch (|value * gelu(gate)| <= |value| |gate|): no absolute-maximum collection, no fp32 intermediate
+            const int n_blk8 = (a.M / 2) / 8;
+            char *pn = a.sec[0].ptr + (int64_t)n * (n_blk8 / 2) * 4 * a.P * 16;
+            const float os = a.sec[0].scale;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t px = p0 + (2 * wave + j) * 32 + l32;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float av = acc[0][j][r] * inv, gv = acc[MT - 1][j][r] * inv;
+                    if (hb) { av += ba[r]; gv += bg[r]; }
+                    const float t = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+                    v[r] = px >= a.geglu_L ? 0.f : t * os;
+                }
+                sink_store_planes(pn, a.P, mb * 4, n_blk8, px, kg, v);
+            }
+            return;
         }
         float mx = 0.f;
 #pragma unroll
@@ -905,7 +987,7 @@ __device__ __forceinline__ void cv_static_for(F &&f) {
 }
 constexpr int G5_DB = 6;        // B prefetch depth in 16-k chunks
 constexpr int G5_CA = 4;        // 16-k chunks per A ring slot
-template <int MT>
+template <int MT, bool SWAP = false>
 __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const GemmArgs a) {
     constexpr int SLOT = G5_CA * MT * 2 * 1024;            // bytes of a ring slot: [u][m][hl][lane][16 B]
     // three separate arrays, not one: the compiler's wait-count pass then knows that an LDS-DMA into one slot cannot
@@ -988,6 +1070,9 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
     // loop has NO branches (every trip issues all of its loads and DMAs): the compiler's wait-count pass then keeps exact
     // counts (s_waitcnt vmcnt(20): the 20 younger B loads stay in flight); with a branch in the body it merges the
     // pending-load states into vmcnt(0) and drains the queue.  The last trips run the guarded copy of the same steps.
+    // SWAP (operand sink of kind 2: attention V fragments; its own launch): the MFMA operands trade places, so the
+    // accumulators hold the TRANSPOSED tile -- lane = row of the weight tile, registers = the 32 tokens of column block j
+    // -- which is the key order of the attention kernel's V fragments; same three products, same roundings per element.
     auto step = [&](int base, auto t_, auto guarded_) {
         constexpr int t = decltype(t_)::value;
         constexpr bool guarded = decltype(guarded_)::value != 0;
@@ -1002,9 +1087,15 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
             const h16x8 al = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 1) * 1024);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][1], acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                if constexpr (SWAP) {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], ah, acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][1], ah, acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], al, acc[m][j], 0, 0, 0);
+                } else {
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][1], acc[m][j], 0, 0, 0);
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                }
             }
         }
         // the scheduler otherwise gathers the loads of several steps into one cluster late in the chunk, which shortens
@@ -1017,6 +1108,8 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
     int base = 0;
     for (; base + 12 + G5_DB <= nck; base += 12) cv_static_for<12>([&](auto t_) { step(base, t_, cic<0>{}); });
     for (; base < nck; base += 12) cv_static_for<12>([&](auto t_) { step(base, t_, cic<1>{}); });
+    if constexpr (SWAP) gemm_epilogue_vfrag<MT>(a, acc, n, mb, p0, wave, lane);
+    else
     gemm_epilogue<MT>(a, acc, n, mb, p0, split, wave, lane);
 }
 
@@ -1479,7 +1572,7 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
-    a.geglu_L = 0; a.absmax_bits = nullptr;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 0; a.v_dt = 1;
     a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = cfg >> 8; cfg &= 255;
@@ -1574,7 +1667,7 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         a.w_scale2 = (const float *)((const char *)packed + M2 * K * 4);
         a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = out;
         a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
-        a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word;
+        a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word; a.nsec = 0; a.v_dt = 1;
         a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
@@ -1583,5 +1676,112 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         else hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(gm_scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2, (unsigned *)zero_word);
+    return check_launch();
+}
+
+// ---- GEMMs whose epilogue writes the NEXT contraction's operands (csrc/plane_sink.h) ------------------------------
+// The M rows are cut into `nsec` <= 3 consecutive sections of sec_rows[i] rows (multiples of 64).  Section i goes to
+// sec_ptr[i] in the format sec_kind[i] -- 1: split planes [N][sec_rows/16][2][2][P][8 halves] (the B operand of a later
+// mvip_gemm_f16x3 / the Q or K operand of the attention kernel), 2: attention V fragments
+// [N][heads][v_dt][P/16][2][64][8 halves] with sec_rows = heads * v_dt * 32 (rows of head h at h * v_dt * 32 ..) -- as
+// (W x + bias) * sec_scale[i], sec_scale a power of two the caller fixed BEFORE the launch from a bound of the result.
+extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
+                                     int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
+                                     void *const *sec_ptr, const float *sec_scale, int v_dt, void *stream) {
+    if (N < 0 || M <= 0 || M % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || nsec < 1 || nsec > 3 ||
+        !sec_rows || !sec_kind || !sec_ptr || !sec_scale)
+        return MVIP_EINVAL;
+    int64_t end = 0, plane_rows = 0;
+    int n_plane = 0;
+    for (int i = 0; i < nsec; ++i) {
+        if (sec_rows[i] <= 0 || sec_rows[i] % 64 != 0 || (sec_kind[i] != 1 && sec_kind[i] != 2) || !(sec_scale[i] > 0.f))
+            return MVIP_EINVAL;
+        // the plane sections come first; a V-fragment section (computed by the transposed instantiation, its own launch)
+        // is the last one
+        if (sec_kind[i] == 2 && (i != nsec - 1 || v_dt < 1 || sec_rows[i] % (32 * (int64_t)v_dt) != 0)) return MVIP_EINVAL;
+        if (sec_kind[i] == 1) { plane_rows += sec_rows[i]; ++n_plane; }
+        end += sec_rows[i];
+    }
+    if (end != M) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!xs || !packed) return MVIP_EINVAL;
+    for (int i = 0; i < nsec; ++i) if (!sec_ptr[i]) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    GemmArgs a;
+    a.xs = (const char *)xs;
+    a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
+    a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = nullptr;
+    a.N = (int)N; a.CK = (int)(K / 16); a.P = P;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.v_dt = v_dt < 1 ? 1 : v_dt;
+    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+#ifdef MVIP_EXPERIMENT_GEMM
+    a.dbg = 0;
+#endif
+    a.tiles = (int)(P / GM_PIX);
+    auto launch = [&](int64_t row0, int64_t rows, bool swap) -> int {
+        a.wp = (const char *)packed + row0 * K * 4;          // row tiles are contiguous in the packed image
+        a.bias = bias ? bias + row0 : nullptr;
+        a.M = (int)rows;
+        const int MT = cv_mt(rows, N * a.tiles) >= 2 ? 2 : 1;
+        a.MB = (int)(rows / (32 * MT));
+        const int64_t blocks = N * a.tiles * a.MB;
+        if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+        if (swap) {
+            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        } else {
+            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        }
+        return MVIP_OK;
+    };
+    for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
+    if (n_plane > 0) {
+        int64_t e = 0;
+        for (int i = 0; i < n_plane; ++i) {
+            e += sec_rows[i];
+            a.sec[i].ptr = (char *)sec_ptr[i]; a.sec[i].scale = sec_scale[i]; a.sec[i].row_end = (int)e; a.sec[i].kind = 1;
+        }
+        a.nsec = n_plane;
+        const int rc = launch(0, plane_rows, false);
+        if (rc != MVIP_OK) return rc;
+    }
+    if (n_plane < nsec) {
+        for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
+        a.sec[0].ptr = (char *)sec_ptr[nsec - 1]; a.sec[0].scale = sec_scale[nsec - 1]; a.sec[0].row_end = (int)sec_rows[nsec - 1];
+        a.sec[0].kind = 2;
+        a.nsec = 1;
+        const int rc = launch(plane_rows, sec_rows[nsec - 1], true);
+        if (rc != MVIP_OK) return rc;
+    }
+    return check_launch();
+}
+
+// mvip_gemm_geglu_f16x3 whose product leaves as the second projection's operand planes [N][(M2/2)/16][2][2][P][8 halves],
+// times the power of two `out_scale` fixed before the launch (|value * gelu(gate)| <= |value| |gate|): no absolute-maximum
+// collection, no scale launch, no fp32 intermediate.
+extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2,
+                                          int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes,
+                                          float out_scale, void *stream) {
+    if (N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+        !(out_scale > 0.f) || (M2 / 2) % 16 != 0)
+        return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!xs || !packed || !out_planes) return MVIP_EINVAL;
+    GemmArgs a;
+    a.xs = (const char *)xs; a.wp = (const char *)packed;
+    a.w_scale2 = (const float *)((const char *)packed + M2 * K * 4);
+    a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = nullptr;
+    a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
+    a.geglu_L = (int)L; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1;
+    for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
+    a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)(M2 / 2); a.sec[0].kind = 1;
+    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+#ifdef MVIP_EXPERIMENT_GEMM
+    a.dbg = 0;
+#endif
+    const int64_t blocks = N * a.tiles * a.MB;
+    if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+    hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     return check_launch();
 }

@@ -10,7 +10,13 @@ Activations stay CHANNEL-MAJOR [N, C, LP] from proj_in to proj_out (LP = tokens,
   * the q / k / v projections are one GEMM with the heads' rows padded to a multiple of 16 channels (40 -> 48,
     zero rows), whose three thirds get their power-of-two scales in one launch;
   * attention is the flash-style kernel of csrc/attention.hip (nothing of size [Lq, Lk] in memory);
-  * the prompt's key / value projections depend only on the (cached) prompt embedding: computed once per prompt.
+  * the prompt's key / value projections depend only on the (cached) prompt embedding: computed once per prompt;
+  * (round 3, USE_SINKS) the contractions hand each other OPERANDS: the q / k / v projection's epilogue writes the attention
+    kernel's Q / K planes and V fragments, attention writes the output projection's operand planes, the GEGLU projection
+    writes the second feed-forward projection's planes -- each at a power-of-two scale fixed at pack time from a rigorous
+    bound of the tensor (|LayerNorm| <= sqrt(C) |gamma|max + |beta|max, |W x| <= |x|max max_row ||W||_1, |softmax V| <=
+    |V|max, |a gelu(g)| <= |a| |g|).  No fp32 intermediate, no absolute-maximum pass, no split pass inside a block:
+    11 launches fewer per block (30 -> 19).
 Stock torch ops left in here: tensor allocation, the zero-padding copy of the 8x8 level, and nothing else.
 """
 import math
@@ -38,6 +44,19 @@ def _ln_scale(ln, C):
 
 def _scale_tensor(s, device):
     return torch.tensor([s, 1.0 / s, 0.0, 0.0], device=device, dtype=torch.float32)
+
+
+USE_SINKS = True      # A/B switch: False restores the round-2 chain (fp32 intermediates + measured scales)
+
+
+def _ln_bound(ln, C):
+    """|LayerNorm(x)_c| <= sqrt(C) |gamma|max + |beta|max for EVERY input (|x_c - mean| <= sqrt(C) std)."""
+    return math.sqrt(C) * float(ln.weight.detach().abs().max()) + float(ln.bias.detach().abs().max())
+
+
+def _row_l1(W):
+    """max over rows of sum_k |W[row][k]|: |W x|max <= |x|max * this."""
+    return float(W.detach().abs().sum(1).max())
 
 
 class _Packed:
@@ -81,6 +100,27 @@ class _Packed:
             s = _ln_scale(ln, C)
             self.ln.append((ln.weight.detach().contiguous(), ln.bias.detach().contiguous(), float(ln.eps), s,
                             _scale_tensor(s, dev)))
+        # ---- operand sinks: weight images and the power-of-two scales of every intermediate, fixed here ----
+        DT = (D + 31) // 32
+        self.DT, self.RV = DT, heads * DT * 32
+        # V rows padded per head to the attention kernel's row tiles (DT * 32), so that a 32-row GEMM tile is one
+        # (head, row tile) block of the V fragments
+        wqkv_s = torch.cat([_pad_head_rows(a1.to_q.weight, heads, D, DP), _pad_head_rows(a1.to_k.weight, heads, D, DP),
+                            _pad_head_rows(a1.to_v.weight, heads, D, DT * 32)], 0).contiguous()
+        self.qkv1_s = pack(wqkv_s, 2 * R + self.RV, C, C, 1)
+        b1n, b2n, b3n = (_ln_bound(ln, C) for ln in (blk.norm1, blk.norm2, blk.norm3))
+        sc = ops.pow2_scale_for_bound
+        self.s_q1 = sc(b1n * _row_l1(a1.to_q.weight))
+        self.s_k1 = sc(b1n * _row_l1(a1.to_k.weight))
+        self.s_v1 = sc(b1n * _row_l1(a1.to_v.weight))
+        self.s_q2 = sc(b2n * _row_l1(a2.to_q.weight))
+        wa, wg = w1.weight.detach()[:4 * C], w1.weight.detach()[4 * C:]
+        ba, bg = w1.bias.detach()[:4 * C], w1.bias.detach()[4 * C:]
+        bound_a = b3n * _row_l1(wa) + float(ba.abs().max())
+        bound_g = b3n * _row_l1(wg) + float(bg.abs().max())
+        self.s_act = sc(bound_a * bound_g)                      # |a gelu(g)| <= |a| |g|
+        self.t_q1, self.t_k1, self.t_v1, self.t_q2, self.t_act = (_scale_tensor(v, dev) for v in
+                                                                  (self.s_q1, self.s_k1, self.s_v1, self.s_q2, self.s_act))
         self.ctx_cache = {}             # (ptr, version, shape) -> (ctx, planes ...): one entry PER PROMPT, never cleared
 
     @staticmethod
@@ -177,7 +217,33 @@ def _prompt_kv(pk, ctx):
     return hit
 
 
+def _block_sinks(h, pk, ctx, N, L, LP):
+    """The block with every contraction writing the next one's operands (module docstring, USE_SINKS)."""
+    C, R, heads, D = pk.C, pk.R, pk.heads, pk.D
+    # ---- self-attention: LayerNorm planes -> {Q planes, K planes, V fragments} -> attention -> o planes -> projection ----
+    g, b, eps, s, st = pk.ln[0]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    qs, ks, vp = ops.gemm_f16x3_sinks(xs, pk.qkv1_s, N, C, LP, [(R, 'planes', pk.s_q1), (R, 'planes', pk.s_k1),
+                                                                (pk.RV, 'vfrag', pk.s_v1)], x_scale2=st, v_dt=pk.DT)
+    op = ops.attention_f16x3_sink(qs, ks, vp, pk.t_q1, pk.t_k1, pk.t_v1, N, heads, D, L, LP, L, L, LP, LP, LP // 16)
+    h = ops.gemm_f16x3(op, pk.o1, N, C, C, LP, bias=pk.bo1, residual=h, x_scale2=pk.t_v1)
+    # ---- cross-attention onto the prompt tokens (their K planes / V fragments are cached per prompt) ----
+    g, b, eps, s, st = pk.ln[1]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    (qs,) = ops.gemm_f16x3_sinks(xs, pk.q2, N, C, LP, [(R, 'planes', pk.s_q2)], x_scale2=st)
+    ks2, vp2, sk2, sv2, T, TP = _prompt_kv(pk, ctx)
+    op = ops.attention_f16x3_sink(qs, ks2, vp2, pk.t_q2, sk2, sv2, N, heads, D, L, LP, T, TP, LP, TP, TP // 16)
+    h = ops.gemm_f16x3(op, pk.o2, N, C, C, LP, bias=pk.bo2, residual=h, x_scale2=sv2)
+    # ---- GEGLU feed-forward: the product leaves the first projection as the second one's operand planes ----
+    g, b, eps, s, st = pk.ln[2]
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    ap = ops.gemm_geglu_f16x3_sink(xs, pk.ff1, pk.b1, N, C, 8 * C, LP, L, pk.s_act, x_scale2=st)
+    return ops.gemm_f16x3(ap, pk.ff2, N, 4 * C, C, LP, bias=pk.b2, residual=h, x_scale2=pk.t_act)
+
+
 def _block(h, pk, ctx, N, L, LP):
+    if USE_SINKS:
+        return _block_sinks(h, pk, ctx, N, L, LP)
     C, R, heads, D, DP = pk.C, pk.R, pk.heads, pk.D, pk.DP
     # ---- self-attention ----
     g, b, eps, s, st = pk.ln[0]

@@ -1259,3 +1259,63 @@ def linear_small(x, W, b, act_in=0):
     call('mvip_linear_small', ptr(xc), ptr(Wc), ptr(None if b is None else _f32c(b)), NB, M, K, int(act_in), ptr(y),
          stream())
     return y
+
+
+# Contractions that hand each other operands (csrc/plane_sink.h): the producer's epilogue writes the consumer's operand
+# format at a power-of-two scale fixed before the launch ------------------------------------------------------------------
+
+def pow2_scale_for_bound(bound, top=32768.0):
+    """Largest power of two s with bound * s <= top (fp16 overflows at 65504; the hi/lo pair keeps ~2^-25 of `top`
+    absolutely, i.e. fp32-grade accuracy relative to the tensor's maximum while the bound is < ~2^15 too wide)."""
+    import math
+    if not (bound > 0.0) or not math.isfinite(bound):
+        return 1.0
+    k = int(math.floor(math.log2(top / bound)))
+    return float(2.0 ** max(-60, min(60, k)))
+
+
+def scale2_tensor(s, device):
+    return torch.tensor([s, 1.0 / s, 0.0, 0.0], device=device, dtype=_F32)
+
+
+def gemm_f16x3_sinks(xs, packed, N, K, P, sections, bias=None, x_scale2=None, v_dt=1):
+    """(W X + bias) with the rows cut into `sections` = [(rows, kind, scale), ...]: kind 'planes' -> fp16 hi/lo split
+    planes [N][rows/16][2][2][P][8], kind 'vfrag' (last section only) -> attention V fragments
+    [N][rows/(32 v_dt)][v_dt][P/16][2][64][8]; returns the list of operand buffers (uint8 / fp16 storage)."""
+    import ctypes
+    n = len(sections)
+    M = sum(r for r, _, _ in sections)
+    rows = (ctypes.c_int64 * n)(*[int(r) for r, _, _ in sections])
+    kinds = (ctypes.c_int * n)(*[1 if k == 'planes' else 2 for _, k, _ in sections])
+    scales = (ctypes.c_float * n)(*[float(sc) for _, _, sc in sections])
+    bufs = []
+    for r, k, _ in sections:
+        if k == 'planes':
+            bufs.append(_split_buffer(N, r, P, xs.device))                          # 4 B per element: fp16 hi + lo
+        else:
+            bufs.append(torch.empty(N * r * P * 4, device=xs.device, dtype=torch.uint8))
+    ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bufs])
+    call('mvip_gemm_f16x3_sinks', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N), int(K),
+         int(M), int(P), n, rows, kinds, ptrs, scales, int(v_dt), stream())
+    return bufs
+
+
+def gemm_geglu_f16x3_sink(xs, packed, bias, N, K, M2, P, L, out_scale, x_scale2=None):
+    """(value * gelu(gate)) * out_scale of the interleaved projection as the second projection's operand planes
+    [N][(M2/2)/16][2][2][P][8]; columns >= L are zero."""
+    out = _split_buffer(N, M2 // 2, P, xs.device)
+    call('mvip_gemm_geglu_f16x3_sink', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
+         int(K), int(M2), int(P), int(L), ptr(out, torch.float16), float(out_scale), stream())
+    return out
+
+
+def attention_f16x3_sink(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, q_stride, k_stride,
+                         v_groups):
+    """mvip_attention_f16x3 on operands written by GEMM epilogues; the result leaves as the output projection's operand
+    planes [N][heads*D/16][2][2][LqP][8], scaled by V's scale (zero beyond Lq when LqP > Lq)."""
+    mk = torch.empty if LqP == Lq else torch.zeros
+    out = mk(N * heads * D * LqP * 2, device=qs.device, dtype=torch.float16)
+    call('mvip_attention_f16x3_sink', ptr(qs, torch.float16), ptr(ks, torch.float16), ptr(vp, torch.uint8), ptr(q_scale2),
+         ptr(k_scale2), ptr(v_scale2), int(N), int(heads), int(D), int(Lq), int(LqP), int(Lk), int(LkP), int(q_stride),
+         int(k_stride), int(v_groups), float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out, torch.float16), stream())
+    return out

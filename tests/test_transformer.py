@@ -156,12 +156,118 @@ def test_absmax_scale_sections(cuda):
         assert 512.0 <= m * sc[s, 0] < 1024.0 and sc[s, 0] * sc[s, 1] == 1.0
 
 
+# ---- contractions that hand each other operands (csrc/plane_sink.h) --------------------------------------------------
+def decode_planes(buf, Nb, rows, P):
+    """fp16 hi/lo split planes [Nb][rows/16][kg 2][hl 2][P][8] -> float64 [Nb, rows, P] (hi + lo)."""
+    t = buf.view(Nb, rows // 16, 2, 2, P, 8).double().cpu()
+    v = t[:, :, :, 0] + t[:, :, :, 1]                          # [Nb, ck, kg, P, 8]
+    return v.permute(0, 1, 2, 4, 3).reshape(Nb, rows, P)
+
+
+def decode_vfrag(buf, Nb, blocks, P):
+    """attention V fragments [Nb][blocks][P/16][hl 2][lane 64][8 halves] -> float64 [Nb, blocks*32 rows, P keys]:
+    element j of lane (l32, hh) of 16-key group s is row l32, key 16 s + 8 (j >> 2) + 4 hh + (j & 3)."""
+    t = buf.view(torch.float16).view(Nb, blocks, P // 16, 2, 2, 32, 8).double().cpu()     # [.., s16, hl, hh, l32, j]
+    v = t[:, :, :, 0] + t[:, :, :, 1]                                                      # [Nb, blk, s16, hh, l32, j]
+    out = torch.zeros(Nb, blocks, 32, P, dtype=torch.float64)
+    for hh in range(2):
+        for j in range(8):
+            keys = torch.arange(P // 16) * 16 + 8 * (j >> 2) + 4 * hh + (j & 3)
+            out[:, :, :, keys] = v[:, :, :, hh, :, j].permute(0, 1, 3, 2)
+    return out.reshape(Nb, blocks * 32, P)
+
+
+@pytest.mark.parametrize('Nb,K,P,rq,rv,v_dt', [(2, 320, 256, 384, 512, 2), (1, 640, 512, 640, 768, 3), (2, 1280, 256, 1280, 1280, 5),
+                                                (1, 64, 256, 64, 0, 1)])
+def test_gemm_sinks_vs_fp64(cuda, Nb, K, P, rq, rv, v_dt):
+    """mvip_gemm_f16x3_sinks: one GEMM whose row sections leave as Q planes, K planes and (transposed launch) attention
+    V fragments at three different fixed power-of-two scales, against W X + b in fp64 -- decoded from the operand
+    formats themselves (hi + lo), so layout, exchange and scales are all checked.  5e-6 of each section's scale."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(K + P)
+    M = 2 * rq + rv
+    x = torch.randn(Nb, K, P, generator=gen) * 1.7
+    W = torch.randn(M, K, generator=gen) / K ** 0.5
+    b = torch.randn(M, generator=gen) * 0.3
+    ref = torch.einsum('mk,nkp->nmp', W.double(), x.double()) + b.double()[None, :, None]
+    s2 = ops.absmax_scale(x.to(cuda))
+    xs = ops.split_planes_strided(x.to(cuda), Nb, K, P, K * P, P, 1, s2)
+    secs = [(rq, 'planes', 0.5), (rq, 'planes', 64.0)] + ([(rv, 'vfrag', 4.0)] if rv else [])
+    bufs = ops.gemm_f16x3_sinks(xs, ops.gemm_pack_a(W.to(cuda), M, K, K, 1), Nb, K, P, secs, bias=b.to(cuda), x_scale2=s2,
+                                v_dt=v_dt)
+    torch.cuda.synchronize()
+    row = 0
+    for (rows, kind, sc), buf in zip(secs, bufs):
+        want = ref[:, row:row + rows] * sc
+        got = decode_planes(buf, Nb, rows, P) if kind == 'planes' else decode_vfrag(buf, Nb, rows // 32, P)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=5e-6 * float(want.abs().max()), err_msg=f'{kind}@{row}')
+        row += rows
+
+
+def test_gemm_geglu_sink_vs_fp64(cuda):
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    Nb, K, R, P, L = 2, 320, 256, 512, 450
+    x = torch.randn(Nb, K, P, generator=gen)
+    W = torch.randn(2 * R, K, generator=gen) / K ** 0.5
+    b = torch.randn(2 * R, generator=gen) * 0.2
+    y = torch.einsum('mk,nkp->nmp', W.double(), x.double()) + b.double()[None, :, None]
+    ref = y[:, :R] * torch.nn.functional.gelu(y[:, R:])
+    ref[:, :, L:] = 0
+    wi, bi = ops.geglu_interleave(W.to(cuda), b.to(cuda))
+    s2 = ops.absmax_scale(x.to(cuda))
+    xs = ops.split_planes_strided(x.to(cuda), Nb, K, P, K * P, P, 1, s2)
+    out = ops.gemm_geglu_f16x3_sink(xs, ops.gemm_pack_a(wi, 2 * R, K, K, 1), bi, Nb, K, 2 * R, P, L, 8.0, x_scale2=s2)
+    got = decode_planes(out, Nb, R, P) / 8.0
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-6 * float(ref.abs().max()))
+    assert float(got[:, :, L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('heads,D,L,LP', [(8, 40, 256, 256), (8, 80, 256, 256), (8, 160, 64, 256), (4, 40, 1024, 1024), (8, 40, 4096, 4096)])
+def test_attention_between_sinks_vs_fp64(cuda, heads, D, L, LP):
+    """q / k / v projection (sinks) -> attention (operands at the GEMM's strides, result as operand planes) -> output
+    projection, against the fp64 statement; fixed scales chosen 2^6 .. 2^9 too wide on purpose."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(heads * D + L)
+    Nb, C = 2, heads * D
+    DP, DT = (D + 15) // 16 * 16, (D + 31) // 32
+    R, RV = heads * DP, heads * DT * 32
+    x = torch.zeros(Nb, C, LP)
+    x[:, :, :L] = torch.randn(Nb, C, L, generator=gen)
+    Wq, Wk, Wv, Wo = (torch.randn(C, C, generator=gen) / C ** 0.5 * g for g in (2.0, 2.0, 1.0, 1.0))
+    bo = torch.randn(C, generator=gen) * 0.1
+    q, k, v = (torch.einsum('mk,nkp->nmp', Wm.double(), x.double()[:, :, :L]).reshape(Nb, heads, D, L) for Wm in (Wq, Wk, Wv))
+    att = torch.softmax(torch.einsum('nhdi,nhdj->nhij', q, k) * D ** -0.5, -1)
+    o = torch.einsum('nhij,nhdj->nhdi', att, v).reshape(Nb, C, L)
+    ref = torch.einsum('mk,nkp->nmp', Wo.double(), o) + bo.double()[None, :, None]
+
+    def pad_rows(Wm, rows):
+        out = torch.zeros(heads * rows, C)
+        out.view(heads, rows, C)[:, :D] = Wm.view(heads, D, C)
+        return out
+    Wqkv = torch.cat([pad_rows(Wq, DP), pad_rows(Wk, DP), pad_rows(Wv, DT * 32)], 0).to(cuda)
+    xd = x.to(cuda)
+    s2 = ops.absmax_scale(xd)
+    xs = ops.split_planes_strided(xd, Nb, C, LP, C * LP, LP, 1, s2)
+    bound = float(x.abs().max()) * max(float(Wm.abs().sum(1).max()) for Wm in (Wq, Wk, Wv))
+    sq, sk, sv = (ops.pow2_scale_for_bound(bound * f) for f in (1.0, 8.0, 64.0))
+    qs, ks, vp = ops.gemm_f16x3_sinks(xs, ops.gemm_pack_a(Wqkv, 2 * R + RV, C, C, 1), Nb, C, LP,
+                                      [(R, 'planes', sq), (R, 'planes', sk), (RV, 'vfrag', sv)], x_scale2=s2, v_dt=DT)
+    tq, tk, tv = (ops.scale2_tensor(t, cuda) for t in (sq, sk, sv))
+    op = ops.attention_f16x3_sink(qs, ks, vp, tq, tk, tv, Nb, heads, D, L, LP, L, L, LP, LP, LP // 16)
+    y = ops.gemm_f16x3(op, ops.gemm_pack_a(Wo.to(cuda), C, C, C, 1), Nb, C, C, LP, bias=bo.to(cuda), x_scale2=tv)
+    np.testing.assert_allclose(N(y)[:, :, :L], ref.float().numpy(), rtol=0, atol=6e-6 * float(ref.abs().max()))
+    assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize('sinks', [True, False])
 @pytest.mark.parametrize('C,heads,H,W', [(320, 8, 16, 16), (640, 8, 16, 16), (1280, 8, 16, 16), (1280, 8, 8, 8)])
-def test_transformer2d_hip_path_vs_fp64_module(cuda, C, heads, H, W):
+def test_transformer2d_hip_path_vs_fp64_module(cuda, C, heads, H, W, sinks):
     """Transformer2DModel (GroupNorm, proj_in, self-attention, cross-attention, GEGLU, proj_out, residual) on the
     HIP kernels vs the SAME module evaluated in fp64 by torch on the host."""
     from mvip_nerf_amd.guidance import sd_nets, transformer_cm
     torch.manual_seed(C + H)
+    transformer_cm.USE_SINKS = sinks       # True: contractions hand each other operands at bound-based scales (default)
     mod = sd_nets.Transformer2DModel(C, heads, 768).eval()
     with torch.no_grad():
         for name, p in mod.named_parameters():                     # non-trivial norms and biases
@@ -196,6 +302,7 @@ def test_transformer2d_hip_path_vs_fp64_module(cuda, C, heads, H, W):
         mod.proj_out.bias.add_(1.0)
         moved = mod(xd, cd)
     np.testing.assert_allclose(N(moved), N(got) + 1.0, rtol=0, atol=1e-5 * scale)
+    transformer_cm.USE_SINKS = True
 
 
 def test_unet_forward_has_no_library_attention_or_gemm(cuda):
