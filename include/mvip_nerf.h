@@ -397,6 +397,12 @@ int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const f
 int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                           int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
                           void *const *sec_ptr, const float *sec_scale, int v_dt, void *stream);
+/* (W X + bias + residual) * out_scale as ONE section of split planes [N][M/16][2][2][P][8 halves]: the second
+ * feed-forward projection handing the finished residual stream to proj_out as its operand.  Split-K as in
+ * mvip_gemm_f16x3_ws (workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes, NULL when that is 0); M % 32 == 0. */
+int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, const float *bias, const float *residual,
+                              const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P, void *out_planes,
+                              float out_scale, void *workspace, void *stream);
 int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                                int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes, float out_scale,
                                void *stream);

@@ -106,6 +106,7 @@ _SIGNATURES = {
                                     _c_f, _c_f]),
     'mvip_gemm_f16x3_sinks': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _int, ctypes.POINTER(_i64),
                                      ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_flt), _int, _c_f]),
+    'mvip_gemm_f16x3_planes_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f, _c_f]),
     'mvip_gemm_geglu_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f]),
     'mvip_attention_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                          _i64, _i64, _flt, _int, _c_f, _c_f]),

@@ -679,6 +679,44 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
     *reinterpret_cast<f32x4 *>(y + i4) = v;
 }
 
+// The same reduction whose result leaves as split planes [N][M/16][2][2][P][8 halves] * out_scale (an operand sink behind a
+// split-K launch): thread = (sample, 8-row block, column); the 8 rows of a fragment are 8 coalesced row reads per split.
+__global__ void __launch_bounds__(256)
+cv_split_reduce_planes_kernel(const float *__restrict__ partial, int splits, int N, int M, int64_t P,
+                              const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
+                              const float *__restrict__ bias, const float *__restrict__ residual, float out_scale,
+                              uint4 *__restrict__ planes) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y % (M / 8), n = blockIdx.y / (M / 8);
+    if (p >= P) return;
+    const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
+    const int64_t total = (int64_t)N * M * P;
+    const int64_t base = ((int64_t)n * M + blk * 8) * P + p;
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = partial[base + j * P];
+    for (int s = 1; s < splits; ++s) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = partial[(int64_t)s * total + base + j * P];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += t[j];
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = sum[j] * inv;
+        if (bias) t += bias[blk * 8 + j];
+        if (residual) t += residual[base + j * P];
+        v[j] = t * out_scale;
+    }
+    uint4 hi, lo;
+    sink_split8(v, hi, lo);
+    uint4 *dst = planes + (((int64_t)n * (M / 16) + (blk >> 1)) * 4 + (blk & 1) * 2) * P + p;
+    dst[0] = hi;
+    dst[P] = lo;
+}
+
 // ---- plain GEMM (1x1 convolution, attention products) on the same operand formats -----------------------
 //   Y[n][m][p] = sum_k A[m][k] X[n][k][p] / (s_a s_x) + bias[m] + chan_add[n][m] + residual[n][m][p]
 // A packed by gm_pack_kernel, X in split planes [n][K/16][2][2][P][8].  Workgroup = 32*MT rows x 256
@@ -754,27 +792,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
 #endif
     // all loads of the epilogue are issued together, ahead of the arithmetic (see the convolution's epilogue)
     const bool hb = a.bias != nullptr, hc = a.chan_add != nullptr, hr = a.residual != nullptr;
-    if (a.nsec > 0 && a.geglu_L == 0) {
+    if (a.nsec > 0 && a.geglu_L == 0 && !a.partial) {       // (split-K: raw partial sums first, the sink is the reduce launch)
         // ---- operand sinks: this workgroup's MT row tiles lie in ONE section (sections are multiples of 64 rows) ----
         const int row0 = mb * MT * 32;
         GemmArgs::Sec sc = a.sec[0];                 // static indices only: a dynamically indexed kernel argument goes to scratch
         int sec_row0 = 0;
         if (a.nsec > 1 && row0 >= a.sec[0].row_end) { sc = a.sec[1]; sec_row0 = a.sec[0].row_end; }
         if (a.nsec > 2 && row0 >= a.sec[1].row_end) { sc = a.sec[2]; sec_row0 = a.sec[1].row_end; }
-        const float mul = inv * sc.scale;
         {
             const int n_blk8 = (sc.row_end - sec_row0) / 8;
             char *pn = sc.ptr + (int64_t)n * (n_blk8 / 2) * 4 * a.P * 16;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float bv[16];
+                f32x16 rv[2];
+                if (hr) {                                       // the residual stream joins before the split (loads issued together)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bv[r] = hb ? a.bias[row0 + m * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] * sc.scale : 0.f;
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            rv[j][r] = a.residual[((int64_t)n * a.M + row0 + m * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)) * a.P + p0 +
+                                                  (2 * wave + j) * 32 + l32];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = hb ? a.bias[row0 + m * 32 + 8 * (r >> 2) + 4 * kg + (r & 3)] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[m][j][r] * mul + bv[r];
+                    for (int r = 0; r < 16; ++r) {
+                        float t = acc[m][j][r] * inv;           // the fp32 epilogue's order of roundings, then the scale
+                        if (hb) t += bv[r];
+                        if (hr) t += rv[j][r];
+                        v[r] = t * sc.scale;
+                    }
                     sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v);
                 }
             }
@@ -1783,5 +1834,49 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
     const int64_t blocks = N * a.tiles * a.MB;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
     hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    return check_launch();
+}
+
+// Y = (W X + bias + residual) * out_scale as ONE section of split planes [N][M/16][2][2][P][8 halves] -- the operand of
+// the next GEMM (the second feed-forward projection handing the residual stream to proj_out) -- with the split-K of
+// mvip_gemm_f16x3_ws: workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (null when that is 0).
+extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, const float *bias, const float *residual,
+                                         const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P, void *out_planes,
+                                         float out_scale, void *workspace, void *stream) {
+    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || !(out_scale > 0.f))
+        return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!xs || !packed || !out_planes) return MVIP_EINVAL;
+    if (!workspace && mvip_gemm_workspace_bytes(N, K, M, P) > 0) return MVIP_EINVAL;
+    GemmArgs a;
+    a.xs = (const char *)xs; a.wp = (const char *)packed;
+    a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
+    a.bias = bias; a.chan_add = nullptr; a.residual = residual; a.x_scale2 = x_scale2; a.y = nullptr;
+    a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1;
+    for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
+    a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)M; a.sec[0].kind = 1;
+    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+#ifdef MVIP_EXPERIMENT_GEMM
+    a.dbg = 0;
+#endif
+    a.tiles = (int)(P / GM_PIX);
+    int MT = gm_mt(M, N * a.tiles);
+    if (MT > 2) MT = 2;
+    a.MB = (int)(M / (32 * MT));
+    int64_t blocks = N * a.tiles * a.MB;
+    if (workspace && gm_auto_cfg(N, M, P) == 1 && MT == gm_mt(M, N * a.tiles)) {
+        a.splits = gm_splits(blocks, K / 32);
+        if (a.splits > 1) { a.sks = (int)((K / 32 + a.splits - 1) / a.splits); a.partial = (float *)workspace; }
+    }
+    blocks *= a.splits;
+    if (blocks > 0x7fffffffLL || N * (M / 8) > 65535) return MVIP_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.partial)
+        hipLaunchKernelGGL(cv_split_reduce_planes_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(N * (M / 8))), dim3(256), 0,
+                           st, a.partial, a.splits, (int)N, (int)M, P, a.w_scale2, x_scale2, bias, residual, out_scale,
+                           (uint4 *)out_planes);
     return check_launch();
 }

@@ -1319,3 +1319,14 @@ def attention_f16x3_sink(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, 
          ptr(k_scale2), ptr(v_scale2), int(N), int(heads), int(D), int(Lq), int(LqP), int(Lk), int(LkP), int(q_stride),
          int(k_stride), int(v_groups), float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out, torch.float16), stream())
     return out
+
+
+def gemm_f16x3_planes(xs, packed, N, K, M, P, out_scale, bias=None, residual=None, x_scale2=None):
+    """(W X + bias + residual) * out_scale as split planes [N][M/16][2][2][P][8] (the next GEMM's operand); split-K as
+    gemm_f16x3 for the small grids."""
+    out = _split_buffer(N, M, P, xs.device)
+    nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))
+    ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32) if nbytes else None
+    call('mvip_gemm_f16x3_planes_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(residual), ptr(x_scale2),
+         int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), stream())
+    return out

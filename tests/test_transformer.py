@@ -223,6 +223,29 @@ def test_gemm_geglu_sink_vs_fp64(cuda):
     assert float(got[:, :, L:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('Nb,K,M,P', [(2, 1280, 320, 512), (2, 5120, 1280, 256), (1, 2560, 640, 1024)])
+def test_gemm_planes_with_residual_and_split_k_vs_fp64(cuda, Nb, K, M, P):
+    """(W X + b + residual) * scale as operand planes, incl. the shapes whose grid is split over K (partial sums + the
+    reduce-to-planes launch): decoded planes vs fp64, and the planes feed a second GEMM."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(K + M)
+    x = torch.randn(Nb, K, P, generator=gen)
+    W = torch.randn(M, K, generator=gen) / K ** 0.5
+    b = torch.randn(M, generator=gen) * 0.2
+    res = torch.randn(Nb, M, P, generator=gen) * 3.0
+    ref = torch.einsum('mk,nkp->nmp', W.double(), x.double()) + b.double()[None, :, None] + res.double()
+    s2 = ops.absmax_scale(x.to(cuda))
+    xs = ops.split_planes_strided(x.to(cuda), Nb, K, P, K * P, P, 1, s2)
+    planes = ops.gemm_f16x3_planes(xs, ops.gemm_pack_a(W.to(cuda), M, K, K, 1), Nb, K, M, P, 16.0, bias=b.to(cuda),
+                                   residual=res.to(cuda), x_scale2=s2)
+    got = decode_planes(planes, Nb, M, P) / 16.0
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-6 * float(ref.abs().max()))
+    W2 = torch.randn(64, M, generator=gen) / M ** 0.5
+    y = ops.gemm_f16x3(planes, ops.gemm_pack_a(W2.to(cuda), 64, M, M, 1), Nb, M, 64, P, x_scale2=ops.scale2_tensor(16.0, cuda))
+    ref2 = torch.einsum('mk,nkp->nmp', W2.double(), ref)
+    np.testing.assert_allclose(N(y), ref2.float().numpy(), rtol=0, atol=6e-6 * float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize('heads,D,L,LP', [(8, 40, 256, 256), (8, 80, 256, 256), (8, 160, 64, 256), (4, 40, 1024, 1024), (8, 40, 4096, 4096)])
 def test_attention_between_sinks_vs_fp64(cuda, heads, D, L, LP):
     """q / k / v projection (sinks) -> attention (operands at the GEMM's strides, result as operand planes) -> output
