@@ -31,7 +31,7 @@ extern "C" {
 #define MVIP_ELAUNCH  -2   /* hipLaunch / runtime error (see mvip_last_hip_error) */
 #define MVIP_EUNSUP   -3   /* shape outside what the kernels are built for */
 
-#define MVIP_ABI_VERSION 1
+#define MVIP_ABI_VERSION 2      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points */
 
 int         mvip_abi_version(void);
 const char *mvip_strerror(int code);
@@ -279,17 +279,17 @@ int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
 int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
 int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *zero_words2, void *stream);
 int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
-                      void *stream);
+                      int prec, void *stream);
 int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
                                 const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
-                                void *stream);
+                                int prec, void *stream);
 int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                       int64_t H, int64_t W, float *y, void *stream);
+                       int64_t H, int64_t W, float *y, int prec, void *stream);
 int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
 int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                          int64_t H, int64_t W, float *y, void *workspace, void *stream);
+                          int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream);
 
 /* The same split-precision machinery as a plain GEMM (1x1 convolutions and the products of the VAE
  * mid-block attention, vae.encode at DS_NeRF/guidance/sd_utils.py:207):
@@ -301,7 +301,7 @@ int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias,
 int64_t mvip_gemm_packed_bytes(int64_t M, int64_t K);
 int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t sm, int64_t sk, void *packed, void *stream);
 int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc, int64_t sp,
-                              const float *scale2, void *xs, void *stream);
+                              const float *scale2, void *xs, int prec, void *stream);
 /* General convolution as this GEMM -- the stride-2 down-samplers of the UNet and the VAE encoder and the layers with 3,
  * 4, 8 or 9 channels (conv_in, conv_out, quant_conv; DS_NeRF/guidance/sd_utils.py:207, :240), which do not fit the 3x3
  * stride-1 kernel's operand tiles:
@@ -312,25 +312,25 @@ int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, 
  * mvip_col2im gathers dx[n][ci][iy][ix] (deterministic). */
 int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW, int stride,
                              int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP, int64_t PP,
-                             const float *scale2, void *xs, void *stream);
+                             const float *scale2, void *xs, int prec, void *stream);
 int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW, int stride, int pad_top,
                 int pad_left, int64_t OH, int64_t OW, int64_t KP, int64_t PP, float *dx, void *stream);
 int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                     const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                    float *y, void *stream);
+                    float *y, int prec, void *stream);
 /* The feed-forward's first projection with the GEGLU in the epilogue (the [N][2R][P] intermediate never exists):
  * out [N][R][P] = (W_v x + b_v) * gelu(W_g x + b_g) for columns < L, zero beyond; `packed` / `bias` hold the M2 = 2R
  * rows interleaved in 32-row tiles (value rows of tile t, then the gate rows of tile t); M2 % 64 == 0.  scale2 and
  * zero_word as in mvip_geglu. */
 int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                           int64_t K, int64_t M2, int64_t P, int64_t L, float *out, float *scale2, void *zero_word,
-                          void *stream);
+                          int prec, void *stream);
 /* the same with the workgroup tile forced (timing switch; identical arithmetic per output element up to the k order
  * inside a stage, which is the same): cfg 0 = by shape (what mvip_gemm_f16x3 does), 1 = 32/64 rows x 256 columns,
  * 2 = 128 x 256 (M % 128 == 0), 3 = 128 x 128 (M % 128 == 0), 4 = 64 x 128 (M % 64 == 0). */
 int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
                         const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                        float *y, int cfg, void *stream);
+                        float *y, int cfg, int prec, void *stream);
 /* mvip_gemm_f16x3 with a caller-owned workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (0 for most shapes;
  * workspace may then be NULL): launches with fewer workgroups than CUs and a long contraction (the UNet's 1280-channel
  * transformer blocks at 16x16 and 8x8) are split over K, each workgroup writing raw partial sums, and a second launch
@@ -338,7 +338,7 @@ int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, c
 int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, int64_t P);
 int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                       float *y, void *workspace, void *stream);
+                       float *y, void *workspace, int prec, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a14-a16  transformer blocks of the SD UNet (unet(...) at DS_NeRF/guidance/sd_utils.py:390-403 and :240;
@@ -369,12 +369,18 @@ int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, co
 int mvip_attention_supported(int64_t D);
 int64_t mvip_attention_v_bytes(int64_t N, int64_t heads, int64_t D, int64_t LkP);
 int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, int64_t D, int64_t DP, int64_t Lk, int64_t LkP,
-                          int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp, void *stream);
+                          int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp, int prec, void *stream);
 int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t sections, int64_t len, float *scale2,
                                void *zero_words64, void *stream);
 int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
                          const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
-                         int64_t Lk, int64_t LkP, float softmax_scale, int flags, float *out, void *stream);
+                         int64_t Lk, int64_t LkP, float softmax_scale, int flags, float *out, int prec, void *stream);
+/* `prec` (round 3) on the operand producers and the contractions of this section and the next: 0 = split precision
+ * ("f16x3": fp16 hi + lo halves of both operands, three products, fp32 accumulate -- fp32-grade results, the default of
+ * the fp32 networks); 1 = the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66, DS_NeRF/run.py:251): ONE fp16
+ * product per step, fp32 accumulate -- producers write the hi planes only, contractions fetch hi planes / hi weight
+ * fragments only (a third of the matrix work, half the operand traffic; ~1e-3 relative, fp16-grade).  Operand buffers have
+ * the same size and layout in both modes. */
 /* Contractions that hand each other OPERANDS (round 3; same call sites: the unet(...) call of
  * DS_NeRF/guidance/sd_utils.py:390-403 / :240).  Between two contractions of a transformer block the reference
  * materialises an fp32 tensor; rounds 1-2 of this library followed it with an absolute-maximum pass and a split pass.
@@ -396,27 +402,27 @@ int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const f
  *   [N][heads*D/16][2][2][LqP][8 halves] scaled by v_scale2[0]; columns >= Lq are not written. */
 int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                           int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
-                          void *const *sec_ptr, const float *sec_scale, int v_dt, void *stream);
+                          void *const *sec_ptr, const float *sec_scale, int v_dt, int prec, void *stream);
 /* (W X + bias + residual) * out_scale as ONE section of split planes [N][M/16][2][2][P][8 halves]: the second
  * feed-forward projection handing the finished residual stream to proj_out as its operand.  Split-K as in
  * mvip_gemm_f16x3_ws (workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes, NULL when that is 0); M % 32 == 0. */
 int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, const float *bias, const float *residual,
                               const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P, void *out_planes,
-                              float out_scale, void *workspace, void *stream);
+                              float out_scale, void *workspace, int prec, void *stream);
 int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                                int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes, float out_scale,
-                               void *stream);
+                               int prec, void *stream);
 int mvip_attention_f16x3_sink(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
                               const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP,
                               int64_t Lk, int64_t LkP, int64_t q_stride, int64_t k_stride, int64_t v_groups,
-                              float softmax_scale, int flags, void *out_planes, void *stream);
+                              float softmax_scale, int flags, void *out_planes, int prec, void *stream);
 /* LayerNorm over the channel axis of x [N][C][LP] for tokens < L, times out_scale (a power of two), written as
  * split planes [N][C/16][2][2][LP][8] (zero for tokens >= L).  C % 64 == 0, LP % 256 == 0; workspace of
  * mvip_layernorm_workspace_bytes(N, C, LP) bytes (fp64 partial moments), 8-byte aligned. */
 int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t LP);
 int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
                                 int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
-                                void *stream);
+                                int prec, void *stream);
 /* GEGLU: y [N][2R][LP] -> out [N][R][LP] = y[:, :R] * gelu(y[:, R:]) (erf form) for tokens < L, zero beyond;
  * scale2 = {2^k, 2^-k, -, -} from the result's absolute maximum; zero_word: one scratch word as in
  * mvip_absmax_scale_sections (zero on entry, zero on exit). */

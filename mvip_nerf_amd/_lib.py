@@ -72,11 +72,11 @@ _SIGNATURES = {
     'mvip_conv3x3_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_conv3x3_pack': (_int, [_c_f, _i64, _i64, _int, _c_f, _c_f]),
     'mvip_absmax_scale': (_int, [_c_f, _i64, _c_f, _c_f, _c_f]),
-    'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
-    'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _c_f]),
-    'mvip_conv3x3_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _int, _c_f]),
+    'mvip_conv3x3_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
     'mvip_conv3x3_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64, _i64]),
-    'mvip_conv3x3_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
+    'mvip_conv3x3_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
     'mvip_hashgrid_forward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_hashgrid_backward': (_int, [_c_f, _c_f, _c_f, _i64, _flt, _c_f, _c_f]),
     'mvip_sh4': (_int, [_c_f, _i64, _c_f, _c_f]),
@@ -89,29 +89,29 @@ _SIGNATURES = {
     'mvip_skinny_linear': (_int, [_c_f, _i64, _i64, _c_f, _i64, _i64, _i64, _int, _c_f, _c_f]),
     'mvip_gemm_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_gemm_pack_a': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
-    'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
-    'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
-    'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
+    'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _int, _c_f]),
     'mvip_im2col_split_planes': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64,
-                                        _c_f, _c_f, _c_f]),
+                                        _c_f, _c_f, _int, _c_f]),
     'mvip_col2im': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64]),
-    'mvip_gemm_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
-    'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
+    'mvip_gemm_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _int, _c_f]),
     'mvip_attention_supported': (_int, [_i64]),
     'mvip_attention_v_bytes': (_i64, [_i64, _i64, _i64, _i64]),
-    'mvip_attention_pack_v': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
+    'mvip_attention_pack_v': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
     'mvip_absmax_scale_sections': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _c_f]),
     'mvip_attention_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _flt, _int,
-                                    _c_f, _c_f]),
+                                    _c_f, _int, _c_f]),
     'mvip_gemm_f16x3_sinks': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _int, ctypes.POINTER(_i64),
-                                     ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_flt), _int, _c_f]),
-    'mvip_gemm_f16x3_planes_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f, _c_f]),
-    'mvip_gemm_geglu_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f]),
+                                     ctypes.POINTER(_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_flt), _int, _int, _c_f]),
+    'mvip_gemm_f16x3_planes_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _flt, _c_f, _int, _c_f]),
+    'mvip_gemm_geglu_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _flt, _int, _c_f]),
     'mvip_attention_f16x3_sink': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                                         _i64, _i64, _flt, _int, _c_f, _c_f]),
+                                         _i64, _i64, _flt, _int, _c_f, _int, _c_f]),
     'mvip_layernorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),
-    'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f, _c_f]),
+    'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f, _int, _c_f]),
     'mvip_geglu': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
     'mvip_linear_small': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _c_f, _c_f]),
     'mvip_groupnorm_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _int, _c_f, _c_f,
@@ -142,7 +142,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mvip_abi_version() != 1:
+    if lib.mvip_abi_version() != 2:
         raise MvipError('libmvipnerf.so ABI version mismatch')
     _lib = lib
     return lib

@@ -64,7 +64,9 @@ constexpr float P_SHIFT = 10.0f;          // probabilities travel as p * 2^10 so
 // NW waves per workgroup = NW * 32 queries sharing every K / V tile: the tiles arrive by LDS-DMA, whose rate per CU
 // (11-13 B/clk, MI355X_MICROARCH.md) is what bounds this kernel at 128 queries per workgroup (14 KB of operands per
 // 21 MFMAs per wave = 21 B/clk/CU at full matrix rate); 256 queries halve the bytes per FLOP.
-template <int NCH, int DT, int KT, int NW = 4>
+// F16 (the reference's --fp16 mode): ONE fp16 product per step in both contractions -- the hi halves of Q, K, V and of the
+// probabilities only; the lo halves of the operand images are neither fetched nor expected to be written.
+template <int NCH, int DT, int KT, int NW = 4, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : (NCH <= 3 ? (KT == 32 ? 4 : 2) : (NCH <= 5 ? 2 : 1))))
 attn_f16x3_kernel(const AttnArgs a) {
     constexpr int KB = NCH * 4 * KT * 16;                 // K tile bytes: [NCH][kg][hl][KT][16 B]
@@ -94,7 +96,7 @@ attn_f16x3_kernel(const AttnArgs a) {
     for (int c = 0; c < NCH; ++c) {
         const int64_t plane = ((int64_t)(n * QC + head * NCH + c) * 2 + h) * 2;
         qh[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 0) * a.q_stride + q) * 16);
-        ql[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 1) * a.q_stride + q) * 16);
+        if constexpr (!F16) ql[c] = *reinterpret_cast<const h16x8 *>(a.qs + ((plane + 1) * a.q_stride + q) * 16);
     }
 
     const char *k_base = a.ks + (int64_t)(n * QC + head * NCH) * 4 * a.k_stride * 16;
@@ -107,9 +109,9 @@ attn_f16x3_kernel(const AttnArgs a) {
             const int p = p0 + wave;
             if (p < NKP) {
                 if (KT == 64) {            // piece = (chunk, kg, hl): 64 keys x 16 B, contiguous in the plane
-                    glds16b(k_base + ((int64_t)p * a.k_stride + k0 + lane) * 16, kd + p * 1024);
+                    if (!F16 || !(p & 1)) glds16b(k_base + ((int64_t)p * a.k_stride + k0 + lane) * 16, kd + p * 1024);
                 } else {                   // KT == 32: piece = (chunk, kg), lanes 0..31 -> hi plane, 32..63 -> lo plane
-                    glds16b(k_base + ((int64_t)(p * 2 + h) * a.k_stride + k0 + l32) * 16, kd + p * 1024);
+                    if (!F16 || h == 0) glds16b(k_base + ((int64_t)(p * 2 + h) * a.k_stride + k0 + l32) * 16, kd + p * 1024);
                 }
             }
         }
@@ -118,7 +120,7 @@ attn_f16x3_kernel(const AttnArgs a) {
             const int p = p0 + wave;
             if (p < NVP) {
                 const int dt = p / ((KT / 16) * 2), r = p % ((KT / 16) * 2);
-                glds16b(v_base + ((int64_t)dt * a.v_groups * 2 + (k0 / 16) * 2 + r) * 1024 + lane * 16, vd + p * 1024);
+                if (!F16 || !(r & 1)) glds16b(v_base + ((int64_t)dt * a.v_groups * 2 + (k0 / 16) * 2 + r) * 1024 + lane * 16, vd + p * 1024);
             }
         }
     };
@@ -149,10 +151,12 @@ attn_f16x3_kernel(const AttnArgs a) {
             for (int c = 0; c < NCH; ++c) {
                 const char *kp = kb + (((c * 2 + h) * 2) * KT + sub * 32 + l32) * 16;
                 const h16x8 kh = *reinterpret_cast<const h16x8 *>(kp);
-                const h16x8 kl = *reinterpret_cast<const h16x8 *>(kp + KT * 16);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], s, 0, 0, 0);
+                if constexpr (!F16) {
+                    const h16x8 kl = *reinterpret_cast<const h16x8 *>(kp + KT * 16);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], s, 0, 0, 0);
+                }
             }
             // ---- keys beyond Lk (prompt padding) never contribute ----
             const int key0 = t * KT + sub * 32 + 4 * h;
@@ -197,10 +201,12 @@ attn_f16x3_kernel(const AttnArgs a) {
                 for (int d = 0; d < DT; ++d) {
                     const char *vq = vb + ((d * (KT / 16) + sub * 2 + s2) * 2) * 1024 + lane * 16;
                     const h16x8 vh = *reinterpret_cast<const h16x8 *>(vq);
-                    const h16x8 vl = *reinterpret_cast<const h16x8 *>(vq + 1024);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bh, o[d], 0, 0, 0);
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, o[d], 0, 0, 0);
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, o[d], 0, 0, 0);
+                    if constexpr (!F16) {
+                        const h16x8 vl = *reinterpret_cast<const h16x8 *>(vq + 1024);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, bl, o[d], 0, 0, 0);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, bh, o[d], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -220,7 +226,7 @@ attn_f16x3_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) v[r] = o[d][r] * il;
             // blocks of this head beyond its D channels (head dim padded to DT * 32 rows) are not written
             const int head_blk = head * (a.D / 8), last = head_blk + a.D / 8;
-            sink_store_planes(pn, a.LqP, head_blk + d * 4, last < n8 ? last : n8, q, h, v, q_ok);
+            sink_store_planes(pn, a.LqP, head_blk + d * 4, last < n8 ? last : n8, q, h, v, q_ok, !F16);
         }
         return;
     }
@@ -240,7 +246,7 @@ attn_f16x3_kernel(const AttnArgs a) {
 // V [rows][keys] (any strides) -> A fragments in the accumulator-row key order, scaled, hi / lo.
 __global__ void __launch_bounds__(256)
 attn_pack_v_kernel(const float *__restrict__ v, int heads, int DP, int Lk, int LkP, int DT, int64_t sn, int64_t sr,
-                   int64_t sk, const float *__restrict__ scale2, uint4 *__restrict__ out, int64_t total) {
+                   int64_t sk, const float *__restrict__ scale2, uint4 *__restrict__ out, int64_t total, int prec) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int64_t r = idx;
@@ -269,7 +275,7 @@ attn_pack_v_kernel(const float *__restrict__ v, int heads, int DP, int Lk, int L
     // [n][head][dt][s16][hl][lane]
     const int64_t base = ((((n * heads + head) * DT + dt) * (LkP / 16) + s16) * 2) * 64 + lane;
     out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    out[base + 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (prec == 0) out[base + 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // ---- absolute maxima of several equally long sections at once -> one power-of-two scale per section ----
@@ -358,14 +364,14 @@ extern "C" int64_t mvip_attention_v_bytes(int64_t N, int64_t heads, int64_t D, i
 
 extern "C" int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, int64_t D, int64_t DP, int64_t Lk,
                                      int64_t LkP, int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp,
-                                     void *stream) {
-    if (N < 0 || heads <= 0 || D <= 0 || DP < D || Lk <= 0 || LkP < Lk || LkP % 32 != 0) return MVIP_EINVAL;
+                                     int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || heads <= 0 || D <= 0 || DP < D || Lk <= 0 || LkP < Lk || LkP % 32 != 0) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!v || !vp || !scale2) return MVIP_EINVAL;
     const int DT = (int)((D + 31) / 32);
     const int64_t total = N * heads * DT * (LkP / 16) * 64;
     hipLaunchKernelGGL(attn_pack_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), v,
-                       (int)heads, (int)DP, (int)Lk, (int)LkP, DT, sn, sr, sk, scale2, (uint4 *)vp, total);
+                       (int)heads, (int)DP, (int)Lk, (int)LkP, DT, sn, sr, sk, scale2, (uint4 *)vp, total, prec);
     return check_launch();
 }
 
@@ -388,8 +394,8 @@ extern "C" int mvip_absmax_scale_sections(const float *x, int64_t outer, int64_t
 static int attention_launch(const void *qs, const void *ks, const void *vp, const float *q_scale2, const float *k_scale2,
                             const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP, int64_t Lk,
                             int64_t LkP, int64_t q_stride, int64_t k_stride, int64_t v_groups, float softmax_scale, int flags,
-                            float *out, void *out_planes, void *stream) {
-    if (N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0 ||
+                            float *out, void *out_planes, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0 ||
         q_stride < Lq || k_stride < LkP || v_groups < LkP / 16)
         return MVIP_EINVAL;
     if (!mvip_attention_supported(D)) return MVIP_EUNSUP;
@@ -408,25 +414,26 @@ static int attention_launch(const void *qs, const void *ks, const void *vp, cons
     const int64_t blocks = N * heads * a.qblocks;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (wide)
-        hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32, 8>), dim3((unsigned)blocks), dim3(512), 0, st, a);
-    else if (D == 40 && (flags & 1))          // tuning switch: 64-key tiles (two workgroups per CU) instead of 32-key tiles (four)
-        hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 64>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (D == 40)
-        hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (D == 80)
-        hipLaunchKernelGGL((attn_f16x3_kernel<5, 3, 32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((attn_f16x3_kernel<10, 5, 32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+#define MVIP_ATTN(F16_)                                                                                                       \
+    do {                                                                                                                     \
+        if (wide) hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32, 8, F16_>), dim3((unsigned)blocks), dim3(512), 0, st, a);           \
+        else if (D == 40 && (flags & 1)) /* tuning switch: 64-key tiles (two workgroups per CU) instead of 32-key tiles (four) */ \
+            hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 64, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);                 \
+        else if (D == 40) hipLaunchKernelGGL((attn_f16x3_kernel<3, 2, 32, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);   \
+        else if (D == 80) hipLaunchKernelGGL((attn_f16x3_kernel<5, 3, 32, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((attn_f16x3_kernel<10, 5, 32, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);               \
+    } while (0)
+    if (prec) MVIP_ATTN(true); else MVIP_ATTN(false);
+#undef MVIP_ATTN
     return check_launch();
 }
 
 extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const float *q_scale2,
                                     const float *k_scale2, const float *v_scale2, int64_t N, int64_t heads, int64_t D,
                                     int64_t Lq, int64_t LqP, int64_t Lk, int64_t LkP, float softmax_scale, int flags,
-                                    float *out, void *stream) {
+                                    float *out, int prec, void *stream) {
     return attention_launch(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, Lq, LkP, LkP / 16,
-                            softmax_scale, flags, out, nullptr, stream);
+                            softmax_scale, flags, out, nullptr, prec, stream);
 }
 
 // The same attention between two GEMMs that exchange OPERANDS: qs / ks / vp as written by mvip_gemm_f16x3_sinks (planes of
@@ -436,8 +443,9 @@ extern "C" int mvip_attention_f16x3(const void *qs, const void *ks, const void *
 extern "C" int mvip_attention_f16x3_sink(const void *qs, const void *ks, const void *vp, const float *q_scale2,
                                          const float *k_scale2, const float *v_scale2, int64_t N, int64_t heads, int64_t D,
                                          int64_t Lq, int64_t LqP, int64_t Lk, int64_t LkP, int64_t q_stride, int64_t k_stride,
-                                         int64_t v_groups, float softmax_scale, int flags, void *out_planes, void *stream) {
+                                         int64_t v_groups, float softmax_scale, int flags, void *out_planes, int prec,
+                                         void *stream) {
     if (!out_planes) return MVIP_EINVAL;
     return attention_launch(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, LqP, Lk, LkP, q_stride, k_stride,
-                            v_groups, softmax_scale, flags, nullptr, out_planes, stream);
+                            v_groups, softmax_scale, flags, nullptr, out_planes, prec, stream);
 }

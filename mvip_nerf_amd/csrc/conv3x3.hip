@@ -214,7 +214,7 @@ template <bool GN, bool SILU>
 __global__ void __launch_bounds__(256)
 cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ scale2,
-                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp) {
+                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp, int prec) {
     __shared__ float pa[16], pb[16], pm[16];
     const int CK = C / 16;
     const int ck = (int)(blockIdx.y % CK);
@@ -255,7 +255,7 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
         uint4 hi, lo;
         split8(t, hi, lo);
         dst[(kg * 2 + 0) * HW] = hi;
-        dst[(kg * 2 + 1) * HW] = lo;
+        if (prec == 0) dst[(kg * 2 + 1) * HW] = lo;          // prec 1 (fp16 mode): consumers fetch the hi plane only
     }
 }
 
@@ -272,7 +272,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int KH, int KW, int stride, int pad_top,
                        int pad_left, int OH, int OW, int KP, int64_t PP, const float *__restrict__ scale2,
-                       uint4 *__restrict__ xs) {
+                       uint4 *__restrict__ xs, int prec) {
     const int CKP = KP / 16;
     const int ck = (int)(blockIdx.y % CKP);
     const int64_t n = blockIdx.y / CKP;
@@ -311,7 +311,7 @@ cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int K
         uint4 hi, lo;
         split8(t8, hi, lo);
         dst[(kg * 2 + 0) * PP] = hi;
-        dst[(kg * 2 + 1) * PP] = lo;
+        if (prec == 0) dst[(kg * 2 + 1) * PP] = lo;
     }
 }
 
@@ -373,7 +373,10 @@ struct ConvArgs {
 // Split-K: at the inner UNet levels the grid of (pixel tile, row block) pairs is far smaller than the chip (1280 channels
 // at 16 x 16 x 2 images: 80 workgroups, at 8 x 8: 40) while one layer's weights are 59-118 MB, so those layers are bound by
 // how many CUs pull weights at once; with a.partial set the channel range is divided over a.splits workgroups.
-template <int MT, int TW = CV_TW, int NW = 4>
+// F16 (the reference's --fp16 mode, DS_NeRF/guidance/sd_utils.py:66): ONE fp16 product per contraction step -- only the hi
+// plane of the activations and the hi fragments of the weights are fetched (the lo halves of both operand images are
+// neither read nor, by the producers, written), fp32 accumulation; a third of the matrix work and half the operand traffic.
+template <int MT, int TW = CV_TW, int NW = 4, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
     constexpr int NT = NW * 64;
     constexpr int TH = NT / TW, HW = TW + 2, RPB = 32 / TW;                         // RPB: image rows per column block
@@ -416,7 +419,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     for (int r = 0; r < CV_IN_ROUNDS; ++r) {
         const int s = r * NT + tid;
         in_off[r] = s < 4 * PIX ? -1 : -2;             // -1: halo outside the image (zero page), -2: no slot
-        if (s < 4 * PIX) {
+        if (F16 && s < 4 * PIX && ((s / PIX) & 1)) in_off[r] = -2;        // lo planes (piece = kg*2 + hl) are not fetched
+        if (s < 4 * PIX && in_off[r] != -2) {
             const int piece = s / PIX, p = s - piece * PIX;
             const int row = p / HW, col = p - row * HW;
             if constexpr (TW == 8) {
@@ -452,7 +456,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 #pragma unroll
         for (int b0 = 0; b0 < 6 * MT; b0 += NW) {       // LDS block b = m*6 + kx*2 + hl
             const int b = b0 + wave;
-            if (b < 6 * MT) glds16b(src + (int64_t)(b / 6) * a.CK * 3 * WROW + (b % 6) * 1024, dst + b * 1024);
+            if (b < 6 * MT && !(F16 && (b & 1)))           // b odd = lo fragments
+                glds16b(src + (int64_t)(b / 6) * a.CK * 3 * WROW + (b % 6) * 1024, dst + b * 1024);
         }
     };
 
@@ -484,7 +489,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     auto load_a = [&](const char *wb, int g, int set) {
         const int kx = g / MT, m = g % MT;
         Ah[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
-        Al[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
+        if constexpr (!F16) Al[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
     };
     auto load_b = [&](const char *inb, int ky, int kx) {
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
             if (a.dbg & 32) p = (j * 3 + kx) * 64 + lane - (kg * 2) * PIX;          // timing only: wave-linear 1-KB fragment reads
 #endif
             Bh[kx][j] = *reinterpret_cast<const h16x8 *>(inb + p * 16);
-            Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + PIX * 16 + p * 16);
+            if constexpr (!F16) Bl[kx][j] = *reinterpret_cast<const h16x8 *>(inb + PIX * 16 + p * 16);
         }
     };
     auto w_base = [&](int t) { return lds_w + (t % 3) * WB + lane * 16; };
@@ -565,10 +570,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][1], acc[m][1], 0, 0, 0);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][0], acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][1], acc[m][1], 0, 0, 0);
+            if constexpr (!F16) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][1], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][1], acc[m][1], 0, 0, 0);
+            }
         }
     }
 
@@ -685,7 +692,7 @@ __global__ void __launch_bounds__(256)
 cv_split_reduce_planes_kernel(const float *__restrict__ partial, int splits, int N, int M, int64_t P,
                               const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
                               const float *__restrict__ bias, const float *__restrict__ residual, float out_scale,
-                              uint4 *__restrict__ planes) {
+                              uint4 *__restrict__ planes, int prec) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int blk = blockIdx.y % (M / 8), n = blockIdx.y / (M / 8);
     if (p >= P) return;
@@ -714,7 +721,7 @@ cv_split_reduce_planes_kernel(const float *__restrict__ partial, int splits, int
     sink_split8(v, hi, lo);
     uint4 *dst = planes + (((int64_t)n * (M / 16) + (blk >> 1)) * 4 + (blk & 1) * 2) * P + p;
     dst[0] = hi;
-    dst[P] = lo;
+    if (prec == 0) dst[P] = lo;
 }
 
 // ---- plain GEMM (1x1 convolution, attention products) on the same operand formats -----------------------
@@ -746,6 +753,7 @@ struct GemmArgs {
     // y is not written for these rows.
     struct Sec { char *ptr; float scale; int row_end, kind; } sec[3];
     int nsec, v_dt;              // v_dt: 32-row tiles per head in a kind-2 section
+    int prec;                    // 1: single fp16 product (hi planes / hi fragments only; sinks write no lo halves)
 #ifdef MVIP_EXPERIMENT_GEMM
     int dbg;                     // timing experiments: 1 = no epilogue stores, 2 = no MFMAs, 4 = no LDS reads either
 #endif
@@ -771,7 +779,7 @@ __device__ __forceinline__ void gemm_epilogue_vfrag(const GemmArgs &a, f32x16 (&
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[m][j][r] * mul + bs;
-            sink_store_vfrag(vt, (int)((p0 + (2 * wave + j) * 32) / 16), lane, v);
+            sink_store_vfrag(vt, (int)((p0 + (2 * wave + j) * 32) / 16), lane, v, a.prec == 0);
         }
     }
 }
@@ -826,7 +834,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                         if (hr) t += rv[j][r];
                         v[r] = t * sc.scale;
                     }
-                    sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v);
+                    sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v, true, a.prec == 0);
                 }
             }
         }
@@ -859,7 +867,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                     const float t = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
                     v[r] = px >= a.geglu_L ? 0.f : t * os;
                 }
-                sink_store_planes(pn, a.P, mb * 4, n_blk8, px, kg, v);
+                sink_store_planes(pn, a.P, mb * 4, n_blk8, px, kg, v, true, a.prec == 0);
             }
             return;
         }
@@ -1038,8 +1046,9 @@ __device__ __forceinline__ void cv_static_for(F &&f) {
 }
 constexpr int G5_DB = 6;        // B prefetch depth in 16-k chunks
 constexpr int G5_CA = 4;        // 16-k chunks per A ring slot
-template <int MT, bool SWAP = false>
+template <int MT, bool SWAP = false, bool F16 = false>
 __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const GemmArgs a) {
+    constexpr int NHL = F16 ? 1 : 2;                        // operand halves fetched per fragment
     constexpr int SLOT = G5_CA * MT * 2 * 1024;            // bytes of a ring slot: [u][m][hl][lane][16 B]
     // three separate arrays, not one: the compiler's wait-count pass then knows that an LDS-DMA into one slot cannot
     // alias the fragment reads of another and puts no vmcnt(0) in front of them
@@ -1075,13 +1084,13 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         bsrc[j] = a.xs + (((int64_t)n * a.CK + ck0) * 4 + kg * 2) * plane + (p0 + (2 * wave + j) * 32 + l32) * 16;
-    h16x8 Bq[G5_DB][2][2];
+    h16x8 Bq[G5_DB][2][NHL];
     auto load_b = [&](int ck, auto slot_) {
         constexpr int slot = decltype(slot_)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
+            for (int hl = 0; hl < NHL; ++hl)
                 Bq[slot][j][hl] = *reinterpret_cast<const h16x8 *>(bsrc[j] + ((int64_t)ck * 4 + hl) * plane);
     };
     // A: ring slot `slot` <- 16-k chunks c*CA .. c*CA+CA-1 of the MT row blocks; piece q = (u*MT + m)*2 + hl.  The slot
@@ -1090,13 +1099,15 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
         constexpr int slot = decltype(slot_)::value;
         if (always || c < nchunk) {
 #pragma unroll
-            for (int q0 = 0; q0 < G5_CA * MT * 2; q0 += 4) {
-                const int q = q0 + wave;
+            for (int q0 = 0; q0 < G5_CA * MT * NHL; q0 += 4) {
+                const int qq = q0 + wave;                    // F16: the hi pieces only, spread over the four waves
+                const int q = F16 ? qq * 2 : qq;
                 const int hl = q & 1, m = (q >> 1) % MT, u = (q >> 1) / MT;
                 int ck = c * G5_CA + u;
                 if (ck >= nck) ck = nck - 1;                 // partial last chunk: a valid address, never multiplied
-                glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + ck0 + ck) * 2 + hl) * 1024) + lane * 16,
-                        ring(slot_) + q * 1024);
+                if (!F16 || qq < G5_CA * MT)
+                    glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + ck0 + ck) * 2 + hl) * 1024) + lane * 16,
+                            ring(slot_) + q * 1024);
             }
         }
     };
@@ -1113,7 +1124,7 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
     issue_a(1, cic<1>{});
     cv_static_for<G5_DB>([&](auto d) { if (d.value < nck) load_b(d.value, d); });
     // ring slots 0 and 1 are in LDS once this wave's loads issued before B(0) have returned and every wave says so
-    if (nck >= G5_DB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (G5_DB - 1)) : "memory");
+    if (nck >= G5_DB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NHL * (G5_DB - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
@@ -1135,6 +1146,14 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const h16x8 ah = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 0) * 1024);
+            if constexpr (F16) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (SWAP) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], ah, acc[m][j], 0, 0, 0);
+                    else acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                }
+                continue;
+            }
             const h16x8 al = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 1) * 1024);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -1370,21 +1389,21 @@ extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void 
     return check_launch();
 }
 
-extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
+extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs, int prec,
                                  void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, C * HW, HW, (int64_t)1);
+                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, C * HW, HW, (int64_t)1, prec);
     return check_launch();
 }
 
 extern "C" int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW,
                                         int stride, int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP,
-                                        int64_t PP, const float *scale2, void *xs, void *stream) {
-    if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
+                                        int64_t PP, const float *scale2, void *xs, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
         OH <= 0 || OW <= 0 || KP <= 0 || KP % 16 != 0 || KP < Cin * KH * KW || PP < OH * OW || H * W > (1 << 30) ||
         OH * OW > (1 << 30))
         return MVIP_EINVAL;
@@ -1392,7 +1411,7 @@ extern "C" int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, 
     if (!x || !xs || N * (KP / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((PP + 255) / 256), (unsigned)(N * (KP / 16)));
     hipLaunchKernelGGL(cv_im2col_split_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)Cin, (int)H, (int)W, KH, KW,
-                       stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, scale2, (uint4 *)xs);
+                       stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, scale2, (uint4 *)xs, prec);
     return check_launch();
 }
 
@@ -1411,29 +1430,29 @@ extern "C" int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, 
 }
 
 extern "C" int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc,
-                                         int64_t sp, const float *scale2, void *xs, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0) return MVIP_EINVAL;
+                                         int64_t sp, const float *scale2, void *xs, int prec, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, sn, sc, sp);
+                       nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, sn, sc, sp, prec);
     return check_launch();
 }
 
 extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
                                            const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu,
-                                           void *xs, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0) return MVIP_EINVAL;
+                                           void *xs, int prec, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || !mean || !rstd || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     if (silu)
         hipLaunchKernelGGL((cv_to_split_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
-                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1);
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec);
     else
         hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
-                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1);
+                           rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec);
     return check_launch();
 }
 
@@ -1473,8 +1492,8 @@ extern "C" int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t 
 
 static int conv3x3_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                          int64_t H, int64_t W, float *y, void *workspace, void *stream) {
-    if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return MVIP_EINVAL;
+                          int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream) {
+    if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W) || (prec != 0 && prec != 1)) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
     int tw, MT;
@@ -1499,7 +1518,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
     // four-wave tile on every VAE / UNet shape and on the whole step, 7.56 vs 7.65 ms -- tools/conv_wide_ab.py)
     static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
-    if (tw == CV_TW && wide_mode && H % 16 == 0) {
+    if (tw == CV_TW && wide_mode && H % 16 == 0 && prec == 0) {
         const int64_t tiles16 = N * (W / CV_TW) * (H / 16);
         int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
         // MVIP_CONV_WIDE=2: 128 rows x 512 pixels per eight-wave workgroup (one per CU, two waves per SIMD, 128
@@ -1524,16 +1543,16 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     }
     blocks *= a.splits;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    if (tw == 8)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (tw == 16)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (MT == 4)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (MT == 2)
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+#define MVIP_CV_LAUNCH(F16_)                                                                                                   \
+    do {                                                                                                                      \
+        if (tw == 8) hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 8, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);         \
+        else if (tw == 16) hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);  \
+        else if (MT == 4) hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, CV_TW, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        else if (MT == 2) hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
+    } while (0)
+    if (prec) MVIP_CV_LAUNCH(true); else MVIP_CV_LAUNCH(false);
+#undef MVIP_CV_LAUNCH
     if (a.partial) {
         const int64_t total = N * Cout * H * W;
         hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
@@ -1544,17 +1563,17 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
 
 extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                   const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                                  int64_t H, int64_t W, float *y, void *stream) {
-    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, nullptr, stream);
+                                  int64_t H, int64_t W, float *y, int prec, void *stream) {
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, nullptr, prec, stream);
 }
 
 // The same with a caller-owned workspace of mvip_conv3x3_workspace_bytes(...) bytes (may be null when that is 0): layers
 // whose grid would leave most of the chip idle are split over the input channels and summed by a second launch.
 extern "C" int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                      const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                                     int64_t H, int64_t W, float *y, void *workspace, void *stream) {
+                                     int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream) {
     if (!workspace && mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W) > 0) return MVIP_EINVAL;
-    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, workspace, stream);
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, workspace, prec, stream);
 }
 
 /* ---- plain GEMM ---------------------------------------------------------------------------------------- */
@@ -1614,8 +1633,9 @@ extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, in
 
 static int gemm_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                       float *y, int cfg, void *workspace, void *stream) {
-    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return MVIP_EINVAL;
+                       float *y, int cfg, void *workspace, int prec, void *stream) {
+    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || (prec != 0 && prec != 1))
+        return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
     GemmArgs a;
@@ -1623,14 +1643,14 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
-    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 0; a.v_dt = 1;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 0; a.v_dt = 1; a.prec = prec;
     a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = cfg >> 8; cfg &= 255;
 #endif
     hipStream_t st = as_stream(stream);
     const bool auto_cfg = cfg == 0;
-    if (cfg == 0) cfg = gm_auto_cfg(N, M, P);
+    if (cfg == 0) cfg = prec ? 1 : gm_auto_cfg(N, M, P);     // the single-product instantiation exists for the 32/64-row kernel
     if (cfg < 0 || cfg > 5) return MVIP_EINVAL;
     if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
     if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
@@ -1657,7 +1677,10 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
         // cfg 5 (and the automatic choice unless MVIP_GEMM_STREAM=0): the B-in-registers kernel
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
         const bool stream = cfg == 5 || (auto_cfg && stream_env);
-        if (MT == 4)
+        if (prec && MT <= 2 && stream) {
+            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        } else if (MT == 4)
             hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else if (MT == 2 && stream)
             hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -1680,14 +1703,14 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
 // 5 = 32/64-row kernel with the B operand streamed into registers (timing switch)
 extern "C" int mvip_gemm_f16x3_cfg(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                    const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                                   float *y, int cfg, void *stream) {
-    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, cfg, nullptr, stream);
+                                   float *y, int cfg, int prec, void *stream) {
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, cfg, nullptr, prec, stream);
 }
 
 extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                               float *y, void *stream) {
-    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, nullptr, stream);
+                               float *y, int prec, void *stream) {
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, nullptr, prec, stream);
 }
 
 // mvip_gemm_f16x3 with a caller-owned workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (null when that is 0):
@@ -1695,9 +1718,9 @@ extern "C" int mvip_gemm_f16x3(const void *xs, const void *packed, const float *
 // 80 workgroups x 160 stages) are split over K and summed by a second launch, in index order.
 extern "C" int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                                   const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                                  float *y, void *workspace, void *stream) {
+                                  float *y, void *workspace, int prec, void *stream) {
     if (!workspace && mvip_gemm_workspace_bytes(N, K, M, P) > 0) return MVIP_EINVAL;
-    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, workspace, stream);
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, workspace, prec, stream);
 }
 
 // First projection of the transformer feed-forward with the GEGLU fused into the epilogue:
@@ -1706,8 +1729,8 @@ extern "C" int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const floa
 // the same t); scale2 receives the power-of-two scale of |out|max; zero_word as in mvip_absmax_scale_sections.
 extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias, const float *x_scale2,
                                      int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, float *out, float *scale2,
-                                     void *zero_word, void *stream) {
-    if (N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+                                     void *zero_word, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
         !scale2 || !zero_word)
         return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -1718,12 +1741,13 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         a.w_scale2 = (const float *)((const char *)packed + M2 * K * 4);
         a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = out;
         a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
-        a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word; a.nsec = 0; a.v_dt = 1;
+        a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word; a.nsec = 0; a.v_dt = 1; a.prec = prec;
         a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
-        if (stream_env) hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (stream_env) hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(gm_scale_from_bits_kernel, dim3(1), dim3(1), 0, st, scale2, (unsigned *)zero_word);
@@ -1738,8 +1762,8 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
 // (W x + bias) * sec_scale[i], sec_scale a power of two the caller fixed BEFORE the launch from a bound of the result.
 extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                                      int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
-                                     void *const *sec_ptr, const float *sec_scale, int v_dt, void *stream) {
-    if (N < 0 || M <= 0 || M % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || nsec < 1 || nsec > 3 ||
+                                     void *const *sec_ptr, const float *sec_scale, int v_dt, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || M <= 0 || M % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || nsec < 1 || nsec > 3 ||
         !sec_rows || !sec_kind || !sec_ptr || !sec_scale)
         return MVIP_EINVAL;
     int64_t end = 0, plane_rows = 0;
@@ -1763,7 +1787,7 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = nullptr;
     a.N = (int)N; a.CK = (int)(K / 16); a.P = P;
-    a.geglu_L = 0; a.absmax_bits = nullptr; a.v_dt = v_dt < 1 ? 1 : v_dt;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.v_dt = v_dt < 1 ? 1 : v_dt; a.prec = prec;
     a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = 0;
@@ -1777,13 +1801,14 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
         a.MB = (int)(rows / (32 * MT));
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-        if (swap) {
-            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        } else {
-            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        }
+#define MVIP_G5(MT_, SW_)                                                                                                    \
+        do {                                                                                                                    \
+            if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);    \
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);        \
+        } while (0)
+        if (swap) { if (MT == 2) MVIP_G5(2, true); else MVIP_G5(1, true); }
+        else { if (MT == 2) MVIP_G5(2, false); else MVIP_G5(1, false); }
+#undef MVIP_G5
         return MVIP_OK;
     };
     for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
@@ -1813,8 +1838,8 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
 // collection, no scale launch, no fp32 intermediate.
 extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2,
                                           int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes,
-                                          float out_scale, void *stream) {
-    if (N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+                                          float out_scale, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
         !(out_scale > 0.f) || (M2 / 2) % 16 != 0)
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
@@ -1824,7 +1849,7 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
     a.w_scale2 = (const float *)((const char *)packed + M2 * K * 4);
     a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = nullptr;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
-    a.geglu_L = (int)L; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1;
+    a.geglu_L = (int)L; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1; a.prec = prec;
     for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
     a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)(M2 / 2); a.sec[0].kind = 1;
     a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
@@ -1833,7 +1858,8 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
 #endif
     const int64_t blocks = N * a.tiles * a.MB;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     return check_launch();
 }
 
@@ -1842,8 +1868,8 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
 // mvip_gemm_f16x3_ws: workspace of mvip_gemm_workspace_bytes(N, K, M, P) bytes (null when that is 0).
 extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, const float *bias, const float *residual,
                                          const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P, void *out_planes,
-                                         float out_scale, void *workspace, void *stream) {
-    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || !(out_scale > 0.f))
+                                         float out_scale, void *workspace, int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || !(out_scale > 0.f))
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !out_planes) return MVIP_EINVAL;
@@ -1853,7 +1879,7 @@ extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, con
     a.w_scale2 = (const float *)((const char *)packed + M * K * 4);
     a.bias = bias; a.chan_add = nullptr; a.residual = residual; a.x_scale2 = x_scale2; a.y = nullptr;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
-    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1;
+    a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1; a.prec = prec;
     for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
     a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)M; a.sec[0].kind = 1;
     a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
@@ -1872,11 +1898,16 @@ extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, con
     blocks *= a.splits;
     if (blocks > 0x7fffffffLL || N * (M / 8) > 65535) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (prec) {
+        if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     if (a.partial)
         hipLaunchKernelGGL(cv_split_reduce_planes_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(N * (M / 8))), dim3(256), 0,
                            st, a.partial, a.splits, (int)N, (int)M, P, a.w_scale2, x_scale2, bias, residual, out_scale,
-                           (uint4 *)out_planes);
+                           (uint4 *)out_planes, prec);
     return check_launch();
 }

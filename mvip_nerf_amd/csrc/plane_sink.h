@@ -60,7 +60,7 @@ __device__ __forceinline__ void sink_exchange(const float (&v)[16], float (&f0)[
 // inside the sample's plane set (row / 8), n_blk8 = valid 8-row blocks of the set (blocks beyond it are not written);
 // p = this lane's column.  kg = lane >> 5.
 __device__ __forceinline__ void sink_store_planes(char *planes_n, int64_t P, int blk8, int n_blk8, int64_t p, int kg,
-                                                  const float (&v)[16], bool col_ok = true) {
+                                                  const float (&v)[16], bool col_ok = true, bool write_lo = true) {
     float f0[8], f1[8];
     sink_exchange(v, f0, f1);
     uint4 hi, lo;
@@ -69,20 +69,20 @@ __device__ __forceinline__ void sink_store_planes(char *planes_n, int64_t P, int
         sink_split8(f0, hi, lo);
         uint4 *dst = reinterpret_cast<uint4 *>(planes_n) + ((int64_t)(b0 >> 1) * 4 + (b0 & 1) * 2) * P + p;
         dst[0] = hi;
-        dst[P] = lo;
+        if (write_lo) dst[P] = lo;                    // fp16 mode: the consumer fetches hi planes only
     }
     if (col_ok && b1 < n_blk8) {
         sink_split8(f1, hi, lo);
         uint4 *dst = reinterpret_cast<uint4 *>(planes_n) + ((int64_t)(b1 >> 1) * 4 + (b1 & 1) * 2) * P + p;
         dst[0] = hi;
-        dst[P] = lo;
+        if (write_lo) dst[P] = lo;
     }
 }
 
 // Store one TRANSPOSED tile (lane = channel row, registers = 32 tokens) as two attention V fragments (csrc/attention.hip):
 // registers 0..7 are the fragment of the tile's first 16 keys, 8..15 of its second 16, already in the kernel's key order.
 // frag16: [.. s16][hl 2][lane 64][16 B], vt = the (head, dt) block's base, s16 = first 16-key group of the tile.
-__device__ __forceinline__ void sink_store_vfrag(char *vt, int s16, int lane, const float (&v)[16]) {
+__device__ __forceinline__ void sink_store_vfrag(char *vt, int s16, int lane, const float (&v)[16], bool write_lo = true) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         float t[8];
@@ -92,7 +92,7 @@ __device__ __forceinline__ void sink_store_vfrag(char *vt, int s16, int lane, co
         sink_split8(t, hi, lo);
         uint4 *dst = reinterpret_cast<uint4 *>(vt) + ((int64_t)(s16 + s) * 2) * 64 + lane;
         dst[0] = hi;
-        dst[64] = lo;
+        if (write_lo) dst[64] = lo;
     }
 }
 

@@ -63,7 +63,7 @@ ln_stats_kernel(const float *__restrict__ x, int C, int L, int LP, double *__res
 __global__ void __launch_bounds__(256)
 ln_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                 const double *__restrict__ part, int C, int L, int LP, float eps, float out_scale,
-                uint4 *__restrict__ xs) {
+                uint4 *__restrict__ xs, int prec) {
     const int CK = C / 16, S = C / 64;
     const int ck = blockIdx.y % CK, n = blockIdx.y / CK;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -99,7 +99,7 @@ ln_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
         uint4 hi, lo;
         split8(t, hi, lo);
         dst[(int64_t)(kg * 2 + 0) * LP] = hi;
-        dst[(int64_t)(kg * 2 + 1) * LP] = lo;
+        if (prec == 0) dst[(int64_t)(kg * 2 + 1) * LP] = lo;        // fp16 mode: hi planes only
     }
 }
 
@@ -193,15 +193,15 @@ extern "C" int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t 
 
 extern "C" int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
                                            int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
-                                           void *stream) {
-    if (N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535) return MVIP_EINVAL;
+                                           int prec, void *stream) {
+    if ((prec != 0 && prec != 1) || N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!x || !xs || !workspace) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(LP / 64), (unsigned)(C / 64), (unsigned)N), dim3(256), 0, st, x,
                        (int)C, (int)L, (int)LP, (double *)workspace);
     hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)(LP / 256), (unsigned)(N * (C / 16))), dim3(256), 0, st, x, gamma,
-                       beta, (const double *)workspace, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs);
+                       beta, (const double *)workspace, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs, prec);
     return check_launch();
 }
 

@@ -304,7 +304,16 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(block_out[0], out_channels, 3, padding=1)
         self._t_dim = block_out[0]
 
+    mfma_prec = 0          # 1: the reference's --fp16 mode on the hand-written kernels (one fp16 product; SDNetworks sets it)
+
     def forward(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False):
+        if sample.is_cuda:
+            from .. import ops
+            with ops.precision(self.mfma_prec):
+                return self._forward(sample.to(self.conv_in.weight.dtype), timestep, encoder_hidden_states)
+        return self._forward(sample, timestep, encoder_hidden_states)
+
+    def _forward(self, sample, timestep, encoder_hidden_states):
         t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
         temb = self.time_embedding(timestep_sinusoid(t, self._t_dim).to(sample.dtype))
         x = conv_any(self.conv_in, sample)
@@ -422,7 +431,14 @@ class AutoencoderKL(nn.Module):
         self.quant_conv, self.post_quant_conv = nn.Conv2d(8, 8, 1), nn.Conv2d(4, 4, 1)
         self.config = self.Cfg()
 
+    mfma_prec = 0          # as UNet2DConditionModel.mfma_prec
+
     def encode(self, x):
+        if x.is_cuda:
+            from .. import ops
+            with ops.precision(self.mfma_prec):
+                x = x.to(self.quant_conv.weight.dtype)
+                return _EncOut(LatentDist(conv_any(self.quant_conv, self.encoder(x))))
         return _EncOut(LatentDist(conv_any(self.quant_conv, self.encoder(x))))
 
     def decode(self, z, return_dict=False):
@@ -485,13 +501,25 @@ class SDNetworks:
     def __init__(self, device, dtype=torch.float32, seed=3):
         g = torch.random.get_rng_state()
         torch.manual_seed(seed)
-        self.vae = AutoencoderKL().to(device=device, dtype=dtype).eval()
-        self.unet = UNet2DConditionModel().to(device=device, dtype=dtype).eval()
-        self.text_encoder = CLIPTextModel().to(device=device, dtype=dtype).eval()
+        # dtype float16 = the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66: every network in half).  On the
+        # device it runs on the hand-written kernels in their single-product arithmetic (mfma_prec = 1: fp16 operands,
+        # fp32 accumulate): the parameters are ROUNDED to fp16 values and kept in fp32 containers, so that the operand
+        # packers, GroupNorm / LayerNorm and the epilogues read them as they read the fp32 networks' parameters, and
+        # tensors between kernels stay fp32 (wider than the reference's fp16 tensors, never narrower).  On the host (shape
+        # checks only) the modules are plain half modules.
+        on_kernels = dtype == torch.float16 and torch.device(device).type == 'cuda'
+        pdt = torch.float32 if on_kernels else dtype
+        self.vae = AutoencoderKL().to(device=device, dtype=pdt).eval()
+        self.unet = UNet2DConditionModel().to(device=device, dtype=pdt).eval()
+        self.text_encoder = CLIPTextModel().to(device=device, dtype=pdt).eval()
         torch.random.set_rng_state(g)
         for m in (self.vae, self.unet, self.text_encoder):
             for p in m.parameters():
                 p.requires_grad_(False)
+                if on_kernels:
+                    p.data = p.data.half().float()
+        if on_kernels:
+            self.vae.mfma_prec = self.unet.mfma_prec = 1
         self.tokenizer = ByteTokenizer()
         self.alphas_cumprod = scaled_linear_alphas_cumprod()
         self.device, self.dtype = device, dtype

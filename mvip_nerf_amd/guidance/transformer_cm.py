@@ -206,7 +206,7 @@ def prompt_entries(unet):
 def _prompt_kv(pk, ctx, want_vmax=False):
     """Key planes / value fragments of the prompt tokens for the cross-attention (constant per prompt).  want_vmax: also
     the power of two >= |v|max (read back ONCE per prompt, when the entry is made: 1024 / scale of the measured split)."""
-    key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+    key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), ops._prec())     # fp16-mode entries carry no lo halves
     hit = pk.ctx_cache.get(key)
     if hit is not None:
         return hit[1:] if want_vmax else hit[1:-1]

@@ -558,6 +558,30 @@ def conv3x3_supported(conv, x):
     return ok
 
 
+# Arithmetic of the SDS networks' contractions (csrc/conv3x3.hip, attention.hip): 0 = split precision (fp16 hi + lo halves of
+# both operands, three products: fp32-grade, the fp32 networks), 1 = the reference's --fp16 mode (DS_NeRF/guidance/
+# sd_utils.py:66): one fp16 product, hi halves only.  Set for the duration of a network's forward by `precision(...)`
+# (guidance/sd_nets.py); autograd Functions remember it for their backward.
+PREC = 0
+
+
+class precision:
+    def __init__(self, prec):
+        self.prec = int(prec)
+
+    def __enter__(self):
+        global PREC
+        self.old, PREC = PREC, self.prec
+
+    def __exit__(self, *exc):
+        global PREC
+        PREC = self.old
+
+
+def _prec():
+    return int(PREC)
+
+
 def conv3x3_pack(weight, transpose=False):
     """Packed split-precision image of a [Cout, Cin, 3, 3] weight (transpose: the data-gradient operator)."""
     Cout, Cin = weight.shape[0], weight.shape[1]
@@ -584,6 +608,14 @@ def _split_buffer(N, C, HW, device):
     return torch.empty(N * C * HW * 2, device=device, dtype=torch.float16)
 
 
+def _with_saved_prec(backward):
+    """The backward of an SDS contraction runs in the arithmetic of its forward (ctx.prec), whatever is current."""
+    def wrapped(ctx, *grads):
+        with precision(getattr(ctx, 'prec', 0)):
+            return backward(ctx, *grads)
+    return wrapped
+
+
 class _NormActConv3x3(torch.autograd.Function):
     """conv3x3(act(group_norm(x))) + bias [+ chan_add[:, :, None, None]] [+ residual]: statistics, split-plane
     writer (normalise + SiLU fused) and the MFMA convolution.  Backward: dY -> split planes (scaled by a power of
@@ -592,6 +624,7 @@ class _NormActConv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, chan_add, residual, norm, conv, silu):
+        ctx.prec = _prec()
         for p in (norm.weight, norm.bias, conv.weight, conv.bias):
             if p is not None and p.requires_grad:
                 raise NotImplementedError('conv3x3: parameter gradients are not implemented (frozen networks only)')
@@ -608,7 +641,7 @@ class _NormActConv3x3(torch.autograd.Function):
              ptr(ws, torch.float64), stream())
         xs = _split_buffer(N, C, HW, dev)
         call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
-             int(bool(silu)), ptr(xs, torch.float16), stream())
+             int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
         y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
         bias = None if conv.bias is None else conv.bias.detach().contiguous()
         ca = None if chan_add is None else chan_add.detach().contiguous()
@@ -619,6 +652,7 @@ class _NormActConv3x3(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_with_saved_prec
     def backward(ctx, dy):
         xc, gw, gb, mean, rstd = ctx.saved_tensors
         norm, conv, silu = ctx.mods
@@ -632,7 +666,7 @@ class _NormActConv3x3(torch.autograd.Function):
             scale2 = torch.empty(4, device=dev, dtype=torch.float32)
             call('mvip_absmax_scale', ptr(dyc), dyc.numel(), ptr(scale2), ptr(_zero_words(dev)[32:34], torch.int32), stream())
             dys = _split_buffer(N, Cout, HW, dev)
-            call('mvip_split_planes', ptr(dyc), N, Cout, HW, ptr(scale2), ptr(dys, torch.float16), stream())
+            call('mvip_split_planes', ptr(dyc), N, Cout, HW, ptr(scale2), ptr(dys, torch.float16), _prec(), stream())
             dact = torch.empty_like(xc)
             _conv3x3_launch(dys, _conv_packed(conv, True), None, None, None, scale2, N, Cout, C, H, W, dact)
             del dys
@@ -650,7 +684,7 @@ def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, 
     nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W))
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
     call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
-         ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), stream())
+         ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), _prec(), stream())
 
 
 def conv3x3_plain(x, conv):
@@ -662,7 +696,7 @@ def conv3x3_plain(x, conv):
     Cout, dev = conv.out_channels, xc.device
     scale2 = unit_scale(dev) if FORWARD_UNIT_SCALE else absmax_scale(xc)
     xs = _split_buffer(N, C, H * W, dev)
-    call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), stream())
+    call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
     y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
     bias = None if conv.bias is None else _f32c(conv.bias.detach())
     _conv3x3_launch(xs, _conv_packed(conv, False), bias, None, None, scale2, N, C, Cout, H, W, y)
@@ -843,7 +877,7 @@ def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
     """X[n][k][p] = x.flatten()[n*sn + k*sc + p*sp] (* scale2[0]) -> fp16 hi/lo split planes."""
     xc = x.contiguous()
     xs = _split_buffer(N, K, P, xc.device)
-    call('mvip_split_planes_strided', ptr(xc), N, K, P, sn, sc, sp, ptr(scale2), ptr(xs, torch.float16), stream())
+    call('mvip_split_planes_strided', ptr(xc), N, K, P, sn, sc, sp, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
     return xs
 
 
@@ -855,12 +889,12 @@ def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, 
     y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
     if GEMM_CFG:
         call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
-             ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), stream())
+             ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), _prec(), stream())
         return y
     nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))            # split-K partial sums (few shapes)
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
     call('mvip_gemm_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
-         ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), stream())
+         ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), _prec(), stream())
     return y
 
 
@@ -916,6 +950,7 @@ class _VAEAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod):
+        ctx.prec = _prec()
         for p in mod.parameters():
             if p.requires_grad:
                 raise NotImplementedError('vae_attention: parameter gradients are not implemented (frozen networks only)')
@@ -932,7 +967,7 @@ class _VAEAttention(torch.autograd.Function):
              ptr(ws, torch.float64), stream())
         hs = _split_buffer(N, C, L, dev)
         call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, L, G, 0,
-             ptr(hs, torch.float16), stream())
+             ptr(hs, torch.float16), _prec(), stream())
         qkv = gemm_f16x3(hs, wts['qkv'], N, C, 3 * C, L, bias=wts['bqkv'])           # [N, 3C, L]
         del hs
         probs, O = [], torch.empty((N, C, L), device=dev, dtype=torch.float32)
@@ -952,6 +987,7 @@ class _VAEAttention(torch.autograd.Function):
         return out.reshape(N, C, H, W)
 
     @staticmethod
+    @_with_saved_prec
     def backward(ctx, dout):
         xc, gw, gb, mean, rstd, qkv, *probs = ctx.saved_tensors
         mod = ctx.mod
@@ -1017,6 +1053,7 @@ class _Conv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, conv):
+        ctx.prec = _prec()
         if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
             raise NotImplementedError('conv1x1: parameter gradients are not implemented (frozen networks only)')
         xc = x.contiguous()
@@ -1030,6 +1067,7 @@ class _Conv1x1(torch.autograd.Function):
         return y.reshape(N, Cout, H, W)
 
     @staticmethod
+    @_with_saved_prec
     def backward(ctx, dy):
         conv = ctx.conv
         N, C, H, W = ctx.shape
@@ -1088,6 +1126,7 @@ def _conv_gemm_packed(conv):
 class _ConvGemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, conv, pads):
+        ctx.prec = _prec()
         if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
             raise NotImplementedError('conv_gemm: parameter gradients are not implemented (frozen networks only)')
         xc = _f32c(x)
@@ -1101,7 +1140,7 @@ class _ConvGemm(torch.autograd.Function):
         s2 = absmax_scale(xc)
         xs = _split_buffer(N, KP, PP, xc.device)
         call('mvip_im2col_split_planes', ptr(xc), N, Cin, H, W, k, k, st, pt, pl, OH, OW, KP, PP, ptr(s2),
-             ptr(xs, torch.float16), stream())
+             ptr(xs, torch.float16), _prec(), stream())
         y = gemm_f16x3(xs, a_fwd, N, KP, MP, PP, bias=bias, x_scale2=s2)
         del xs
         ctx.conv, ctx.geom = conv, (N, Cin, H, W, k, st, pt, pl, OH, OW, Cout, MP, KP, P, PP)
@@ -1110,6 +1149,7 @@ class _ConvGemm(torch.autograd.Function):
         return y.reshape(N, Cout, OH, OW)
 
     @staticmethod
+    @_with_saved_prec
     def backward(ctx, dy):
         if not ctx.needs_input_grad[0]:
             return None, None, None
@@ -1148,7 +1188,7 @@ def norm_conv1x1(x, norm, conv):
          stream())
     xs = _split_buffer(N, C, L, dev)
     call('mvip_groupnorm_split_planes', ptr(xc), ptr(norm.weight.detach().contiguous()),
-         ptr(norm.bias.detach().contiguous()), ptr(mean), ptr(rstd), N, C, L, G, 0, ptr(xs, torch.float16), stream())
+         ptr(norm.bias.detach().contiguous()), ptr(mean), ptr(rstd), N, C, L, G, 0, ptr(xs, torch.float16), _prec(), stream())
     bias = None if conv.bias is None else conv.bias.detach().contiguous()
     return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias)     # [N, Cout, L]
 
@@ -1194,7 +1234,7 @@ def layernorm_split(x, weight, bias, eps, N, C, L, LP, out_scale):
     xs = _split_buffer(N, C, LP, x.device)
     ws = torch.empty(int(_lib.load().mvip_layernorm_workspace_bytes(N, C, LP)) // 8, device=x.device, dtype=torch.float64)
     call('mvip_layernorm_split_planes', ptr(x), ptr(weight), ptr(bias), int(N), int(C), int(L), int(LP), float(eps),
-         float(out_scale), ptr(ws, torch.float64), ptr(xs, torch.float16), stream())
+         float(out_scale), ptr(ws, torch.float64), ptr(xs, torch.float16), _prec(), stream())
     return xs
 
 
@@ -1203,7 +1243,7 @@ def attention_pack_v(v, N, heads, D, DP, Lk, LkP, sn, sr, sk, scale2):
     nbytes = int(_lib.load().mvip_attention_v_bytes(N, heads, D, LkP))
     vp = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
     call('mvip_attention_pack_v', ptr(v), int(N), int(heads), int(D), int(DP), int(Lk), int(LkP), int(sn), int(sr),
-         int(sk), ptr(scale2), ptr(vp, torch.uint8), stream())
+         int(sk), ptr(scale2), ptr(vp, torch.uint8), _prec(), stream())
     return vp
 
 
@@ -1218,7 +1258,7 @@ def attention_f16x3(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, Lq, L
         out = mk((N, heads * D, LqP), device=qs.device, dtype=_F32)
     call('mvip_attention_f16x3', ptr(qs, torch.float16), ptr(ks, torch.float16), ptr(vp, torch.uint8), ptr(q_scale2),
          ptr(k_scale2), ptr(v_scale2), int(N), int(heads), int(D), int(Lq), int(LqP), int(Lk), int(LkP),
-         float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out), stream())
+         float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out), _prec(), stream())
     return out
 
 
@@ -1246,7 +1286,7 @@ def gemm_geglu_f16x3(xs, packed, bias, N, K, M2, P, L, x_scale2=None):
     out = torch.empty((N, M2 // 2, P), device=xs.device, dtype=_F32)
     scale2 = torch.empty(4, device=xs.device, dtype=_F32)
     call('mvip_gemm_geglu_f16x3', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
-         int(K), int(M2), int(P), int(L), ptr(out), ptr(scale2), ptr(_zero_words(xs.device), torch.int32), stream())
+         int(K), int(M2), int(P), int(L), ptr(out), ptr(scale2), ptr(_zero_words(xs.device), torch.int32), _prec(), stream())
     return out, scale2
 
 
@@ -1296,7 +1336,7 @@ def gemm_f16x3_sinks(xs, packed, N, K, P, sections, bias=None, x_scale2=None, v_
             bufs.append(torch.empty(N * r * P * 4, device=xs.device, dtype=torch.uint8))
     ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bufs])
     call('mvip_gemm_f16x3_sinks', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N), int(K),
-         int(M), int(P), n, rows, kinds, ptrs, scales, int(v_dt), stream())
+         int(M), int(P), n, rows, kinds, ptrs, scales, int(v_dt), _prec(), stream())
     return bufs
 
 
@@ -1305,7 +1345,7 @@ def gemm_geglu_f16x3_sink(xs, packed, bias, N, K, M2, P, L, out_scale, x_scale2=
     [N][(M2/2)/16][2][2][P][8]; columns >= L are zero."""
     out = _split_buffer(N, M2 // 2, P, xs.device)
     call('mvip_gemm_geglu_f16x3_sink', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
-         int(K), int(M2), int(P), int(L), ptr(out, torch.float16), float(out_scale), stream())
+         int(K), int(M2), int(P), int(L), ptr(out, torch.float16), float(out_scale), _prec(), stream())
     return out
 
 
@@ -1317,7 +1357,7 @@ def attention_f16x3_sink(qs, ks, vp, q_scale2, k_scale2, v_scale2, N, heads, D, 
     out = mk(N * heads * D * LqP * 2, device=qs.device, dtype=torch.float16)
     call('mvip_attention_f16x3_sink', ptr(qs, torch.float16), ptr(ks, torch.float16), ptr(vp, torch.uint8), ptr(q_scale2),
          ptr(k_scale2), ptr(v_scale2), int(N), int(heads), int(D), int(Lq), int(LqP), int(Lk), int(LkP), int(q_stride),
-         int(k_stride), int(v_groups), float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out, torch.float16), stream())
+         int(k_stride), int(v_groups), float(D) ** -0.5, int(ATTENTION_FLAGS), ptr(out, torch.float16), _prec(), stream())
     return out
 
 
@@ -1328,5 +1368,5 @@ def gemm_f16x3_planes(xs, packed, N, K, M, P, out_scale, bias=None, residual=Non
     nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))
     ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32) if nbytes else None
     call('mvip_gemm_f16x3_planes_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(residual), ptr(x_scale2),
-         int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), stream())
+         int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), _prec(), stream())
     return out

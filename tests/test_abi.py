@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert _lib.load().mvip_abi_version() == 1
+    assert _lib.load().mvip_abi_version() == 2
     assert _lib.load().mvip_mlp_packed_floats() == 597248
     assert _lib.load().mvip_strerror(-1).decode().startswith('invalid')
 

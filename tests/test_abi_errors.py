@@ -27,23 +27,35 @@ CASES = [
     # SDS operand producers and contractions (rows a14-a16)
     ('mvip_resize_bilinear', (P0, 3, 0, 8, 16, 16, P0, P0), (P0, 0, 8, 8, 16, 16, P0, P0), (P0, 3, 8, 8, 16, 16, P0, P0)),
     ('mvip_absmax_scale', (P0, -1, P0, P0, P0), None, (P0, 16, P0, P0, P0)),
-    ('mvip_split_planes', (P0, 1, 24, 64, P0, P0, P0), (P0, 0, 32, 64, P0, P0, P0), (P0, 1, 32, 64, P0, P0, P0)),
+    ('mvip_split_planes', (P0, 1, 24, 64, P0, P0, 0, P0), (P0, 0, 32, 64, P0, P0, 0, P0), (P0, 1, 32, 64, P0, P0, 0, P0)),
+    ('mvip_split_planes', (P0, 1, 32, 64, P0, P0, 2, P0), None, None),                 # prec is 0 (f16x3) or 1 (fp16 mode)
     ('mvip_groupnorm_stats', (P0, 1, 30, 64, 32, 1e-6, 0, P0, P0, P0, P0), (P0, 0, 64, 64, 32, 1e-6, 0, P0, P0, P0, P0),
      (P0, 1, 64, 64, 32, 1e-6, 0, P0, P0, P0, P0)),
     # 3x3 convolution: 33 output channels / a 12 x 12 image are not tileable
-    ('mvip_conv3x3_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 32, 33, 64, 64, P0, P0, P0),
-     (P0, P0, P0, P0, P0, P0, 0, 32, 32, 64, 64, P0, P0, P0), (P0, P0, P0, P0, P0, P0, 1, 32, 32, 64, 64, P0, P0, P0)),
-    ('mvip_conv3x3_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 32, 32, 12, 12, P0, P0, P0), None, None),
+    ('mvip_conv3x3_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 32, 33, 64, 64, P0, P0, 0, P0),
+     (P0, P0, P0, P0, P0, P0, 0, 32, 32, 64, 64, P0, P0, 1, P0), (P0, P0, P0, P0, P0, P0, 1, 32, 32, 64, 64, P0, P0, 1, P0)),
+    ('mvip_conv3x3_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 32, 32, 12, 12, P0, P0, 0, P0), None, None),
+    ('mvip_conv3x3_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 32, 32, 64, 64, P0, P0, 3, P0), None, None),
     # GEMM: K must be a multiple of 32, M of 32, P of the pixel tile
-    ('mvip_gemm_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 48, 64, 256, P0, P0, P0), (P0, P0, P0, P0, P0, P0, 0, 64, 64, 256, P0, P0, P0),
-     (P0, P0, P0, P0, P0, P0, 1, 64, 64, 256, P0, P0, P0)),
-    ('mvip_gemm_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 64, 40, 256, P0, P0, P0), None, None),
-    ('mvip_im2col_split_planes', (P0, 1, 4, 16, 16, 3, 3, 0, 1, 1, 8, 8, 48, 64, P0, P0, P0), None,
-     (P0, 1, 4, 16, 16, 3, 3, 2, 1, 1, 8, 8, 48, 64, P0, P0, P0)),
+    ('mvip_gemm_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 48, 64, 256, P0, P0, 0, P0), (P0, P0, P0, P0, P0, P0, 0, 64, 64, 256, P0, P0, 0, P0),
+     (P0, P0, P0, P0, P0, P0, 1, 64, 64, 256, P0, P0, 1, P0)),
+    ('mvip_gemm_f16x3_ws', (P0, P0, P0, P0, P0, P0, 1, 64, 40, 256, P0, P0, 0, P0), None, None),
+    # GEMMs / attention whose epilogue writes the next contraction's operands: sections are multiples of 64 rows that add up
+    # to M, a V-fragment section is the last one, scales are positive
+    ('mvip_gemm_f16x3_sinks', (P0, P0, P0, P0, 1, 64, 128, 256, 0, None, None, None, None, 1, 0, P0), None, None),
+    ('mvip_gemm_f16x3_planes_ws', (P0, P0, P0, P0, P0, 1, 64, 48, 256, P0, 1.0, P0, 0, P0), (P0, P0, P0, P0, P0, 0, 64, 64, 256, P0, 1.0, P0, 0, P0),
+     (P0, P0, P0, P0, P0, 1, 64, 64, 256, P0, 1.0, P0, 1, P0)),
+    ('mvip_gemm_f16x3_planes_ws', (P0, P0, P0, P0, P0, 1, 64, 64, 256, P0, 0.0, P0, 0, P0), None, None),      # out_scale must be > 0
+    ('mvip_gemm_geglu_f16x3_sink', (P0, P0, P0, P0, 1, 64, 96, 256, 256, P0, 1.0, 0, P0), (P0, P0, P0, P0, 0, 64, 128, 256, 256, P0, 1.0, 0, P0),
+     (P0, P0, P0, P0, 1, 64, 128, 256, 256, P0, 1.0, 0, P0)),
+    ('mvip_attention_f16x3_sink', (P0, P0, P0, P0, P0, P0, 1, 8, 40, 256, 256, 256, 256, 128, 256, 16, 0.158, 0, P0, 0, P0), None,
+     (P0, P0, P0, P0, P0, P0, 1, 8, 40, 256, 256, 256, 256, 256, 256, 16, 0.158, 0, P0, 0, P0)),                 # q_stride < Lq
+    ('mvip_im2col_split_planes', (P0, 1, 4, 16, 16, 3, 3, 0, 1, 1, 8, 8, 48, 64, P0, P0, 0, P0), None,
+     (P0, 1, 4, 16, 16, 3, 3, 2, 1, 1, 8, 8, 48, 64, P0, P0, 0, P0)),
     ('mvip_col2im', (P0, 1, 4, 16, 16, 3, 3, 2, 1, 1, 8, 8, 16, 64, P0, P0), (P0, 0, 4, 16, 16, 3, 3, 2, 1, 1, 8, 8, 48, 64, P0, P0),
      (P0, 1, 4, 16, 16, 3, 3, 2, 1, 1, 8, 8, 48, 64, P0, P0)),
-    ('mvip_layernorm_split_planes', (P0, P0, P0, 1, 100, 77, 256, 1e-5, 1.0, P0, P0, P0), (P0, P0, P0, 0, 320, 77, 256, 1e-5, 1.0, P0, P0, P0),
-     (P0, P0, P0, 1, 320, 77, 256, 1e-5, 1.0, P0, P0, P0)),
+    ('mvip_layernorm_split_planes', (P0, P0, P0, 1, 100, 77, 256, 1e-5, 1.0, P0, P0, 0, P0), (P0, P0, P0, 0, 320, 77, 256, 1e-5, 1.0, P0, P0, 0, P0),
+     (P0, P0, P0, 1, 320, 77, 256, 1e-5, 1.0, P0, P0, 1, P0)),
     # hash-grid model's small layers (row f4): at most 64 x 64, points in fours
     ('mvip_skinny_linear', (P0, 1, 1, P0, 65, 16, 128, 0, P0, P0), (P0, 1, 1, P0, 16, 16, 0, 0, P0, P0), (P0, 1, 1, P0, 16, 16, 128, 0, P0, P0)),
     ('mvip_skinny_linear', (P0, 1, 1, P0, 16, 16, 130, 0, P0, P0), None, None),

@@ -558,7 +558,7 @@ def test_conv3x3_with_and_without_workspace(cuda, N_, cin, cout, H, W):
     ca = torch.randn(N_, cout, generator=g).to(cuda)
     s2 = ops.absmax_scale(x)
     xs = ops._split_buffer(N_, cin, H * W, cuda)
-    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), stream())
+    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
     pk = ops._conv_packed(conv, False)
     bias = conv.bias.detach()
     nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N_, cin, cout, H, W))
@@ -566,10 +566,10 @@ def test_conv3x3_with_and_without_workspace(cuda, N_, cin, cout, H, W):
     ws = torch.empty(nbytes // 4, device=cuda)
     y0, y1, y2 = (torch.empty(N_, cout, H, W, device=cuda) for _ in range(3))
     call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_, cin, cout,
-         H, W, ptr(y0), stream())
+         H, W, ptr(y0), 0, stream())
     for y in (y1, y2):
         call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_,
-             cin, cout, H, W, ptr(y), ptr(ws), stream())
+             cin, cout, H, W, ptr(y), ptr(ws), 0, stream())
     ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + ca.double()[:, :, None, None] + rs.double()
     scale = float(ref.abs().max())
     np.testing.assert_allclose(N(y0), ref.float().cpu().numpy(), rtol=0, atol=1e-5 * scale)
@@ -577,17 +577,21 @@ def test_conv3x3_with_and_without_workspace(cuda, N_, cin, cout, H, W):
     assert torch.equal(y1, y2)
     with pytest.raises(Exception):                           # the library refuses a missing workspace where it needs one
         call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), ptr(ca), ptr(rs), ptr(s2), N_,
-             cin, cout, H, W, ptr(y1), ptr(None), stream())
+             cin, cout, H, W, ptr(y1), ptr(None), 0, stream())
 
 
-def test_sds_step_launches_no_library_contraction(cuda):
-    """One full-size train_step_sd (forward + backward to the image) under the profiler: no library convolution, GEMM,
+@pytest.mark.parametrize('fp16', [False, True])
+def test_sds_step_launches_no_library_contraction(cuda, fp16):
+    """(fp16 = True: the reference's --fp16 mode, DS_NeRF/guidance/sd_utils.py:66 -- the same hand-written kernels in their
+    single-product instantiations; it used to fall through every dtype gate onto MIOpen / CK / AOTriton.)
+    One full-size train_step_sd (forward + backward to the image) under the profiler: no library convolution, GEMM,
     attention or layout-transpose kernel is launched -- every contraction of the step is a kernel of this repository
     (MIOpen: `igemm`, `miopen`, `naive_conv`, `Im2d2Col`, `Col2Im`, `batched_transpose`; hipBLASLt / rocBLAS: `Cijk_`;
     AOTriton: `attn_fwd`)."""
     from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
     torch.manual_seed(0)
-    sd = StableDiffusion(cuda, False, False)
+    sd = StableDiffusion(cuda, fp16, False)
+    assert sd.unet.mfma_prec == int(fp16) and sd.vae.mfma_prec == int(fp16)
     gen = torch.Generator(device=cuda).manual_seed(3)
     pred = torch.rand(1, 3, 378, 504, device=cuda, generator=gen).requires_grad_(True)
     mask = torch.zeros(1, 1, 378, 504, device=cuda)
@@ -602,11 +606,20 @@ def test_sds_step_launches_no_library_contraction(cuda):
         torch.cuda.synchronize()
     assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
     names = [e.key for e in prof.key_averages()]
-    banned = ('igemm', 'miopen', 'naive_conv', 'Im2d2Col', 'Col2Im', 'batched_transpose', 'Cijk_', 'attn_fwd')
+    banned = ('igemm', 'miopen', 'naive_conv', 'Im2d2Col', 'Col2Im', 'batched_transpose', 'Cijk_', 'attn_fwd', 'ck::',
+              'grouped_conv', 'MIOpen', 'gemm_kernel', 'softmax_warp')
     assert not [n for n in names if any(b in n for b in banned)], [n for n in names if any(b in n for b in banned)]
     for must in ('conv3x3_f16x3_kernel', 'gemm5_f16x3_kernel', 'attn_f16x3_kernel', 'cv_im2col_split_kernel',
                  'resize_bilinear_fwd_kernel', 'resize_bilinear_bwd_kernel'):
         assert any(must in n for n in names), must
+    # the template flag of the single-product instantiations shows in the kernel names: <..., true> in fp16 mode only
+    single = [n for n in names if ('conv3x3_f16x3_kernel' in n or 'gemm5_f16x3_kernel' in n or 'attn_f16x3_kernel' in n)
+              and n.split('(')[0].rstrip('>').endswith('true')]
+    assert bool(single) == fp16, single
+    if fp16:
+        triple = [n for n in names if ('conv3x3_f16x3_kernel' in n or 'gemm5_f16x3_kernel' in n or 'attn_f16x3_kernel' in n)
+                  and not n.split('(')[0].rstrip('>').endswith('true')]
+        assert not triple, triple
 
 
 def test_plain_conv3x3_on_mfma_kernel(cuda):
@@ -631,3 +644,64 @@ def test_plain_conv3x3_on_mfma_kernel(cuda):
     # with autograd enabled on a grad-carrying input the module takes a differentiable path (ops.conv_gemm)
     xg = torch.randn(1, 64, 8, 16, device=cuda, requires_grad=True)
     assert up(xg).requires_grad
+
+
+def test_fp16_mode_kernels_vs_fp64(cuda):
+    """ops.precision(1) -- the reference's --fp16 arithmetic on the hand-written kernels: ONE fp16 product per step, fp32
+    accumulate, hi planes only -- against fp64 at fp16 tolerance (2e-3 of the output scale), forward and data gradient of
+    the GroupNorm + SiLU + 3x3 convolution, the GEMM (incl. split-K) and the im2col convolution; and it really IS the
+    single-product path (error well above the split-precision kernels' 1e-5)."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm, norm_act_conv
+    gen = torch.Generator().manual_seed(12)
+    for N_, cin, cout, H, W in ((1, 128, 128, 32, 32), (2, 320, 64, 8, 8), (2, 640, 64, 16, 16), (1, 64, 64, 8, 64)):
+        norm = GroupNorm(32, cin, eps=1e-6)
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_((torch.randn(conv.weight.shape, generator=gen) * (2.0 / (9 * cin)) ** 0.5).half().float())
+        for p in list(norm.parameters()) + list(conv.parameters()):
+            p.requires_grad_(False)
+        x = torch.randn(N_, cin, H, W, generator=gen) * 1.3 + 0.2
+        dy = torch.randn(N_, cout, H, W, generator=gen) * 1e-5
+        xr = x.double().requires_grad_(True)
+        h = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 32, norm.weight.double(), norm.bias.double(), 1e-6))
+        yr = torch.nn.functional.conv2d(h, conv.weight.double(), conv.bias.double(), padding=1)
+        yr.backward(dy.double())
+        norm_d, conv_d = norm.to(cuda), conv.to(cuda)
+        xd = x.to(cuda).requires_grad_(True)
+        with ops.precision(1):
+            y = norm_act_conv(norm_d, conv_d, xd)
+        y.backward(dy.to(cuda))                                  # outside the context: the Function remembers its arithmetic
+        e_f = float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.abs().max())
+        e_b = float((xd.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max())
+        assert 2e-5 < e_f < 2e-3 and e_b < 2e-3, (cin, cout, H, W, e_f, e_b)
+    # GEMM, also split over K
+    for M, K, P in ((96, 64, 512), (160, 1376, 256)):
+        A = (torch.randn(M, K, generator=gen) * 0.05).half().float()
+        X = torch.randn(2, K, P, generator=gen)
+        bias, res = torch.randn(M, generator=gen), torch.randn(2, M, P, generator=gen)
+        ref = torch.einsum('mk,nkp->nmp', A.double(), X.double()) + bias.double()[None, :, None] + res.double()
+        Xd = X.to(cuda)
+        with ops.precision(1):
+            s2 = ops.absmax_scale(Xd)
+            xs = ops.split_planes_strided(Xd, 2, K, P, K * P, P, 1, s2)
+            y = ops.gemm_f16x3(xs, ops.gemm_pack_a(A.to(cuda), M, K, K, 1), 2, K, M, P, bias=bias.to(cuda), residual=res.to(cuda),
+                               x_scale2=s2)
+        err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert 2e-6 < err < 2e-3, (M, K, P, err)
+    # stride-2 convolution through im2col planes + GEMM, forward and data gradient
+    conv = torch.nn.Conv2d(128, 128, 3, stride=2, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.half().float())
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(1, 128, 32, 32, generator=gen)
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, conv.weight.double(), conv.bias.double(), stride=2, padding=1)
+    yr.sum().backward()
+    xd = x.to(cuda).requires_grad_(True)
+    with ops.precision(1):
+        y = ops.conv_gemm(xd, conv.to(cuda))
+    y.sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.abs().max()) < 2e-3
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()) < 2e-3

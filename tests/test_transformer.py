@@ -412,3 +412,41 @@ def test_gemm_random_shapes_vs_fp64(cuda):
                            residual=None if res is None else res.to(cuda), x_scale2=s2)
         np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=4e-6 * float(ref.abs().max()),
                                    err_msg=f'case {case}: N={Nb} M={M} K={K} P={P}')
+
+
+@pytest.mark.parametrize('C,heads,H,W', [(320, 8, 16, 16), (1280, 8, 8, 8)])
+def test_transformer2d_fp16_mode_vs_fp64(cuda, C, heads, H, W):
+    """The whole Transformer2DModel in the single-product arithmetic (ops.precision(1): the reference's --fp16 mode on the
+    hand-written kernels) vs the fp64 module: fp16-grade (5e-3 of the output scale through eleven chained contractions and
+    two softmaxes), and measurably not the split-precision result."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance import sd_nets, transformer_cm
+    torch.manual_seed(C + H)
+    mod = sd_nets.Transformer2DModel(C, heads, 768).eval()
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(p.half().float())
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, C, H, W) * 1.5
+    ctx = torch.randn(2, 77, 768)
+    with torch.no_grad():
+        ref = mod.double()(x.double(), ctx.double())
+    mod = mod.float().to(cuda)
+    with torch.no_grad():
+        full = mod(x.to(cuda), ctx.to(cuda))
+        mod.__dict__.pop('_mvip_cm', None)                     # the prompt planes are cached per arithmetic
+        with ops.precision(1):
+            got = mod(x.to(cuda), ctx.to(cuda))
+    scale = float(ref.abs().max())
+    e16 = float((got.cpu().double() - ref).abs().max()) / scale
+    e32 = float((full.cpu().double() - ref).abs().max()) / scale
+    assert e32 < 1e-5 and 1e-5 < e16 < 5e-3, (e32, e16)
+
+
+@pytest.mark.parametrize('heads,D,Lq,Lk', [(8, 40, 256, 256), (8, 80, 256, 256), (8, 160, 64, 77), (8, 40, 4096, 4096)])
+def test_attention_fp16_mode_vs_fp64(cuda, heads, D, Lq, Lk):
+    from mvip_nerf_amd import ops
+    with ops.precision(1):
+        err, got, ref = _attention_case(cuda, 2, heads, D, Lq, Lk, None, seed=5)
+    assert 1e-5 < err < 2e-3, err

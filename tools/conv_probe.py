@@ -12,7 +12,7 @@ for (N, cin, cout, H, W) in [(1, 128, 128, 512, 512), (1, 512, 512, 128, 128), (
     rs = torch.randn(N, cout, H, W, device=dev)
     s2 = ops.absmax_scale(x)
     xs = ops._split_buffer(N, cin, H * W, dev)
-    call('mvip_split_planes', ptr(x), N, cin, H * W, ptr(s2), ptr(xs, torch.float16), stream())
+    call('mvip_split_planes', ptr(x), N, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
     y = torch.empty(N, cout, H, W, device=dev)
     pk = ops._conv_packed(conv, False)
     bias = conv.bias.detach()

@@ -7,7 +7,7 @@ N, cin, cout, H, W = 1, 512, 512, 128, 128
 conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
 x = torch.randn(N, cin, H, W, device=dev); rs = torch.randn(N, cout, H, W, device=dev)
 s2 = ops.absmax_scale(x); xs = ops._split_buffer(N, cin, H * W, dev)
-call('mvip_split_planes', ptr(x), N, cin, H * W, ptr(s2), ptr(xs, torch.float16), stream())
+call('mvip_split_planes', ptr(x), N, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
 y = torch.empty(N, cout, H, W, device=dev); pk = ops._conv_packed(conv, False); bias = conv.bias.detach()
 for _ in range(3): ops._conv3x3_launch(xs, pk, bias, None, rs, s2, N, cin, cout, H, W, y)
 torch.cuda.synchronize()
