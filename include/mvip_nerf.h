@@ -432,6 +432,11 @@ int mvip_geglu(const float *y, int64_t N, int64_t R, int64_t L, int64_t LP, floa
  * the ResNet blocks' time projections (published SD-1.5 UNet), exact fp32, one wavefront per output feature. */
 int mvip_linear_small(const float *x, const float *W, const float *b, int64_t NB, int64_t M, int64_t K, int act_in,
                       float *y, void *stream);
+/* The same for several layers sharing the input x (the UNet's 22 ResNet time projections all read silu(temb)): W [M][K]
+ * and b [M] hold the layers' rows one after the other, layer_off (n_layers + 1 device ints) their first rows, and layer
+ * l's result is its own contiguous [NB][C_l] block at y + layer_off[l] * NB. */
+int mvip_linear_small_grouped(const float *x, const float *W, const float *b, int64_t NB, int64_t M, int64_t K, int act_in,
+                              const int *layer_off, int64_t n_layers, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * encodings of the reference's second model NeRF_TCNN

@@ -114,6 +114,7 @@ _SIGNATURES = {
     'mvip_layernorm_split_planes': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _c_f, _int, _c_f]),
     'mvip_geglu': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _c_f]),
     'mvip_linear_small': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _c_f, _c_f]),
+    'mvip_linear_small_grouped': (_int, [_c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _c_f, _i64, _c_f, _c_f]),
     'mvip_groupnorm_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _int, _c_f, _c_f,
                                        _c_f]),
 }

@@ -181,6 +181,41 @@ linear_small_kernel(const float *__restrict__ x, const float *__restrict__ W, co
     }
 }
 
+// The same product for SEVERAL layers that share the input (the 22 ResNet time projections of the UNet all read
+// silu(temb)): W / b are the layers' rows one after the other, `off` the layers' first rows (nl + 1 entries, device), and
+// layer l's result is written as its own contiguous [NB][C_l] block at y + off[l] * NB.  One launch instead of 22.
+template <int NB>
+__global__ void __launch_bounds__(256)
+linear_small_grouped_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ b, int64_t M, int K,
+                            int act_in, const int *__restrict__ off, int nl, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float *w = W + m * K;
+    float acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[k];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float xv = x[(int64_t)i * K + k];
+            if (act_in == 1) xv = xv / (1.0f + expf(-xv));
+            acc[i] = fmaf(wv, xv, acc[i]);
+        }
+    }
+    int l = 0;
+    while (l + 1 < nl && m >= off[l + 1]) ++l;                  // <= 32 layers: a linear walk over scalar loads
+    const int64_t o0 = off[l], cl = off[l + 1] - o0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) y[o0 * NB + (int64_t)i * cl + (m - o0)] = v + (b ? b[m] : 0.f);
+    }
+}
+
 }  // namespace tok
 }  // namespace mvip
 
@@ -228,6 +263,20 @@ extern "C" int mvip_linear_small(const float *x, const float *W, const float *b,
     hipStream_t st = as_stream(stream);
     switch (NB) {
 #define MVIP_LS(n) case n: hipLaunchKernelGGL((linear_small_kernel<n>), grid, dim3(256), 0, st, x, W, b, M, (int)K, act_in, y); break;
+        MVIP_LS(1) MVIP_LS(2) MVIP_LS(3) MVIP_LS(4) MVIP_LS(5) MVIP_LS(6) MVIP_LS(7) MVIP_LS(8)
+#undef MVIP_LS
+    }
+    return check_launch();
+}
+
+extern "C" int mvip_linear_small_grouped(const float *x, const float *W, const float *b, int64_t NB, int64_t M, int64_t K,
+                                         int act_in, const int *layer_off, int64_t n_layers, float *y, void *stream) {
+    if (NB <= 0 || NB > 8 || M <= 0 || K <= 0 || K > 0x7fffffff || n_layers <= 0 || n_layers > 64 || !x || !W || !y || !layer_off)
+        return MVIP_EINVAL;
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = as_stream(stream);
+    switch (NB) {
+#define MVIP_LS(n) case n: hipLaunchKernelGGL((linear_small_grouped_kernel<n>), grid, dim3(256), 0, st, x, W, b, M, (int)K, act_in, layer_off, (int)n_layers, y); break;
         MVIP_LS(1) MVIP_LS(2) MVIP_LS(3) MVIP_LS(4) MVIP_LS(5) MVIP_LS(6) MVIP_LS(7) MVIP_LS(8)
 #undef MVIP_LS
     }

@@ -80,9 +80,13 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
+    _t_ready = None        # set by UNet2DConditionModel for one forward: this block's time projection, already computed
+
     def forward(self, x, temb=None):
         if self.time_emb_proj is None:
             t = None
+        elif self._t_ready is not None:
+            t, self._t_ready = self._t_ready, None
         elif (USE_HIP_TIME_LINEARS and temb.is_cuda and temb.dtype == torch.float32 and temb.shape[0] <= 8
               and not (torch.is_grad_enabled() and temb.requires_grad)):
             from .. import ops
@@ -313,9 +317,31 @@ class UNet2DConditionModel(nn.Module):
                 return self._forward(sample.to(self.conv_in.weight.dtype), timestep, encoder_hidden_states)
         return self._forward(sample, timestep, encoder_hidden_states)
 
+    def _time_projections(self, temb):
+        """All 22 ResNet blocks project the SAME silu(temb): one grouped launch (ops.linear_small_grouped) whose per-block
+        results are handed to the blocks, instead of 22 launches of a few microseconds of work each."""
+        if not (USE_HIP_TIME_LINEARS and temb.is_cuda and temb.dtype == torch.float32 and temb.shape[0] <= 8
+                and not (torch.is_grad_enabled() and temb.requires_grad)):
+            return
+        from .. import ops
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        key = tuple((m.time_emb_proj.weight.data_ptr(), m.time_emb_proj.weight._version, m.time_emb_proj.bias._version)
+                    for m in blocks)
+        cache = self.__dict__.get('_tcat')
+        if cache is None or cache[0] != key:
+            sizes = [m.time_emb_proj.out_features for m in blocks]
+            offs = torch.tensor([sum(sizes[:k]) for k in range(len(sizes) + 1)], dtype=torch.int32, device=temb.device)
+            cache = (key, torch.cat([m.time_emb_proj.weight.detach() for m in blocks], 0).contiguous(),
+                     torch.cat([m.time_emb_proj.bias.detach() for m in blocks], 0).contiguous(), offs, sizes)
+            self.__dict__['_tcat'] = cache
+        outs = ops.linear_small_grouped(temb, cache[1], cache[2], cache[3], cache[4], act_in=1)
+        for m, o in zip(blocks, outs):
+            m._t_ready = o
+
     def _forward(self, sample, timestep, encoder_hidden_states):
         t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
         temb = self.time_embedding(timestep_sinusoid(t, self._t_dim).to(sample.dtype))
+        self._time_projections(temb)
         x = conv_any(self.conv_in, sample)
         skips = [x]
         for blk in self.down_blocks:

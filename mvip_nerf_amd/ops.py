@@ -1370,3 +1370,19 @@ def gemm_f16x3_planes(xs, packed, N, K, M, P, out_scale, bias=None, residual=Non
     call('mvip_gemm_f16x3_planes_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(residual), ptr(x_scale2),
          int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), _prec(), stream())
     return out
+
+
+def linear_small_grouped(x, Wcat, bcat, offsets_dev, sizes, act_in=0):
+    """act(x) @ W_l^T + b_l for several layers sharing x [NB <= 8, K] in ONE launch; returns one contiguous [NB, C_l]
+    tensor per layer (views of one buffer).  Wcat [sum C_l, K], offsets_dev int32 [L + 1] on the device."""
+    xc = _f32c(x)
+    NB, K = xc.shape
+    M = Wcat.shape[0]
+    y = torch.empty(NB * M, device=xc.device, dtype=_F32)
+    call('mvip_linear_small_grouped', ptr(xc), ptr(Wcat), ptr(bcat), NB, M, K, int(act_in), ptr(offsets_dev, torch.int32),
+         len(sizes), ptr(y), stream())
+    out, o = [], 0
+    for c in sizes:
+        out.append(y[o * NB:(o + c) * NB].view(NB, c))
+        o += c
+    return out

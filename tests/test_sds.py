@@ -592,6 +592,8 @@ def test_sds_step_launches_no_library_contraction(cuda, fp16):
     torch.manual_seed(0)
     sd = StableDiffusion(cuda, fp16, False)
     assert sd.unet.mfma_prec == int(fp16) and sd.vae.mfma_prec == int(fp16)
+    assert sd.use_graphs is True               # the built-in networks replay a captured hipGraph by default ...
+    sd.use_graphs = False                      # ... this test wants to see the launches one by one
     gen = torch.Generator(device=cuda).manual_seed(3)
     pred = torch.rand(1, 3, 378, 504, device=cuda, generator=gen).requires_grad_(True)
     mask = torch.zeros(1, 1, 378, 504, device=cuda)

@@ -13,7 +13,10 @@ from mvip_nerf_amd.guidance.sd_utils import StableDiffusion          # noqa: E40
 
 def main():
     dev = torch.device('cuda', 0)
-    sd = StableDiffusion(dev, False, False)
+    fp16 = '--fp16' in sys.argv            # the reference's --fp16 mode on the single-product kernels
+    graphs = '--graphs' in sys.argv        # also time the captured-hipGraph replay of the same step
+    out_name = next((a.split('=', 1)[1] for a in sys.argv if a.startswith('--out=')), 'sds_step_profile.json')
+    sd = StableDiffusion(dev, fp16, False)
     g = torch.Generator(device=dev).manual_seed(2)
     H, W = 378, 504
     pred = torch.rand(1, 3, H, W, device=dev, generator=g).requires_grad_(True)
@@ -46,9 +49,24 @@ def main():
         rows.append([round(e.device_time_total / 1e3, 3), e.count, e.key[:120]])
     own = sum(e.device_time_total for e in ev if 'mvip::' in e.key) / 1e3
     print(f'   hand-written (mvip::) kernels: {own:.2f} ms of {total:.2f} ms device-busy')
+    graph_ms = None
+    if graphs:
+        sd.use_graphs = True
+        for k in range(3):
+            step(2000 + k)
+        torch.cuda.synchronize()
+        tg = []
+        for k in range(9):
+            t0 = time.perf_counter()
+            step(2010 + k)
+            torch.cuda.synchronize()
+            tg.append((time.perf_counter() - t0) * 1e3)
+        graph_ms = sorted(tg)[len(tg) // 2]
+        print(f'   hipGraph replay of the same step: median {graph_ms:.2f} ms {[round(t, 1) for t in tg]}')
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump({'median_wall_ms': sorted(ts)[len(ts) // 2], 'wall_ms': ts, 'device_busy_ms': total, 'kernels': n,
-               'mvip_kernels_ms': own, 'top': rows}, open('gpurun_out/sds_step_profile.json', 'w'), indent=1)
+    json.dump({'fp16_mode': fp16, 'median_wall_ms': sorted(ts)[len(ts) // 2], 'wall_ms': ts, 'hipgraph_replay_ms': graph_ms,
+               'device_busy_ms': total, 'kernels': n, 'mvip_kernels_ms': own, 'top': rows},
+              open(os.path.join('gpurun_out', out_name), 'w'), indent=1)
 
 
 if __name__ == '__main__':
