@@ -116,6 +116,26 @@ int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const floa
 int mvip_mlp_forward_points16(const float *packed16, const float *pts, const float *dirs, int64_t P,
                               float *raw, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a10 (row g)  render_rays as TWO launches per chunk (DS_NeRF/run.py:1703-1847), no-grad renders of the native 8x256
+ * networks with 64 coarse + <= 64 fine samples: the same device functions as the stand-alone entry points, fused behind
+ * the network so that no raw / weights / depth tensor of the coarse pass and no z tensor of its samples ever exists.
+ * Every output is BIT-IDENTICAL to the unfused chain (tests/test_render.py).
+ * mvip_render_coarse_fused: rows [B,11] -> stratified depths (t_vals [64] = linspace(0,1,64); t_rand [B,64] or NULL) ->
+ *   coarse network (packed16 of mvip_mlp_pack16) -> raw2outputs (noise [B,64] or NULL; flags MVIP_COMP_*) ->
+ *   inverse-CDF resampling with Nf <= 64 uniforms (u [B,Nf], or one row of Nf when u_is_row) -> sort(cat[z, z_samples]).
+ *   Outputs rgb0 [B,3], disp0 [B], acc0 [B], z_merged [B,64+Nf], z_std [B]; depth0 [B], weights0 [B,64], alpha0 [B,64]
+ *   optional (NULL = not wanted).
+ * mvip_render_fine_fused: network at the 128 depths z [B,128] -> raw2outputs; outputs as mvip_composite_forward plus
+ *   raw [B,128,4] (NULL = not wanted), alpha optional. */
+int mvip_render_coarse_fused(const float *packed16, const float *rows, int64_t B, const float *t_vals, int lindisp,
+                             const float *t_rand, const float *noise, const float *u, int u_is_row, int Nf, int flags,
+                             float *rgb0, float *disp0, float *acc0, float *depth0, float *weights0, float *alpha0,
+                             float *z_merged, float *z_std, void *stream);
+int mvip_render_fine_fused(const float *packed16, const float *rows, const float *z, int64_t B, const float *noise,
+                           int flags, float *raw, float *rgb, float *disp, float *acc, float *depth, float *weights,
+                           float *alpha, void *stream);
+
 /* Backward: d_raw [P,4] -> the 24 parameter gradients.  grads_host is a HOST array of 24 device
  * pointers (state-dict order, natural [out][in] shapes) that are ACCUMULATED into with fp32
  * atomics (zero them, or pass .grad buffers).  Inputs are re-encoded and activations recomputed

@@ -37,6 +37,9 @@ _SIGNATURES = {
     'mvip_mlp_forward_rays16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
     'mvip_mlp_forward_rays_stash16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_points16': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
+    'mvip_render_coarse_fused': (_int, [_c_f, _c_f, _i64, _c_f, _int, _c_f, _c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f,
+                                        _c_f, _c_f, _c_f, _c_f, _c_f]),
+    'mvip_render_fine_fused': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     'mvip_mlp_backward_workspace_bytes': (_i64, [_i64]),
     'mvip_mlp_backward_rays': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, ctypes.POINTER(ctypes.c_void_p), _c_f, _i64,
                                       _int, _c_f]),

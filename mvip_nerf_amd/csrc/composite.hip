@@ -4,78 +4,9 @@
 // ray are read as one contiguous 16*S-byte run (16 B per lane per item) and the transmittance
 // cumprod / suffix sums are wave-level scans on shuffles: no LDS, no atomics.  HBM-bound:
 // forward reads 16+4(+4) B and writes 4(+4) B per sample (+24 B per ray).
-#include "common.h"
+#include "composite_device.h"
 
 namespace mvip {
-
-template <int ITEMS>
-struct RayState {
-    float z[ITEMS], dist[ITEMS], sig[ITEMS], e[ITEMS], alpha[ITEMS], t[ITEMS], T[ITEMS], w[ITEMS];
-    float c[ITEMS][3];
-    bool valid[ITEMS];
-};
-
-// Recomputes everything the forward defines for one ray.  Returns (acc, depth, rgb sums).
-template <int ITEMS>
-__device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const float *__restrict__ z,
-                                            const float *__restrict__ noise, float dnorm, int S,
-                                            RayState<ITEMS> &st, float sums[5]) {
-    const int l = lane_id();
-    float zfirst_next;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int s = l * ITEMS + i;
-        st.valid[i] = s < S;
-        st.z[i] = st.valid[i] ? z[s] : 0.f;
-    }
-    zfirst_next = __shfl_down(st.z[0], 1, 64);
-    float lane_prod = 1.f;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int s = l * ITEMS + i;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        float nz = 0.f;
-        if (st.valid[i]) {
-            r = reinterpret_cast<const float4 *>(raw)[s];
-            if (noise) nz = noise[s];
-        }
-        const float znext = (i + 1 < ITEMS) ? st.z[(i + 1) % ITEMS] : zfirst_next;
-        float d = (s == S - 1) ? 1e10f : (znext - st.z[i]);
-        d = d * dnorm;
-        const float pre = r.w + nz;
-        const float sg = pre > 0.f ? pre : 0.f;                 // relu
-        const float ee = st.valid[i] ? expf(-sg * d) : 1.f;
-        const float a = 1.f - ee;                               // raw2alpha
-        st.dist[i] = d; st.sig[i] = pre; st.e[i] = ee; st.alpha[i] = a;
-        st.t[i] = (1.f - a) + 1e-10f;
-        st.c[i][0] = 1.f / (1.f + expf(-r.x));                  // sigmoid
-        st.c[i][1] = 1.f / (1.f + expf(-r.y));
-        st.c[i][2] = 1.f / (1.f + expf(-r.z));
-        st.T[i] = lane_prod;                                    // exclusive product inside the lane
-        lane_prod *= st.t[i];
-    }
-    float incl = wave_incl_prod(lane_prod);
-    float excl = __shfl_up(incl, 1, 64);
-    if (l == 0) excl = 1.f;
-    float a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        st.T[i] *= excl;
-        st.w[i] = st.valid[i] ? st.alpha[i] * st.T[i] : 0.f;
-        a_sum += st.w[i];
-        d_sum += st.w[i] * st.z[i];
-        c0 += st.w[i] * st.c[i][0];
-        c1 += st.w[i] * st.c[i][1];
-        c2 += st.w[i] * st.c[i][2];
-    }
-    sums[0] = wave_sum(a_sum); sums[1] = wave_sum(d_sum);
-    sums[2] = wave_sum(c0); sums[3] = wave_sum(c1); sums[4] = wave_sum(c2);
-}
-
-__device__ __forceinline__ float dir_norm(const float *__restrict__ row) {
-    const float x = row[3], y = row[4], zc = row[5];
-    return sqrtf((x * x + y * y) + zc * zc);
-}
 
 template <int ITEMS>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
@@ -90,26 +21,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float sums[5];
     ray_forward<ITEMS>(raw + ray * S * 4, z + ray * S, noise ? noise + ray * S : nullptr,
                        dir_norm(rows + ray * ncols), S, st, sums);
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int s = l * ITEMS + i;
-        if (st.valid[i]) {
-            weights[ray * S + s] = st.w[i];
-            if (alpha) alpha[ray * S + s] = st.alpha[i];
-        }
-    }
-    if (l == 0) {
-        const float a = sums[0], d = sums[1];
-        const float q = d / a;
-        const float m = (q != q) ? q : fmaxf(1e-10f, q);        // torch.max propagates NaN (0/0 rays)
-        const float white = (flags & MVIP_COMP_WHITE) ? (1.f - a) : 0.f;
-        rgb[ray * 3 + 0] = sums[2] + white;
-        rgb[ray * 3 + 1] = sums[3] + white;
-        rgb[ray * 3 + 2] = sums[4] + white;
-        disp[ray] = 1.f / m;
-        acc[ray] = a;
-        depth[ray] = d;
-    }
+    composite_store<ITEMS>(st, sums, ray, S, flags, rgb, disp, acc, depth, weights, alpha);
 }
 
 template <int ITEMS>

@@ -1,0 +1,111 @@
+// Device side of raw2outputs (DS_NeRF/run_nerf_helpers.py:350-404), shared by csrc/composite.hip (stand-alone launches,
+// forward and backward) and the fused render kernels of csrc/mlp_fwd16.hip: one 64-lane wavefront per ray, ITEMS
+// consecutive samples per lane, the transmittance cumprod / suffix sums as wave-level scans on shuffles.
+#pragma once
+#include "common.h"
+
+namespace mvip {
+
+template <int ITEMS>
+struct RayState {
+    float z[ITEMS], dist[ITEMS], sig[ITEMS], e[ITEMS], alpha[ITEMS], t[ITEMS], T[ITEMS], w[ITEMS];
+    float c[ITEMS][3];
+    bool valid[ITEMS];
+};
+
+// Recomputes everything the forward defines for one ray.  Returns (acc, depth, rgb sums).
+// z == nullptr: the caller has already put the ray's depths into st.z (a fused kernel that computed them itself).
+template <int ITEMS>
+__device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const float *__restrict__ z,
+                                            const float *__restrict__ noise, float dnorm, int S,
+                                            RayState<ITEMS> &st, float sums[5]) {
+    const int l = lane_id();
+    float zfirst_next;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int s = l * ITEMS + i;
+        st.valid[i] = s < S;
+        if (z) st.z[i] = st.valid[i] ? z[s] : 0.f;
+        else if (!st.valid[i]) st.z[i] = 0.f;
+    }
+    zfirst_next = __shfl_down(st.z[0], 1, 64);
+    float lane_prod = 1.f;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int s = l * ITEMS + i;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        float nz = 0.f;
+        if (st.valid[i]) {
+            r = reinterpret_cast<const float4 *>(raw)[s];
+            if (noise) nz = noise[s];
+        }
+        const float znext = (i + 1 < ITEMS) ? st.z[(i + 1) % ITEMS] : zfirst_next;
+        float d = (s == S - 1) ? 1e10f : (znext - st.z[i]);
+        d = d * dnorm;
+        const float pre = r.w + nz;
+        const float sg = pre > 0.f ? pre : 0.f;                 // relu
+        const float ee = st.valid[i] ? expf(-sg * d) : 1.f;
+        const float a = 1.f - ee;                               // raw2alpha
+        st.dist[i] = d; st.sig[i] = pre; st.e[i] = ee; st.alpha[i] = a;
+        st.t[i] = (1.f - a) + 1e-10f;
+        st.c[i][0] = 1.f / (1.f + expf(-r.x));                  // sigmoid
+        st.c[i][1] = 1.f / (1.f + expf(-r.y));
+        st.c[i][2] = 1.f / (1.f + expf(-r.z));
+        st.T[i] = lane_prod;                                    // exclusive product inside the lane
+        lane_prod *= st.t[i];
+    }
+    float incl = wave_incl_prod(lane_prod);
+    float excl = __shfl_up(incl, 1, 64);
+    if (l == 0) excl = 1.f;
+    float a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        st.T[i] *= excl;
+        st.w[i] = st.valid[i] ? st.alpha[i] * st.T[i] : 0.f;
+        a_sum += st.w[i];
+        d_sum += st.w[i] * st.z[i];
+        c0 += st.w[i] * st.c[i][0];
+        c1 += st.w[i] * st.c[i][1];
+        c2 += st.w[i] * st.c[i][2];
+    }
+    sums[0] = wave_sum(a_sum); sums[1] = wave_sum(d_sum);
+    sums[2] = wave_sum(c0); sums[3] = wave_sum(c1); sums[4] = wave_sum(c2);
+}
+
+__device__ __forceinline__ float dir_norm(const float *__restrict__ row) {
+    const float x = row[3], y = row[4], zc = row[5];
+    return sqrtf((x * x + y * y) + zc * zc);
+}
+
+
+// The forward's outputs of one ray from the state ray_forward left (lane 0 writes the per-ray values): what
+// composite_fwd_kernel writes, as a function so that a fused kernel produces the same bits.
+template <int ITEMS>
+__device__ __forceinline__ void composite_store(const RayState<ITEMS> &st, const float sums[5], int64_t ray, int S, int flags,
+                                                float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc,
+                                                float *__restrict__ depth, float *__restrict__ weights,
+                                                float *__restrict__ alpha) {
+    const int l = lane_id();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int s = l * ITEMS + i;
+        if (st.valid[i]) {
+            if (weights) weights[ray * S + s] = st.w[i];
+            if (alpha) alpha[ray * S + s] = st.alpha[i];
+        }
+    }
+    if (l == 0) {
+        const float a = sums[0], d = sums[1];
+        const float q = d / a;
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);        // torch.max propagates NaN (0/0 rays)
+        const float white = (flags & MVIP_COMP_WHITE) ? (1.f - a) : 0.f;
+        rgb[ray * 3 + 0] = sums[2] + white;
+        rgb[ray * 3 + 1] = sums[3] + white;
+        rgb[ray * 3 + 2] = sums[4] + white;
+        disp[ray] = 1.f / m;
+        acc[ray] = a;
+        if (depth) depth[ray] = d;
+    }
+}
+
+}  // namespace mvip

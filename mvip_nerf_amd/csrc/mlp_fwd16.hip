@@ -20,6 +20,9 @@
 // ([row tile of 32 units][point tile of 32][32][32] fp32, mlp_device.h) -- a wave's 16 x 16 tile is four stores of four
 // 64-byte row segments, the two waves that share a point tile filling the other half of each 128-byte row.
 #include "mlp_device16.h"
+#include "rays_device.h"
+#include "composite_device.h"
+#include "sample_pdf_device.h"
 
 namespace mvip {
 using namespace mlp;
@@ -41,11 +44,28 @@ __device__ __forceinline__ float enc_channel(float x, float y, float z, int c) {
     return val;
 }
 
-template <bool FROM_RAYS, bool STASH = false>
+// FUSE (rays form only; DS_NeRF/run.py:1703-1847 render_rays as TWO launches per chunk instead of six):
+//   1  the COARSE pass: 64 samples per ray, a workgroup = two rays.  The depths are computed here (stratified_point, no z
+//      tensor), and after the network the first wave of each ray composites its 64 samples (raw2outputs) from the
+//      workgroup's raw values in LDS, draws the fine samples by inverse CDF from the weights still in its registers and
+//      writes the merged 128 depths: rgb0 / disp0 / acc0 (/ alpha0), z_std, z_merged -- no raw, weights or depth tensor of
+//      the coarse pass ever exists;
+//   2  the FINE pass: 128 samples per ray, a workgroup = one ray; wave 0 composites after the network.
+// Both run the same device functions as the stand-alone kernels (composite_device.h, sample_pdf_device.h,
+// rays_device.h), so every output is bit-identical to the unfused path.
+struct FuseArgs {
+    const float *t_vals, *t_rand, *noise, *u;
+    int u_is_row, lindisp, flags, Nf;
+    float *rgb, *disp, *acc, *depth, *weights, *alpha, *z_merged, *z_std;
+};
+
+template <bool FROM_RAYS, bool STASH = false, int FUSE = 0>
 __global__ void __launch_bounds__(512, 2)
 mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__ in_a, const float *__restrict__ in_b,
-                     int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash = nullptr, int64_t n_pt = 0) {
+                     int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash = nullptr, int64_t n_pt = 0,
+                     const FuseArgs fa = FuseArgs{}) {
     __shared__ __attribute__((aligned(16))) float lds[LDS16_FLOATS];
+    __shared__ __attribute__((aligned(16))) float raw_s[FUSE ? WG_POINTS * 4 : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -63,7 +83,10 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     if constexpr (FROM_RAYS) {
         const int64_t ray = p / S;
         const float *row = in_a + ray * 11;
-        const float zz = in_b[p];
+        float zz;
+        if constexpr (FUSE == 1) zz = stratified_point(row[6], row[7], fa.t_vals, (int)(p - ray * S), S, fa.lindisp,
+                                                        fa.t_rand ? fa.t_rand + p : nullptr);
+        else zz = in_b[p];
         px = row[0] + row[3] * zz; py = row[1] + row[4] * zz; pz = row[2] + row[5] * zz;
         vx = row[8]; vy = row[9]; vz = row[10];
     } else {
@@ -164,8 +187,38 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
         });
     r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
     r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
-    if (live && g == 0)
-        reinterpret_cast<float4 *>(raw)[p] = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
+    const float4 out4 = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
+    if (live && g == 0 && raw) reinterpret_cast<float4 *>(raw)[p] = out4;
+    if constexpr (FUSE != 0) {
+        // ---- the rest of the pass, by the first wave of each ray, from the workgroup's raw values in LDS ----
+        if (g == 0) reinterpret_cast<float4 *>(raw_s)[wave * 16 + n] = out4;
+        __syncthreads();
+        constexpr int RAYS = FUSE == 1 ? 2 : 1, WPR = 8 / RAYS, SR = WG_POINTS / RAYS;      // rays, waves and samples per ray
+        if (wave % WPR != 0) return;
+        const int64_t ray = (int64_t)blockIdx.x * RAYS + wave / WPR;
+        if (ray * SR >= P) return;
+        const float *row = in_a + ray * 11;
+        constexpr int IT = SR / 64;
+        RayState<IT> stt;
+        float sums[5];
+        if constexpr (FUSE == 1) {
+            // this lane's sample = lane: the same expression the network's prologue evaluated for the point
+            stt.z[0] = stratified_point(row[6], row[7], fa.t_vals, lane, SR, fa.lindisp,
+                                        fa.t_rand ? fa.t_rand + ray * SR + lane : nullptr);
+            ray_forward<IT>(raw_s + (wave / WPR) * SR * 4, nullptr, fa.noise ? fa.noise + ray * SR : nullptr, dir_norm(row), SR,
+                            stt, sums);
+            composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
+            // inverse-CDF resampling + merge from the weights in registers: weight e of the pdf = coarse weight e + 1
+            float zc[1] = {stt.z[0]}, wts[1], uu[1];
+            const float wn = __shfl_down(stt.w[0], 1, 64);
+            wts[0] = lane < SR - 2 ? wn : 0.f;
+            uu[0] = lane < fa.Nf ? (fa.u_is_row ? fa.u[lane] : fa.u[ray * fa.Nf + lane]) : 2.f;
+            sample_merge_ray<1>(zc, wts, uu, ray, SR, fa.Nf, nullptr, fa.z_merged, fa.z_std, nullptr, nullptr);
+        } else {
+            ray_forward<IT>(raw_s, in_b + ray * SR, fa.noise ? fa.noise + ray * SR : nullptr, dir_norm(row), SR, stt, sums);
+            composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
+        }
+    }
 }
 
 // ---- packing ---------------------------------------------------------------------------------------------------
@@ -252,5 +305,50 @@ extern "C" int mvip_mlp_forward_points16(const float *packed16, const float *pts
     if (!packed16 || !pts || !dirs || !raw) return MVIP_EINVAL;
     hipLaunchKernelGGL((mlp_forward16_kernel<false>), dim3((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), dim3(512), 0,
                        as_stream(stream), packed16, pts, dirs, P, 1, raw);
+    return check_launch();
+}
+
+// ---- render_rays in two launches (no-grad renders of the native 8x256 networks; DS_NeRF/run.py:1703-1847) --------------
+// Coarse pass, 64 samples per ray: stratified depths (t_vals [64], t_rand [B,64] or NULL) -> network -> raw2outputs (noise
+// [B,64] or NULL, flags as mvip_composite_forward) -> inverse-CDF resampling with Nf <= 64 uniforms (u [B,Nf], or one row
+// when u_is_row) -> merged depths.  Outputs: rgb0 [B,3], disp0 [B], acc0 [B], z_merged [B,64+Nf], z_std [B]; alpha0 [B,64],
+// depth0 [B], weights0 [B,64] optional (NULL = not wanted).  Every value is bit-identical to the chain
+// mvip_stratified_z -> mvip_mlp_forward_rays16 -> mvip_composite_forward -> mvip_sample_pdf_merge.
+extern "C" int mvip_render_coarse_fused(const float *packed16, const float *rows, int64_t B, const float *t_vals, int lindisp,
+                                        const float *t_rand, const float *noise, const float *u, int u_is_row, int Nf, int flags,
+                                        float *rgb0, float *disp0, float *acc0, float *depth0, float *weights0, float *alpha0,
+                                        float *z_merged, float *z_std, void *stream) {
+    if (B < 0 || Nf < 1 || Nf > 64) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!packed16 || !rows || !t_vals || !u || !rgb0 || !disp0 || !acc0 || !z_merged || !z_std) return MVIP_EINVAL;
+    FuseArgs fa;
+    fa.t_vals = t_vals; fa.t_rand = t_rand; fa.noise = noise; fa.u = u; fa.u_is_row = u_is_row; fa.lindisp = lindisp;
+    fa.flags = flags; fa.Nf = Nf;
+    fa.rgb = rgb0; fa.disp = disp0; fa.acc = acc0; fa.depth = depth0; fa.weights = weights0; fa.alpha = alpha0;
+    fa.z_merged = z_merged; fa.z_std = z_std;
+    const int64_t P = B * 64;
+    hipLaunchKernelGGL((mlp_forward16_kernel<true, false, 1>), dim3((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), dim3(512), 0,
+                       as_stream(stream), packed16, rows, (const float *)nullptr, P, 64, (float *)nullptr, (float *)nullptr,
+                       (int64_t)0, fa);
+    return check_launch();
+}
+
+// Fine pass, 128 samples per ray at the depths z [B,128]: network -> raw2outputs.  Outputs as mvip_composite_forward
+// (weights required, alpha optional) plus raw [B,128,4] (optional); bit-identical to mvip_mlp_forward_rays16 ->
+// mvip_composite_forward.
+extern "C" int mvip_render_fine_fused(const float *packed16, const float *rows, const float *z, int64_t B, const float *noise,
+                                      int flags, float *raw, float *rgb, float *disp, float *acc, float *depth, float *weights,
+                                      float *alpha, void *stream) {
+    if (B < 0) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!packed16 || !rows || !z || !rgb || !disp || !acc || !depth || !weights) return MVIP_EINVAL;
+    FuseArgs fa;
+    fa.t_vals = nullptr; fa.t_rand = nullptr; fa.noise = noise; fa.u = nullptr; fa.u_is_row = 0; fa.lindisp = 0;
+    fa.flags = flags; fa.Nf = 0;
+    fa.rgb = rgb; fa.disp = disp; fa.acc = acc; fa.depth = depth; fa.weights = weights; fa.alpha = alpha;
+    fa.z_merged = nullptr; fa.z_std = nullptr;
+    const int64_t P = B * 128;
+    hipLaunchKernelGGL((mlp_forward16_kernel<true, false, 2>), dim3((unsigned)(P / WG_POINTS)), dim3(512), 0, as_stream(stream),
+                       packed16, rows, z, P, 128, raw, (float *)nullptr, (int64_t)0, fa);
     return check_launch();
 }

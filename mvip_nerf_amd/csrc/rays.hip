@@ -1,7 +1,7 @@
 // Ray generation, ray-row assembly, stratified depths and the materialised sinusoidal encoding.
 // All HBM-bound, one element per thread, arithmetic written in the reference's operation order
 // (the library is built with -ffp-contract=off so a*b+c stays two roundings like torch's).
-#include "common.h"
+#include "rays_device.h"
 
 namespace mvip {
 
@@ -61,11 +61,6 @@ __global__ void ray_rows_pose_kernel(const float *__restrict__ c2w, int H, int W
     write_row(rows + i * 11, o, d, d, near, far);
 }
 
-// run.py:1759-1781
-__device__ __forceinline__ float z_at(float near, float far, float t, int lindisp) {
-    if (lindisp) return 1.f / ((1.f / near) * (1.f - t) + (1.f / far) * t);
-    return near * (1.f - t) + far * t;
-}
 
 __global__ void stratified_z_kernel(const float *__restrict__ rows, int ncols, int64_t B, int S,
                                     const float *__restrict__ t_vals, int lindisp,
@@ -75,13 +70,7 @@ __global__ void stratified_z_kernel(const float *__restrict__ rows, int ncols, i
     const int64_t r = i / S;
     const int s = (int)(i % S);
     const float near = rows[r * ncols + 6], far = rows[r * ncols + 7];
-    const float zc = z_at(near, far, t_vals[s], lindisp);
-    if (!t_rand) { z[i] = zc; return; }
-    const float zl = s > 0 ? z_at(near, far, t_vals[s - 1], lindisp) : zc;
-    const float zr = s < S - 1 ? z_at(near, far, t_vals[s + 1], lindisp) : zc;
-    const float upper = s < S - 1 ? .5f * (zr + zc) : zc;
-    const float lower = s > 0 ? .5f * (zc + zl) : zc;
-    z[i] = lower + (upper - lower) * t_rand[i];
+    z[i] = stratified_point(near, far, t_vals, s, S, lindisp, t_rand ? t_rand + i : nullptr);
 }
 
 // Four consecutive samples of one ray per thread (S % 4 == 0): the two per-ray reciprocals are taken once and

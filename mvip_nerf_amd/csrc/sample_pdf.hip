@@ -11,205 +11,9 @@
 //   * the 2-point gathers of cdf/bins are cross-lane shuffles;
 //   * sort(cat[z, z_samples]) is a bitonic network over registers + shuffles.
 // HBM traffic per ray (Nc=Nf=64): 512 B in (z, weights) + 256 B (u) and 512+256+4 B out.
-#include "common.h"
-#include <math.h>
+#include "sample_pdf_device.h"
 
 namespace mvip {
-
-template <int IT>
-__device__ __forceinline__ float strided_get(const float (&v)[IT], int e) {
-    float out = 0.f;
-    const int src = e & 63, item = e >> 6;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const float t = __shfl(v[i], src, 64);
-        if (item == i) out = t;
-    }
-    return out;
-}
-
-// bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
-// Produces samples (strided) and inds; cdf_out strided (nb entries).
-// Up to 64 bins (the reference configuration: 63 midpoints of 64 coarse samples): everything in one register
-// per lane.  The normaliser is an fp64 butterfly sum, the CDF an fp64 Hillis-Steele scan rounded to fp32 per
-// entry (torch's CPU cumsum accumulates in fp64 in index order; a different summation ORDER changes the fp64
-// value by ~1e-16 relative, i.e. the rounded fp32 entry in ~1 of 1e8 cases), and searchsorted(right=True) is a
-// six-step binary search on cross-lane reads of the sorted CDF.  ~150 instructions per ray instead of ~2000.
-// Returns false (nothing written) if some pdf entry is negative: the CDF is then not sorted and the caller
-// takes the index-ordered path.
-__device__ __forceinline__ bool inverse_cdf_fast(const float bins, const float wts, int nb, const float u,
-                                                 float &sample, int &ind, float &cdf_out) {
-    const int l = lane_id();
-    const int nw = nb - 1;
-    const float w5 = wts + 1e-5f;
-    double tot = l < nw ? (double)w5 : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    const float total = (float)tot;
-    const float pdf = l < nw ? w5 / total : 0.f;
-    if (__any(pdf < 0.f)) return false;
-    double run = (double)pdf;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(run, o, 64); if (l >= o) run += t; }
-    const float incl = (float)run;                              // cdf[l + 1]
-    const float up = __shfl_up(incl, 1, 64);
-    const float cdf = l == 0 ? 0.f : up;                        // cdf[l], valid for l < nb
-    const float key = l < nb ? cdf : INFINITY;
-    int cnt = 0;                                                // #{k < nb : cdf[k] <= u}
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int probe = cnt + step;
-        const float c = __shfl(key, (probe - 1) & 63, 64);
-        if (probe <= 64 && c <= u) cnt = probe;
-    }
-    const float c63 = __shfl(key, 63, 64);                      // the steps sum to at most 63: one more probe for 64
-    if (cnt == 63 && c63 <= u) cnt = 64;
-    const int below = max(0, cnt - 1), above = min(nb - 1, cnt);
-    const float cb = __shfl(cdf, below, 64), ca = __shfl(cdf, above, 64);
-    const float bb = __shfl(bins, below, 64), ba = __shfl(bins, above, 64);
-    float den = ca - cb;
-    den = den < 1e-5f ? 1.f : den;
-    const float t = (u - cb) / den;
-    sample = bb + t * (ba - bb);
-    ind = cnt;
-    cdf_out = cdf;
-    return true;
-}
-
-template <int IT>
-__device__ __forceinline__ void inverse_cdf(const float (&bins)[IT], const float (&wts)[IT], int nb,
-                                            const float (&u)[IT], int nf, float (&samples)[IT],
-                                            int (&inds)[IT], float (&cdf)[IT]) {
-    if constexpr (IT == 1) {
-        if (inverse_cdf_fast(bins[0], wts[0], nb, u[0], samples[0], inds[0], cdf[0])) return;
-    }
-    const int l = lane_id();
-    const int nw = nb - 1;
-    // weights + 1e-5, total in index order
-    float w5[IT];
-    double total_d = 0.0;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) w5[i] = wts[i] + 1e-5f;
-#pragma unroll
-    for (int i = 0; i < IT; ++i)
-        for (int k = 0; k < 64; ++k) {
-            if (i * 64 + k >= nw) break;
-            total_d += (double)__shfl(w5[i], k, 64);
-        }
-    const float total = (float)total_d;
-    // cdf[0] = 0; cdf[k+1] = cdf[k] + pdf[k]; count cdf entries <= u on the fly
-    double run_d = 0.0;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) { inds[i] = 0; cdf[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) inds[i] += (0.f <= u[i]) ? 1 : 0;          // cdf[0] = 0
-#pragma unroll
-    for (int i = 0; i < IT; ++i)
-        for (int k = 0; k < 64; ++k) {
-            const int e = i * 64 + k;                  // weight index; writes cdf[e+1]
-            if (e >= nw) break;
-            const float pdf = __shfl(w5[i], k, 64) / total;
-            run_d += (double)pdf;
-            const float run = (float)run_d;
-            const int dst = e + 1;
-#pragma unroll
-            for (int ii = 0; ii < IT; ++ii) {
-                if ((dst >> 6) == ii && (dst & 63) == l) cdf[ii] = run;
-                inds[ii] += (run <= u[ii]) ? 1 : 0;
-            }
-        }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int below = max(0, inds[i] - 1);
-        const int above = min(nb - 1, inds[i]);
-        const float cb = strided_get<IT>(cdf, below), ca = strided_get<IT>(cdf, above);
-        const float bb = strided_get<IT>(bins, below), ba = strided_get<IT>(bins, above);
-        float den = ca - cb;
-        den = den < 1e-5f ? 1.f : den;
-        const float t = (u[i] - cb) / den;
-        samples[i] = bb + t * (ba - bb);
-    }
-    (void)nf;
-}
-
-// Bitonic sort, ascending, of 64*M values in strided layout (index e = i*64 + lane).
-template <int M>
-__device__ __forceinline__ void bitonic_sort(float (&v)[M]) {
-    const int l = lane_id();
-#pragma unroll
-    for (int k = 2; k <= 64 * M; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const int dj = j >> 6;
-#pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    if ((i & dj) == 0) {
-                        const int e = i * 64 + l;
-                        const bool up = (e & k) == 0;
-                        const float a = v[i], b = v[i | dj];
-                        const bool sw = up ? (a > b) : (a < b);
-                        v[i] = sw ? b : a;
-                        v[i | dj] = sw ? a : b;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    const int e = i * 64 + l;
-                    const bool up = (e & k) == 0;
-                    const float other = __shfl_xor(v[i], j, 64);
-                    const bool lower = (l & j) == 0;
-                    const float mn = fminf(v[i], other), mx = fmaxf(v[i], other);
-                    v[i] = (lower == up) ? mn : mx;
-                }
-            }
-        }
-    }
-}
-
-// #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
-// +inf): six binary-search steps on cross-lane reads + one probe for the count 64.
-template <bool STRICT>
-__device__ __forceinline__ int count_below(const float key, const float x) {
-    int cnt = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int probe = cnt + step;
-        const float c = __shfl(key, (probe - 1) & 63, 64);
-        if (probe <= 64 && (STRICT ? c < x : c <= x)) cnt = probe;
-    }
-    const float c63 = __shfl(key, 63, 64);
-    if (cnt == 63 && (STRICT ? c63 < x : c63 <= x)) cnt = 64;
-    return cnt;
-}
-
-// Merge of two SORTED lists of <= 64 values each by rank: element i of a lands at i + #{b < a_i}, element j of b at
-// j + #{a <= b_j} (ties: the coarse depth first; the VALUES equal those of sort(cat[a, b]) in every case).  12
-// cross-lane reads and two scattered 4-byte stores into the ray's own 512-byte row instead of the 28-stage / 54-shuffle
-// bitonic network over 128 values.  Returns false (nothing written) if either list is not sorted.
-__device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int nb, bool b_may_be_unsorted,
-                                             float *__restrict__ out_row) {
-    const int l = lane_id();
-    const float a_key = l < na ? a : INFINITY;
-    float b_key = l < nb ? b : INFINITY;
-    const float a_next = __shfl_down(a_key, 1, 64), b_next = __shfl_down(b_key, 1, 64);
-    if (__any(l < 63 && a_next < a_key)) return false;
-    if (__any(l < 63 && b_next < b_key)) {
-        if (!b_may_be_unsorted) return false;
-        float v[1] = {b_key};                                    // random u: sort the 64 new samples (21 stages)
-        bitonic_sort<1>(v);
-        b_key = v[0];
-    }
-    if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
-    // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
-    // +inf padding lanes of the other list and land beyond the ray's own row
-    const int pa = l + min(count_below<true>(b_key, a_key), nb);
-    const int pb = l + min(count_below<false>(a_key, b_key), na);
-    if (l < na) out_row[pa] = a_key;
-    if (l < nb) out_row[pb] = b_key;
-    return true;
-}
 
 template <int IT>
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
@@ -220,8 +24,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     if (ray >= B) return;
     const int l = lane_id();
     const int nb = Nc - 1;                           // midpoints
-    float zc[IT], bins[IT], wts[IT], uu[IT], smp[IT], cdf[IT];
-    int inds[IT];
+    float zc[IT], wts[IT], uu[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int e = i * 64 + l;
@@ -230,56 +33,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
         wts[i] = e < nb - 1 ? weights[ray * Nc + e + 1] : 0.f;
         uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
     }
-    // mids[e] = .5 * (z[e+1] + z[e])
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        float nxt = __shfl_down(zc[i], 1, 64);
-        const float wrap = __shfl(zc[(i + 1) % IT], 0, 64);      // all lanes take part in the shuffle
-        if (l == 63) nxt = (i + 1 < IT) ? wrap : 0.f;
-        bins[i] = .5f * (nxt + zc[i]);
-    }
-    inverse_cdf<IT>(bins, wts, nb, uu, Nf, smp, inds, cdf);
-    float s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int e = i * 64 + l;
-        if (e < Nf) {
-            z_samples[ray * Nf + e] = smp[i];
-            if (inds_out) inds_out[ray * Nf + e] = inds[i];
-            s1 += smp[i];
-        }
-        if (cdf_out && e < nb) cdf_out[ray * nb + e] = cdf[i];
-    }
-    // population std of the new samples (torch.std(unbiased=False))
-    const float mean = wave_sum(s1) / (float)Nf;
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int e = i * 64 + l;
-        if (e < Nf) { const float d = smp[i] - mean; s2 += d * d; }
-    }
-    s2 = wave_sum(s2);
-    if (l == 0) z_std[ray] = sqrtf(s2 / (float)Nf);
-    // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
-    // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
-    if constexpr (IT == 1) {
-        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf))) return;
-    }
-    constexpr int M = 2 * IT;
-    float v[M];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int e = i * 64 + l;
-        v[i] = e < Nc ? zc[i] : INFINITY;
-        v[IT + i] = e < Nf ? smp[i] : INFINITY;
-    }
-    bitonic_sort<M>(v);
-    const int N = Nc + Nf;
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        const int e = i * 64 + l;
-        if (e < N) z_merged[ray * N + e] = v[i];
-    }
+    sample_merge_ray<IT>(zc, wts, uu, ray, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out);
 }
 
 template <int IT>

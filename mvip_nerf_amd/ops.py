@@ -1386,3 +1386,45 @@ def linear_small_grouped(x, Wcat, bcat, offsets_dev, sizes, act_in=0):
         out.append(y[o * NB:(o + c) * NB].view(NB, c))
         o += c
     return out
+
+
+# render_rays in two launches (csrc/mlp_fwd16.hip, FUSE = 1 / 2): no-grad renders of the native networks ----------------
+
+def render_coarse_fused(packed16, rows, lindisp, t_rand, noise, u, white_bkgd, need_alpha=False):
+    """Coarse pass of render_rays (64 samples) behind ONE launch: stratified depths -> network -> raw2outputs -> inverse-CDF
+    resampling (u: [B, Nf] or a shared row [Nf], Nf <= 64) -> merged depths.  Returns (rgb0, disp0, acc0, alpha0 | None,
+    z_merged [B, 64 + Nf], z_std), bit-identical to stratified_z -> mlp_rays -> composite -> sample_pdf_merge."""
+    rows = _f32c(rows)
+    B, dev = rows.shape[0], rows.device
+    u = _f32c(u)
+    Nf = u.shape[-1]
+    rgb = torch.empty((B, 3), device=dev, dtype=_F32)
+    disp = torch.empty((B,), device=dev, dtype=_F32)
+    acc = torch.empty((B,), device=dev, dtype=_F32)
+    alpha = torch.empty((B, 64), device=dev, dtype=_F32) if need_alpha else None
+    zm = torch.empty((B, 64 + Nf), device=dev, dtype=_F32)
+    zstd = torch.empty((B,), device=dev, dtype=_F32)
+    tr = None if t_rand is None else _f32c(t_rand)
+    nz = None if noise is None else _f32c(noise)
+    call('mvip_render_coarse_fused', ptr(packed16), ptr(rows), B, ptr(_t_vals(64, dev)), int(bool(lindisp)), ptr(tr), ptr(nz),
+         ptr(u), int(u.dim() == 1), int(Nf), COMP_WHITE if white_bkgd else 0, ptr(rgb), ptr(disp), ptr(acc), ptr(None),
+         ptr(None), ptr(alpha), ptr(zm), ptr(zstd), stream())
+    return rgb, disp, acc, alpha, zm, zstd
+
+
+def render_fine_fused(packed16, rows, z, noise, white_bkgd, need_alpha=False, want_raw=False):
+    """Fine pass of render_rays (128 samples at depths z) behind ONE launch: network -> raw2outputs.  Returns (rgb, disp,
+    acc, weights, depth, alpha | None, raw | None), bit-identical to mlp_rays -> composite."""
+    rows, z = _f32c(rows), _f32c(z)
+    B, dev = rows.shape[0], rows.device
+    rgb = torch.empty((B, 3), device=dev, dtype=_F32)
+    disp = torch.empty((B,), device=dev, dtype=_F32)
+    acc = torch.empty((B,), device=dev, dtype=_F32)
+    depth = torch.empty((B,), device=dev, dtype=_F32)
+    weights = torch.empty((B, 128), device=dev, dtype=_F32)
+    alpha = torch.empty((B, 128), device=dev, dtype=_F32) if need_alpha else None
+    raw = torch.empty((B, 128, 4), device=dev, dtype=_F32) if want_raw else None
+    nz = None if noise is None else _f32c(noise)
+    call('mvip_render_fine_fused', ptr(packed16), ptr(rows), ptr(z), B, ptr(nz), COMP_WHITE if white_bkgd else 0, ptr(raw),
+         ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(weights), ptr(alpha), stream())
+    return rgb, disp, acc, weights, depth, alpha, raw

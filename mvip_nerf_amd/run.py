@@ -117,6 +117,11 @@ def _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_view
     return torch.cat(cols, -1).contiguous()
 
 
+# render_rays as two launches per chunk for no-grad renders of the native networks (64 coarse + <= 64 fine samples);
+# MVIP_FUSED_RENDER=0 restores the six-launch chain (A/B switch; the outputs are bit-identical either way)
+FUSED_RENDER = bool(int(os.environ.get('MVIP_FUSED_RENDER', '1')))
+
+
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., pytest=False,
                 sigma_loss=None, verbose=False, need_alpha=False, detach_weights=False, coarse_grad=True):
@@ -153,10 +158,34 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         if pytest:
             np.random.seed(0)
             t_rand = torch.tensor(np.random.rand(N_rays, N_samples), dtype=torch.float32, device=dev)
-    z_vals = ops.stratified_z(rows, N_samples, lindisp, t_rand)
 
     coarse_net = network_fn if network_fn is not None else (
         network_fine.alpha_model if getattr(network_fine, 'alpha_model', None) is not None else network_fine)
+    fine_net = network_fn if network_fine is None else network_fine
+    if (FUSED_RENDER and not torch.is_grad_enabled() and N_rays > 0 and N_samples == 64 and 0 < N_importance <= 64
+            and ncols == 11 and sigma_loss is None and getattr(network_query_fn, '_mvip_native', False)
+            and isinstance(coarse_net, NeRF) and isinstance(fine_net, NeRF)):
+        c16, f16 = coarse_net._infer16(), fine_net._infer16()
+        if c16 is not None and f16 is not None and N_samples + N_importance == 128:
+            # TWO launches for the whole chunk (csrc/mlp_fwd16.hip, FUSE = 1 / 2): the random draws are made in the order of
+            # the unfused path below, every output is bit-identical to it (tests/test_render.py)
+            noise0 = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)
+            u = _uniforms((N_rays,), N_importance, perturb == 0., pytest, dev)
+            rgb0, disp0, acc0, alpha0, z_vals, z_std = ops.render_coarse_fused(c16, rows, lindisp, t_rand, noise0, u,
+                                                                               white_bkgd, need_alpha)
+            noise = _density_noise((N_rays, N_samples + N_importance), raw_noise_std, pytest, dev)
+            rgb_map, disp_map, acc_map, weights, depth_map, alpha, raw = ops.render_fine_fused(
+                f16, rows, z_vals, noise, white_bkgd, need_alpha, retraw)
+            ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map,
+                   'weights': weights, 'z_vals': z_vals}
+            if retraw:
+                ret['raw'] = raw
+            if need_alpha:
+                ret['alpha'], ret['alpha0'] = alpha, alpha0
+            ret['rgb0'], ret['disp0'], ret['acc0'], ret['z_std'] = rgb0, disp0, acc0, z_std
+            return ret
+    z_vals = ops.stratified_z(rows, N_samples, lindisp, t_rand)
+
     with torch.set_grad_enabled(torch.is_grad_enabled() and (coarse_grad or N_importance <= 0)):
         raw = query(z_vals, coarse_net)
         noise = _density_noise((N_rays, N_samples), raw_noise_std, pytest, dev)

@@ -86,6 +86,54 @@ def test_render_rays_pytest_train_mode_golden(golden, cuda):
     assert_close_outliers(N(r['weights']), g['weights'], 2e-4, 2e-5, outlier_frac=0.01, outlier_atol=5e-2, err_msg='weights')
 
 
+@pytest.mark.parametrize('B', [96, 1023, 2])
+@pytest.mark.parametrize('mode', ['test', 'train_kwargs', 'pytest_hooks'])
+def test_render_rays_two_launch_path_is_bit_identical(cuda, B, mode):
+    """render_rays as TWO launches per chunk (csrc/mlp_fwd16.hip FUSE = 1 / 2: depths + coarse network + compositing +
+    inverse-CDF resampling + merge, then fine network + compositing) against the six-launch chain of stand-alone kernels:
+    every returned tensor identical bit for bit (NaN-safe), in test mode, with the training kwargs' random jitter / density
+    noise under no_grad (same seeded draws in the same order), with the reference's pytest hooks, for odd ray counts, both
+    depth parametrisations and backgrounds; and the fused path really is two launches of mvip:: kernels."""
+    from mvip_nerf_amd import run
+    tr, te, _, _ = build(31, 32, cuda)
+    rays = T(bench_like_rays(B, seed=B), cuda)
+    kw = dict(retraw=True, N_importance=64, network_fine=te['network_fine'], need_alpha=True)
+    if mode == 'test':
+        kw.update(lindisp=True, perturb=0., raw_noise_std=0., white_bkgd=True)
+    elif mode == 'train_kwargs':
+        kw.update(lindisp=False, perturb=1., raw_noise_std=1., white_bkgd=False)
+    else:
+        kw.update(lindisp=True, perturb=1., raw_noise_std=1., white_bkgd=True, pytest=True)
+    outs = {}
+    for fused in (False, True):
+        run.FUSED_RENDER = fused
+        try:
+            torch.manual_seed(5)
+            torch.cuda.manual_seed(5)
+            with torch.no_grad():
+                outs[fused] = run.render_rays(rays, te['network_fn'], te['network_query_fn'], 64, **kw)
+        finally:
+            run.FUSED_RENDER = True
+    assert set(outs[True]) == set(outs[False]) == {'rgb_map', 'disp_map', 'acc_map', 'depth_map', 'weights', 'z_vals', 'raw',
+                                                    'alpha', 'alpha0', 'rgb0', 'disp0', 'acc0', 'z_std'}
+    bits = lambda t: t.contiguous().view(torch.int32)
+    for k in outs[True]:
+        assert outs[True][k].shape == outs[False][k].shape, k
+        assert torch.equal(bits(outs[True][k]), bits(outs[False][k])), k
+    if B == 1023 and mode == 'test':
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            with torch.no_grad():
+                run.render_rays(rays, te['network_fn'], te['network_query_fn'], 64, **kw)
+            torch.cuda.synchronize()
+        launched = [(e.key, e.count) for e in prof.key_averages() if e.device_time_total > 0]
+        assert sum(c for _, c in launched) <= 3, launched               # two fused kernels (+ at most the u row)
+        assert sum(c for k, c in launched if 'mlp_forward16_kernel' in k) == 2, launched
+    # with autograd the six-launch chain (stash-writing forward, separate compositing) still runs: gradients flow
+    r = run.render_rays(rays[:8], tr['network_fn'], tr['network_query_fn'], 64, lindisp=True, perturb=0., N_importance=64,
+                        network_fine=tr['network_fine'], white_bkgd=True)
+    assert r['rgb_map'].requires_grad
+
+
 def _oracle_fp64(rays, seed_c, seed_f, **rand):
     """The oracle's algorithm evaluated in float64 (inputs, weights, constants): the 'true value' of the same
     expressions, against which the fp32 reference and the HIP path are both measured."""
