@@ -15,10 +15,11 @@ struct RayState {
 
 // Recomputes everything the forward defines for one ray.  Returns (acc, depth, rgb sums).
 // z == nullptr: the caller has already put the ray's depths into st.z (a fused kernel that computed them itself).
+// noise_reg != nullptr: this lane's ITEMS noise values, already in registers (a fused kernel that loaded them early).
 template <int ITEMS>
 __device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const float *__restrict__ z,
                                             const float *__restrict__ noise, float dnorm, int S,
-                                            RayState<ITEMS> &st, float sums[5]) {
+                                            RayState<ITEMS> &st, float sums[5], const float *noise_reg = nullptr) {
     const int l = lane_id();
     float zfirst_next;
 #pragma unroll
@@ -37,7 +38,8 @@ __device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const
         float nz = 0.f;
         if (st.valid[i]) {
             r = reinterpret_cast<const float4 *>(raw)[s];
-            if (noise) nz = noise[s];
+            if (noise_reg) nz = noise_reg[i];
+            else if (noise) nz = noise[s];
         }
         const float znext = (i + 1 < ITEMS) ? st.z[(i + 1) % ITEMS] : zfirst_next;
         float d = (s == S - 1) ? 1e10f : (znext - st.z[i]);

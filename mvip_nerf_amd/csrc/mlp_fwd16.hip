@@ -65,7 +65,12 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
                      int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash = nullptr, int64_t n_pt = 0,
                      const FuseArgs fa = FuseArgs{}) {
     __shared__ __attribute__((aligned(16))) float lds[LDS16_FLOATS];
-    __shared__ __attribute__((aligned(16))) float raw_s[FUSE ? WG_POINTS * 4 : 4];
+    // The fused tail's copy of the workgroup's raw values lives in a ring slot the weight stream no longer uses: every wave
+    // that has left the last layer is past the barrier that closed chunk TOTAL_CHUNKS - 2, so that chunk's slot is read by
+    // nobody.  (A separate 2 KB array made the kernel 4-5 % slower: 80,896 instead of 78,848 bytes of LDS per workgroup --
+    // measured 210 vs 201.5 ms on the fine pass with identical instructions in the network part; with 78,848 bytes the
+    // next workgroup's waves evidently start flowing in while this one's last waves finish.)
+    float *raw_s = lds + ((TOTAL_CHUNKS - 2) % NSLOT16) * CHUNK_FLOATS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -80,15 +85,31 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     st.issue_chunk(1, 1);
 
     float px, py, pz, vx, vy, vz;
+    // fused tail (FUSE != 0): what its wave will need is fetched NOW and carried in a few registers through the network --
+    // the tail runs alone on its SIMD at the end of the workgroup, where a global-memory round trip is fully exposed
+    float zz = 0.f, tail_dnorm = 0.f, tail_u = 2.f, tail_nz[2] = {0.f, 0.f};
     if constexpr (FROM_RAYS) {
         const int64_t ray = p / S;
         const float *row = in_a + ray * 11;
-        float zz;
         if constexpr (FUSE == 1) zz = stratified_point(row[6], row[7], fa.t_vals, (int)(p - ray * S), S, fa.lindisp,
                                                         fa.t_rand ? fa.t_rand + p : nullptr);
         else zz = in_b[p];
         px = row[0] + row[3] * zz; py = row[1] + row[4] * zz; pz = row[2] + row[5] * zz;
         vx = row[8]; vy = row[9]; vz = row[10];
+        if constexpr (FUSE != 0) {
+            constexpr int WPR_ = FUSE == 1 ? 4 : 8, SR_ = FUSE == 1 ? 64 : 128;
+            if (wave % WPR_ == 0) {                          // this wave composites its ray at the end: lane = sample(s)
+                tail_dnorm = dir_norm(row);
+                const int64_t tray = (int64_t)blockIdx.x * (8 / WPR_) + wave / WPR_;
+                if (tray * SR_ < P) {
+                    if (FUSE == 1 && lane < fa.Nf) tail_u = fa.u_is_row ? fa.u[lane] : fa.u[tray * fa.Nf + lane];
+                    if (fa.noise) {
+#pragma unroll
+                        for (int i = 0; i < SR_ / 64; ++i) tail_nz[i] = fa.noise[tray * SR_ + lane * (SR_ / 64) + i];
+                    }
+                }
+            }
+        }
     } else {
         px = in_a[p * 3]; py = in_a[p * 3 + 1]; pz = in_a[p * 3 + 2];
         vx = in_b[p * 3]; vy = in_b[p * 3 + 1]; vz = in_b[p * 3 + 2];
@@ -191,32 +212,33 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     if (live && g == 0 && raw) reinterpret_cast<float4 *>(raw)[p] = out4;
     if constexpr (FUSE != 0) {
         // ---- the rest of the pass, by the first wave of each ray, from the workgroup's raw values in LDS ----
-        if (g == 0) reinterpret_cast<float4 *>(raw_s)[wave * 16 + n] = out4;
+        float *z_s = raw_s + WG_POINTS * 4;                  // the points' depths, next to their raw values
+        if (g == 0) {
+            reinterpret_cast<float4 *>(raw_s)[wave * 16 + n] = out4;
+            z_s[wave * 16 + n] = zz;
+        }
         __syncthreads();
         constexpr int RAYS = FUSE == 1 ? 2 : 1, WPR = 8 / RAYS, SR = WG_POINTS / RAYS;      // rays, waves and samples per ray
         if (wave % WPR != 0) return;
+#ifdef MVIP_EXPERIMENT_NO_FUSE_TAIL        // timing experiment only (results are then missing): the network part alone
+        return;
+#endif
         const int64_t ray = (int64_t)blockIdx.x * RAYS + wave / WPR;
         if (ray * SR >= P) return;
-        const float *row = in_a + ray * 11;
         constexpr int IT = SR / 64;
         RayState<IT> stt;
         float sums[5];
+        // depths and raw values from LDS, direction norm / noise / uniforms from the registers filled at the start: the
+        // tail touches global memory only to store
+        ray_forward<IT>(raw_s + (wave / WPR) * SR * 4, z_s + (wave / WPR) * SR, nullptr, tail_dnorm, SR, stt, sums,
+                        fa.noise ? tail_nz : nullptr);
+        composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
         if constexpr (FUSE == 1) {
-            // this lane's sample = lane: the same expression the network's prologue evaluated for the point
-            stt.z[0] = stratified_point(row[6], row[7], fa.t_vals, lane, SR, fa.lindisp,
-                                        fa.t_rand ? fa.t_rand + ray * SR + lane : nullptr);
-            ray_forward<IT>(raw_s + (wave / WPR) * SR * 4, nullptr, fa.noise ? fa.noise + ray * SR : nullptr, dir_norm(row), SR,
-                            stt, sums);
-            composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
             // inverse-CDF resampling + merge from the weights in registers: weight e of the pdf = coarse weight e + 1
-            float zc[1] = {stt.z[0]}, wts[1], uu[1];
+            float zc[1] = {stt.z[0]}, wts[1], uu[1] = {tail_u};
             const float wn = __shfl_down(stt.w[0], 1, 64);
             wts[0] = lane < SR - 2 ? wn : 0.f;
-            uu[0] = lane < fa.Nf ? (fa.u_is_row ? fa.u[lane] : fa.u[ray * fa.Nf + lane]) : 2.f;
             sample_merge_ray<1>(zc, wts, uu, ray, SR, fa.Nf, nullptr, fa.z_merged, fa.z_std, nullptr, nullptr);
-        } else {
-            ray_forward<IT>(raw_s, in_b + ray * SR, fa.noise ? fa.noise + ray * SR : nullptr, dir_norm(row), SR, stt, sums);
-            composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
         }
     }
 }
