@@ -466,7 +466,8 @@ def main():
                 'what': 'NeRF_TCNN (16-level hash grid + 64-wide MLPs, coarse+fine), same frames and same training '
                         'iteration as the 8x256 legs; renders through the fused gather + fp32-MFMA kernel '
                         '(csrc/hashgrid_fused.hip); parity unpinned (tiny-cuda-nn absent)'}
-            del tr_h
+            del tr_h, scene_h
+            torch.cuda.empty_cache()       # the hash-grid leg's 1M-point chunks leave ~40 GB of cached blocks behind
 
         # ---- extra leg: the same frames with the split-precision forward (precision = 1, "f16x3": fp16 MFMA on
         #      hi/lo splits of both operands, fp32 accumulate).  Reported separately; `value` stays exact fp32. ----
@@ -550,48 +551,44 @@ def main():
             mask = torch.zeros(1, 1, H, W, device=device)
             mask[:, :, (H - 104) // 2:(H - 104) // 2 + 104, (W - 111) // 2:(W - 111) // 2 + 111] = 1
 
-            def sds_step(i):
-                pred.grad = None
-                (1e-4 * sd.train_step_sd(i, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
-            sds_step(1000)
-            barrier()
-            sds_times = []                        # per-step timing: the leg reports the MEDIAN step (a library
-            for k in range(args.sds_steps):       # autotune or allocator hiccup in one step was seen to cost 600 ms)
-                t2 = time.perf_counter()
-                sds_step(1000 + k)
-                barrier()
-                sds_times.append(time.perf_counter() - t2)
-            dt_sds = float(np.median(sds_times)) * args.sds_steps
-
-            # the same step replayed as ONE captured hipGraph (fp32), and the reference's --fp16 mode replayed the same way
-            def graphed_ms(sd_g, scale):
-                sd_g.use_graphs = True
+            def timed_steps(sd_x, scale, use_graphs, n):
+                """median wall time of n train_step_sd forward + backward steps (per-step barrier), after 2 warm-ups"""
+                sd_x.use_graphs = use_graphs
                 pg = pred.detach().clone().requires_grad_(True)
 
                 def one(i):
                     pg.grad = None
-                    (scale * sd_g.train_step_sd(i, mask, 'a stone bench in a park', pg, guidance_scale=7.5)).sum().backward()
+                    (scale * sd_x.train_step_sd(i, mask, 'a stone bench in a park', pg, guidance_scale=7.5)).sum().backward()
                 one(1000)
                 one(1001)
                 barrier()
                 ts = []
-                for k in range(max(args.sds_steps, 3)):
+                for k in range(n):
                     tg = time.perf_counter()
                     one(1002 + k)
                     barrier()
                     ts.append(time.perf_counter() - tg)
-                sd_g.use_graphs = False
-                return float(np.median(ts)) * 1e3
-            ms_graph32 = ms_graph16 = None
-            if world == 1:       # per-GPU numbers; not captured next to a live RCCL communicator (its watchdog thread may
-                try:             # touch the device during a global-mode capture)
-                    ms_graph32 = graphed_ms(sd, 1e-4)
+                return ts
+            # the step as the product runs it by default: fp32 networks (split-precision MFMA kernels), ONE captured hipGraph
+            # (StableDiffusion.use_graphs defaults to True for the built-in networks; thread-local capture, so a live RCCL
+            # communicator's watchdog thread does not disturb it) -- and the same step launch by launch
+            n_sds = max(args.sds_steps, 3)
+            sds_times = timed_steps(sd, 1e-4, True, n_sds)
+            dt_sds = float(np.median(sds_times)) * args.sds_steps
+            ms_eager32 = float(np.median(timed_steps(sd, 1e-4, False, n_sds))) * 1e3
+            # the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66) on the SAME hand-written kernels in their
+            # single-product instantiations (round 3; it used to fall onto MIOpen / CK / AOTriton kernels)
+            ms_graph16 = ms_eager16 = None
+            if world == 1:
+                try:
                     sd16 = StableDiffusion(device, True, False)
-                    ms_graph16 = graphed_ms(sd16, 1.0)
+                    ms_graph16 = float(np.median(timed_steps(sd16, 1.0, True, n_sds))) * 1e3
+                    ms_eager16 = float(np.median(timed_steps(sd16, 1.0, False, n_sds))) * 1e3
                     del sd16
                 except Exception as e:                            # reported, never fatal for the bench line
-                    print(f'[bench] hipGraph leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
+                    print(f'[bench] fp16-mode leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
                 torch.cuda.empty_cache()
+            sd.use_graphs = True
             opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                         text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                         colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
@@ -654,7 +651,14 @@ def main():
             fl = sds_step_flops(512)
             sds_ms = dt_sds / args.sds_steps * 1e3
             ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            pmc_sds = os.path.join(ROOT, 'profiles', 'r3_pmc_sds_traffic.json')
+            if os.path.exists(pmc_sds):
+                traffic = json.load(open(pmc_sds)).get('hbm_bytes_per_step')
+                traffic_src = 'profiles/r3_pmc_sds_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one eager step, per kernel)'
             sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
+                        'algorithmic_hbm_bytes': fl['bytes_per_step'], 'traffic': traffic, 'traffic_unit': 'HBM bytes per step',
+                        'traffic_source': traffic_src,
                         'unet_forward_flops': fl['unet_forward'], 'vae_encoder_forward_flops': fl['vae_encoder_forward'],
                         'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
                         'peak': round(PEAK_F16_TFLOPS / 3, 1),
@@ -669,7 +673,11 @@ def main():
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
                              'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 relative)',
                              'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
-                             'ms_per_step_hipgraph': ms_graph32, 'ms_per_step_fp16_hipgraph': ms_graph16,
+                             'mode': 'one captured hipGraph per (shape, prompt): the default of StableDiffusion for the built-in networks',
+                             'ms_per_step_eager': ms_eager32,
+                             'ms_per_step_fp16_hipgraph': ms_graph16, 'ms_per_step_fp16_eager': ms_eager16,
+                             'fp16_what': "the reference's --fp16 mode on the same hand-written kernels, single fp16 product per "
+                                          'step, fp32 accumulate (csrc/conv3x3.hip, attention.hip: <..., true> instantiations)',
                              'what': 'median step; train_step_sd at 504x378 -> 512^2, SD-1.5-inpaint-shaped UNet (B=2, '
                              '9ch, 64x64) + VAE encoder x2 fwd / x1 bwd, random weights; one independent step per rank'}
             mg['train_with_sds_ms'] = dt_full / args.sds_steps * 1e3

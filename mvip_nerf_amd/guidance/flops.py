@@ -18,14 +18,16 @@ import torch.nn as nn
 
 def _count(module, inputs_fn):
     from . import sd_nets
-    total = {'conv': 0, 'linear': 0, 'attention': 0}
+    total = {'conv': 0, 'linear': 0, 'attention': 0, 'bytes': 0}
 
     def conv_hook(m, inp, out):
         n, co, ho, wo = out.shape
         total['conv'] += 2 * co * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1] * ho * wo * n
+        total['bytes'] += 4 * (m.weight.numel() + inp[0].numel() + out.numel())        # fp32: weights + input + output, once each
 
     def lin_hook(m, inp, out):
         total['linear'] += 2 * m.in_features * m.out_features * (out.numel() // m.out_features)
+        total['bytes'] += 4 * (m.weight.numel() + inp[0].numel() + out.numel())
 
     def attn_hook(m, inp, kwargs, out):
         x = inp[0]
@@ -65,7 +67,11 @@ def sds_step_flops(image_size=512, batch_unet=2, ctx_tokens=77):
     u = _count(unet, lambda m: m(torch.empty(batch_unet, 9, lat, lat, device='meta'), torch.zeros(1, device='meta'),
                                  encoder_hidden_states=torch.empty(batch_unet, ctx_tokens, 768, device='meta')))
     e = _count(nn.Sequential(enc, quant), lambda m: m(torch.empty(1, 3, image_size, image_size, device='meta')))
+    ub, eb = u.pop('bytes'), e.pop('bytes')
     uf, ef = sum(u.values()), sum(e.values())
     return {'unet_forward': uf, 'vae_encoder_forward': ef, 'per_step': uf + 3 * ef,
             'breakdown': {'unet': u, 'vae_encoder': e},
+            # algorithmic HBM bytes: every convolution / linear layer reads its fp32 weights and input and writes its output
+            # once (normalisations, attention internals and elementwise glue not counted)
+            'bytes_per_step': ub + 3 * eb, 'unet_forward_bytes': ub, 'vae_encoder_forward_bytes': eb,
             'composition': '1 x UNet forward (batch 2) + 2 x VAE-encoder forward + 1 x VAE-encoder data-gradient pass'}

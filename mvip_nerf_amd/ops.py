@@ -185,11 +185,28 @@ STASH_FREE_FRACTION = 0.6          # of the currently free bytes, after the back
 _stash_live = {}                   # device index -> bytes of live stashes
 
 
+_FREE_CACHE = {}                   # device index -> (monotonic time, free bytes from the driver)
+
+
+def _device_free_bytes(device, ttl=0.25):
+    """hipMemGetInfo through torch, at most once per `ttl` seconds and device: the driver call costs milliseconds once tens
+    of GB are mapped (it turned a 54 ms training iteration into 75-94 ms of wall time with five stash allocations each;
+    tools/train_step_profile.py --after-hashgrid), and the budget is a fraction of the free memory, not an exact figure."""
+    import time
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    now = time.monotonic()
+    hit = _FREE_CACHE.get(key)
+    if hit is None or now - hit[0] > ttl:
+        hit = (now, torch.cuda.mem_get_info(device)[0])
+        _FREE_CACHE[key] = hit
+    return hit[1]
+
+
 def _stash_budget(device):
     env = _os.environ.get('MVIP_STASH_BUDGET_BYTES')
     if env is not None:
         return int(env)
-    free, _total = torch.cuda.mem_get_info(device)
+    free = _device_free_bytes(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
     ws_bytes = 0 if (device, BWD_TILE_POINTS) in _WORKSPACE else int(
         _lib.load().mvip_mlp_backward_workspace_bytes(BWD_TILE_POINTS))
