@@ -1,0 +1,45 @@
+"""HBM traffic of one SDS step per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv):
+usage: python tools/pmc_sds_traffic.py <fetch.csv> <write.csv> <dispatches_per_step_json> out.json
+FETCH_SIZE / WRITE_SIZE come in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE is doubled (the gfx950 correction of the
+same section: the counter sees 32-byte requests as half of what HBM moves).  The profiled program runs STEPS eager steps
+after its warm-up; the totals are divided by the dispatch count ratio to give bytes per step."""
+import collections
+import csv
+import json
+import sys
+
+fetch_csv, write_csv, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: [0.0, 0, 0])
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = r['Kernel_Name'][:100]
+        agg[k][0] += float(r['Counter_Value'])
+        if (k, r['Dispatch_Id']) not in seen:
+            seen.add((k, r['Dispatch_Id']))
+            agg[k][1] += 1
+            agg[k][2] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    return agg
+
+
+f, w = load(fetch_csv), load(write_csv)
+rows = []
+for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, [0])[0] + w.get(k, [0])[0])):
+    fk, wk = f.get(k, [0.0, 0, 0]), w.get(k, [0.0, 0, 0])
+    n = max(fk[1], wk[1], 1)
+    rows.append({'kernel': k, 'dispatches_per_step': round(n / steps, 1),
+                 'fetch_MB_per_step': round(2 * fk[0] * 1024 / 1e6 / steps, 2), 'write_MB_per_step': round(wk[0] * 1024 / 1e6 / steps, 2),
+                 'ms_per_step': round(max(fk[2], wk[2]) / 1e6 / steps, 3)})
+tot = sum(r['fetch_MB_per_step'] + r['write_MB_per_step'] for r in rows) * 1e6
+for r in rows:
+    ms = r['ms_per_step']
+    r['TB_per_s'] = round((r['fetch_MB_per_step'] + r['write_MB_per_step']) / 1e6 / (ms * 1e-3), 2) if ms else None
+json.dump({'hbm_bytes_per_step': tot, 'steps_profiled': steps,
+           'how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs, --kernel-trace only) over tools/sds_profile_steps.py; '
+                  'KB counters, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; eager steps (one dispatch per kernel node)',
+           'kernels': rows[:40]}, open(out, 'w'), indent=1)
+print('HBM bytes per step: %.2f GB' % (tot / 1e9))
+for r in rows[:14]:
+    print(r)
