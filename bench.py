@@ -573,7 +573,7 @@ def main():
             # (StableDiffusion.use_graphs defaults to True for the built-in networks; thread-local capture, so a live RCCL
             # communicator's watchdog thread does not disturb it) -- and the same step launch by launch
             n_sds = max(args.sds_steps, 3)
-            sds_times = timed_steps(sd, 1e-4, True, n_sds)
+            sds_times = timed_steps(sd, 1e-4, world == 1, n_sds)       # (eager next to a live multi-rank group, as the default is)
             dt_sds = float(np.median(sds_times)) * args.sds_steps
             ms_eager32 = float(np.median(timed_steps(sd, 1e-4, False, n_sds))) * 1e3
             # the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66) on the SAME hand-written kernels in their
@@ -588,7 +588,7 @@ def main():
                 except Exception as e:                            # reported, never fatal for the bench line
                     print(f'[bench] fp16-mode leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
                 torch.cuda.empty_cache()
-            sd.use_graphs = True
+            sd.use_graphs = world == 1
             opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                         text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                         colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
@@ -673,7 +673,8 @@ def main():
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
                              'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 relative)',
                              'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
-                             'mode': 'one captured hipGraph per (shape, prompt): the default of StableDiffusion for the built-in networks',
+                             'mode': ('one captured hipGraph per (shape, prompt): the default of StableDiffusion for the built-in networks'
+                                      if world == 1 else 'eager (the default next to a live multi-rank process group)'),
                              'ms_per_step_eager': ms_eager32,
                              'ms_per_step_fp16_hipgraph': ms_graph16, 'ms_per_step_fp16_eager': ms_eager16,
                              'fp16_what': "the reference's --fp16 mode on the same hand-written kernels, single fp16 product per "

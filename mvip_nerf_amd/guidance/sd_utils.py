@@ -221,6 +221,11 @@ class StableDiffusion(nn.Module):
         # library modules that may synchronise) keep the eager path unless asked.
         if use_graphs is None:
             use_graphs = builtin and torch.device(device).type == 'cuda'
+            # next to a live multi-rank process group the default stays eager: a capture beside RCCL's own threads and
+            # streams has not been exercised on hardware (the build boxes have one GPU); use_graphs=True forces it
+            import torch.distributed as dist
+            if use_graphs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                use_graphs = False
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
