@@ -185,19 +185,20 @@ STASH_FREE_FRACTION = 0.6          # of the currently free bytes, after the back
 _stash_live = {}                   # device index -> bytes of live stashes
 
 
-_FREE_CACHE = {}                   # device index -> (monotonic time, free bytes from the driver)
+_FREE_CACHE = {}                   # device index -> (bytes reserved by torch at query time, free bytes from the driver)
 
 
-def _device_free_bytes(device, ttl=0.25):
-    """hipMemGetInfo through torch, at most once per `ttl` seconds and device: the driver call costs milliseconds once tens
-    of GB are mapped (it turned a 54 ms training iteration into 75-94 ms of wall time with five stash allocations each;
-    tools/train_step_profile.py --after-hashgrid), and the budget is a fraction of the free memory, not an exact figure."""
-    import time
+def _device_free_bytes(device):
+    """hipMemGetInfo through torch, asked again only when torch's own reservation has changed since the last answer: the
+    driver call costs milliseconds once tens of GB are mapped (five stash allocations per iteration turned a 54 ms training
+    iteration into 75-94 ms of wall time: tools/train_step_profile.py --after-hashgrid), and between two queries the
+    device's free memory moves only when torch itself maps or unmaps memory -- which `memory_reserved` (a host-side counter)
+    shows.  (Another process on the device can still move it: the allocation itself is guarded, see _take_stash.)"""
     key = device.index if device.index is not None else torch.cuda.current_device()
-    now = time.monotonic()
+    reserved = torch.cuda.memory_reserved(device)
     hit = _FREE_CACHE.get(key)
-    if hit is None or now - hit[0] > ttl:
-        hit = (now, torch.cuda.mem_get_info(device)[0])
+    if hit is None or hit[0] != reserved:
+        hit = (reserved, torch.cuda.mem_get_info(device)[0])
         _FREE_CACHE[key] = hit
     return hit[1]
 

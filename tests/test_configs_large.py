@@ -136,6 +136,7 @@ def _config3_rank(rank, world, port, out):
 
 def test_config3_iteration_rgb_normal_colla_and_world2_twin(tmp_path, cuda):
     out = str(tmp_path)
+    torch.cuda.empty_cache()                      # earlier tests' cached blocks are not part of this iteration's footprint
     _config3_rank(0, 1, 0, out)
     for tag in ('stochastic', 'deterministic'):
         ref = torch.load(os.path.join(out, f'c3w1r0_{tag}.pt'))
@@ -176,6 +177,7 @@ def test_config4_full_guidance_replicas_share_nothing(tmp_path, cuda):
     processes, no process group): both finish, write their own checkpoints under their own basedir/expname, scene 0's
     result equals its solo run (losses and parameter checksum: nothing leaked between the two), and the scenes differ."""
     from mvip_nerf_amd.replicas import launch
+    torch.cuda.empty_cache()                      # this process's cached blocks are not the replicas' to work around
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
     solo_dir, pair_dir = str(tmp_path / 'solo'), str(tmp_path / 'pair')
     r = subprocess.run(_replica_cmd(0, solo_dir), env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
