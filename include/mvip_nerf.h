@@ -322,6 +322,16 @@ int64_t mvip_gemm_packed_bytes(int64_t M, int64_t K);
 int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t sm, int64_t sk, void *packed, void *stream);
 int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc, int64_t sp,
                               const float *scale2, void *xs, int prec, void *stream);
+/* The same planes for the 2x nearest-neighbour up-sampled image [N][C][2H][2W] of x [N][C][H][W] (Upsample2D of the UNet:
+ * F.interpolate(scale_factor=2, mode='nearest') in front of a 3x3 convolution), without materialising it. */
+int mvip_split_planes_upsample2(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, const float *scale2, void *xs,
+                                int prec, void *stream);
+/* Row softmax P = softmax(scale * S) over the last axis of S [rows][cols] (cols <= 8192) and its adjoint
+ * dS = scale * P * (dP - rowsum(dP * P)): the score matrix of AutoencoderKL's single-head mid-block attention inside
+ * vae.encode (DS_NeRF/guidance/sd_utils.py:207) and its data gradient. */
+int mvip_softmax_rows(const float *s, int64_t rows, int64_t cols, float scale, float *p, void *stream);
+int mvip_softmax_rows_backward(const float *p, const float *dp, int64_t rows, int64_t cols, float scale, float *ds,
+                               void *stream);
 /* General convolution as this GEMM -- the stride-2 down-samplers of the UNet and the VAE encoder and the layers with 3,
  * 4, 8 or 9 channels (conv_in, conv_out, quant_conv; DS_NeRF/guidance/sd_utils.py:207, :240), which do not fit the 3x3
  * stride-1 kernel's operand tiles:

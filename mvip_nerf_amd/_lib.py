@@ -93,6 +93,9 @@ _SIGNATURES = {
     'mvip_gemm_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_gemm_pack_a': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_split_planes_strided': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_split_planes_upsample2': (_int, [_c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_softmax_rows': (_int, [_c_f, _i64, _i64, _flt, _c_f, _c_f]),
+    'mvip_softmax_rows_backward': (_int, [_c_f, _c_f, _i64, _i64, _flt, _c_f, _c_f]),
     'mvip_gemm_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _c_f]),
     'mvip_gemm_geglu_f16x3': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _int, _c_f]),
     'mvip_im2col_split_planes': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64,

@@ -261,6 +261,37 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Nearest-neighbour 2x up-sampling folded into the plane writer (Upsample2D of the UNet, F.interpolate(scale_factor=2) in
+// front of a 3x3 convolution): output pixel (oy, ox) of the [2H, 2W] image reads x[oy / 2][ox / 2]; the up-sampled fp32
+// tensor never exists.  grid (ceil(4HW/256), N*C/16).
+__global__ void __launch_bounds__(256)
+cv_to_split_up2_kernel(const float *__restrict__ x, const float *__restrict__ scale2, int C, int H, int W,
+                       uint4 *__restrict__ xs, int prec) {
+    const int CK = C / 16;
+    const int ck = (int)(blockIdx.y % CK);
+    const int64_t n = blockIdx.y / CK;
+    const int64_t OHW = (int64_t)4 * H * W;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= OHW) return;
+    const int oy = (int)(p / (2 * W)), ox = (int)(p - (int64_t)oy * 2 * W);
+    const float s = scale2 ? scale2[0] : 1.f;
+    const float *xr = x + (n * C + (int64_t)ck * 16) * H * W + (int64_t)(oy >> 1) * W + (ox >> 1);
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = xr[(int64_t)c * H * W] * s;
+    uint4 *dst = xs + ((n * CK + ck) * 4) * OHW + p;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[kg * 8 + j];
+        uint4 hi, lo;
+        split8(t, hi, lo);
+        dst[(kg * 2 + 0) * OHW] = hi;
+        if (prec == 0) dst[(kg * 2 + 1) * OHW] = lo;
+    }
+}
+
 // ---- general convolution as a GEMM: the strided and the narrow-channel layers -----------------------------------
 // (the three stride-2 down-samplers of the UNet and of the VAE encoder, conv_in / conv_out with 3, 4, 8 or 9 channels,
 // quant_conv: DS_NeRF/guidance/sd_utils.py:207, :240 -- none fits the 3x3 stride-1 kernel's 16 / 32-channel operand tiles)
@@ -1397,6 +1428,17 @@ extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t H
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
     hipLaunchKernelGGL((cv_to_split_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
                        nullptr, nullptr, scale2, (int)C, HW, 1, (uint4 *)xs, C * HW, HW, (int64_t)1, prec);
+    return check_launch();
+}
+
+extern "C" int mvip_split_planes_upsample2(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, const float *scale2,
+                                           void *xs, int prec, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || H <= 0 || W <= 0 || H * W > (1 << 26) || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((4 * H * W + 255) / 256), (unsigned)(N * (C / 16)));
+    hipLaunchKernelGGL(cv_to_split_up2_kernel, grid, dim3(256), 0, as_stream(stream), x, scale2, (int)C, (int)H, (int)W,
+                       (uint4 *)xs, prec);
     return check_launch();
 }
 

@@ -192,3 +192,91 @@ extern "C" int mvip_sds_grad(const float *eps_uncond, const float *eps_cond, con
                        eps_uncond, eps_cond, noise, guidance_scale, w, n, accumulate, grad);
     return check_launch();
 }
+
+// ---- row softmax of the VAE mid-block attention (AutoencoderKL's single-head attention over 64 x 64 tokens inside
+// vae.encode, DS_NeRF/guidance/sd_utils.py:207): P[i][:] = softmax(scale * S[i][:]) and its adjoint
+// dS[i][j] = scale * P[i][j] * (dP[i][j] - sum_k dP[i][k] P[i][k]).  One workgroup per row, the row held in registers
+// (cols <= 256 * 32); maxima / sums by wave shuffles + one LDS exchange, in a fixed order (bit-reproducible).
+namespace mvip {
+
+__device__ __forceinline__ float sm_block_reduce(float v, bool is_max, float *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, 64); v = is_max ? fmaxf(v, t) : v + t; }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();                                 // sh may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) r = is_max ? fmaxf(r, sh[k]) : r + sh[k];
+    return r;
+}
+
+constexpr int SM_MAX_PER_THREAD = 32;
+
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float *__restrict__ s, int64_t cols, float scale,
+                                                           float *__restrict__ p) {
+    __shared__ float sh[4];
+    const float *sr = s + (int64_t)blockIdx.x * cols;
+    float *pr = p + (int64_t)blockIdx.x * cols;
+    float v[SM_MAX_PER_THREAD];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SM_MAX_PER_THREAD; ++k) {
+        const int64_t c = (int64_t)k * 256 + threadIdx.x;
+        v[k] = c < cols ? sr[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+    mx = sm_block_reduce(mx, true, sh);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAX_PER_THREAD; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }     // exp(-inf) = 0 beyond cols
+    sum = sm_block_reduce(sum, false, sh);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < SM_MAX_PER_THREAD; ++k) {
+        const int64_t c = (int64_t)k * 256 + threadIdx.x;
+        if (c < cols) pr[c] = v[k] * inv;
+    }
+}
+
+__global__ void __launch_bounds__(256) softmax_rows_backward_kernel(const float *__restrict__ p, const float *__restrict__ dp,
+                                                                    int64_t cols, float scale, float *__restrict__ ds) {
+    __shared__ float sh[4];
+    const int64_t r0 = (int64_t)blockIdx.x * cols;
+    float pv[SM_MAX_PER_THREAD], dv[SM_MAX_PER_THREAD];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SM_MAX_PER_THREAD; ++k) {
+        const int64_t c = (int64_t)k * 256 + threadIdx.x;
+        pv[k] = c < cols ? p[r0 + c] : 0.f;
+        dv[k] = c < cols ? dp[r0 + c] : 0.f;
+        dot += pv[k] * dv[k];
+    }
+    dot = sm_block_reduce(dot, false, sh);
+#pragma unroll
+    for (int k = 0; k < SM_MAX_PER_THREAD; ++k) {
+        const int64_t c = (int64_t)k * 256 + threadIdx.x;
+        if (c < cols) ds[r0 + c] = pv[k] * (dv[k] - dot) * scale;
+    }
+}
+
+}  // namespace mvip
+
+extern "C" int mvip_softmax_rows(const float *s, int64_t rows, int64_t cols, float scale, float *p, void *stream) {
+    if (rows < 0 || cols <= 0 || cols > 256 * mvip::SM_MAX_PER_THREAD || rows > 0x7fffffffLL) return MVIP_EINVAL;
+    if (rows == 0) return MVIP_OK;
+    if (!s || !p) return MVIP_EINVAL;
+    hipLaunchKernelGGL(mvip::softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, mvip::as_stream(stream), s, cols, scale, p);
+    return mvip::check_launch();
+}
+
+extern "C" int mvip_softmax_rows_backward(const float *p, const float *dp, int64_t rows, int64_t cols, float scale, float *ds,
+                                          void *stream) {
+    if (rows < 0 || cols <= 0 || cols > 256 * mvip::SM_MAX_PER_THREAD || rows > 0x7fffffffLL) return MVIP_EINVAL;
+    if (rows == 0) return MVIP_OK;
+    if (!p || !dp || !ds) return MVIP_EINVAL;
+    hipLaunchKernelGGL(mvip::softmax_rows_backward_kernel, dim3((unsigned)rows), dim3(256), 0, mvip::as_stream(stream), p, dp, cols,
+                       scale, ds);
+    return mvip::check_launch();
+}

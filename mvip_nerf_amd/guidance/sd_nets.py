@@ -203,11 +203,11 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
-        if x.is_cuda and USE_MFMA_CONV3X3 and not (torch.is_grad_enabled() and x.requires_grad):
+        if x.is_cuda and USE_MFMA_CONV3X3 and not (torch.is_grad_enabled() and x.requires_grad) and x.dim() == 4:
             from .. import ops
-            if ops.conv3x3_supported(self.conv, x):            # 1280 @ 32x32 and 640 @ 64x64 in the UNet
-                return ops.conv3x3_plain(x, self.conv)
+            if ops.conv3x3_supported(self.conv, x, hw=(2 * x.shape[2], 2 * x.shape[3])):    # 1280 @ 32x32, 640 @ 64x64 in the UNet
+                return ops.conv3x3_plain(x, self.conv, upsample2=True)   # the up-sampling is folded into the plane writer
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
         return conv_any(self.conv, x)
 
 

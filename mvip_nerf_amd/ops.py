@@ -562,17 +562,19 @@ def group_norm(x, weight, bias, groups, eps=1e-5, silu=False):
 
 # 3x3 convolution of the SDS networks (split-precision implicit GEMM, csrc/conv3x3.hip) ---------------------
 
-def conv3x3_supported(conv, x):
-    """True when `conv` (an nn.Conv2d) applied to x [N, Cin, H, W] fp32 can run on the HIP kernel."""
+def conv3x3_supported(conv, x, hw=None):
+    """True when `conv` (an nn.Conv2d) applied to x [N, Cin, H, W] fp32 can run on the HIP kernel (hw = (H, W) overrides
+    x's spatial size: the up-sampled image of Upsample2D, which is never materialised)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         return False
     if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32):
         return False
     lib = _lib.load()
-    ok = bool(lib.mvip_conv3x3_supported(conv.out_channels, conv.in_channels, x.shape[2], x.shape[3]))
+    H, W = (x.shape[2], x.shape[3]) if hw is None else hw
+    ok = bool(lib.mvip_conv3x3_supported(conv.out_channels, conv.in_channels, H, W))
     if ok and x.requires_grad and torch.is_grad_enabled():        # the data gradient runs the transposed operator
-        ok = bool(lib.mvip_conv3x3_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]))
+        ok = bool(lib.mvip_conv3x3_supported(conv.in_channels, conv.out_channels, H, W))
     return ok
 
 
@@ -705,16 +707,23 @@ def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, 
          ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), _prec(), stream())
 
 
-def conv3x3_plain(x, conv):
+def conv3x3_plain(x, conv, upsample2=False):
     """conv(x) (+ bias) for a 3x3 / stride 1 / padding 1 convolution on the split-precision MFMA kernel, without a
     preceding GroupNorm and without autograd: the UNet's up-sampling convolutions (the UNet runs under no_grad).  The
-    input is scaled by a power of two from its absmax before the fp16 hi/lo split, as the data gradient is."""
+    input is scaled by a power of two from its absmax before the fp16 hi/lo split, as the data gradient is.
+    upsample2: the convolution runs on the 2x nearest-neighbour up-sampled image, which is never materialised (the plane
+    writer reads x[oy / 2][ox / 2]; the absolute maximum is that of x itself)."""
     xc = _f32c(x.detach())
     N, C, H, W = xc.shape
     Cout, dev = conv.out_channels, xc.device
     scale2 = unit_scale(dev) if FORWARD_UNIT_SCALE else absmax_scale(xc)
-    xs = _split_buffer(N, C, H * W, dev)
-    call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
+    if upsample2:
+        xs = _split_buffer(N, C, 4 * H * W, dev)
+        call('mvip_split_planes_upsample2', ptr(xc), N, C, H, W, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
+        H, W = 2 * H, 2 * W
+    else:
+        xs = _split_buffer(N, C, H * W, dev)
+        call('mvip_split_planes', ptr(xc), N, C, H * W, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
     y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
     bias = None if conv.bias is None else _f32c(conv.bias.detach())
     _conv3x3_launch(xs, _conv_packed(conv, False), bias, None, None, scale2, N, C, Cout, H, W, y)
@@ -993,7 +1002,7 @@ class _VAEAttention(torch.autograd.Function):
             q, k, v = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:]
             ks, s2 = _scaled_planes(k, 1, C, L, 0, L, 1)
             S = gemm_f16x3(ks, gemm_pack_a(q, L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]        # S[i][j] = q_i . k_j
-            Pm = torch.softmax(S * (C ** -0.5), -1)
+            Pm = softmax_rows(S, C ** -0.5)
             del S
             pts, s2 = _scaled_planes(Pm, 1, L, L, 0, 1, L)                                    # X[k=j][p=i] = P[i][j]
             O[n] = gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]
@@ -1022,7 +1031,7 @@ class _VAEAttention(torch.autograd.Function):
             dqkv[n, 2 * C:] = gemm_f16x3(ps, gemm_pack_a(dO[n], C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]      # dV
             vs, s2 = _scaled_planes(v, 1, C, L, 0, L, 1)
             dP = gemm_f16x3(vs, gemm_pack_a(dO[n], L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]    # dP[i][j] = dO_i . v_j
-            dS = Pm * (dP - (dP * Pm).sum(-1, keepdim=True)) * (C ** -0.5)
+            dS = softmax_rows_backward(Pm, dP, C ** -0.5)
             del dP
             s2 = absmax_scale(dS)
             dst = split_planes_strided(dS, 1, L, L, 0, 1, L, s2)                               # X[k=j][p=i] = dS[i][j]
@@ -1446,3 +1455,19 @@ def render_fine_fused(packed16, rows, z, noise, white_bkgd, need_alpha=False, wa
     call('mvip_render_fine_fused', ptr(packed16), ptr(rows), ptr(z), B, ptr(nz), COMP_WHITE if white_bkgd else 0, ptr(raw),
          ptr(rgb), ptr(disp), ptr(acc), ptr(depth), ptr(weights), ptr(alpha), stream())
     return rgb, disp, acc, weights, depth, alpha, raw
+
+
+def softmax_rows(S, scale):
+    """softmax(scale * S, -1) of a 2-D fp32 matrix on the HIP row kernel (the VAE mid-block attention's scores)."""
+    Sc = _f32c(S)
+    P = torch.empty_like(Sc)
+    call('mvip_softmax_rows', ptr(Sc), Sc.shape[0], Sc.shape[1], float(scale), ptr(P), stream())
+    return P
+
+
+def softmax_rows_backward(P, dP, scale):
+    """scale * P * (dP - rowsum(dP * P)): the adjoint of softmax_rows."""
+    Pc, dc = _f32c(P), _f32c(dP)
+    dS = torch.empty_like(Pc)
+    call('mvip_softmax_rows_backward', ptr(Pc), ptr(dc), Pc.shape[0], Pc.shape[1], float(scale), ptr(dS), stream())
+    return dS

@@ -609,7 +609,7 @@ def test_sds_step_launches_no_library_contraction(cuda, fp16):
     assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
     names = [e.key for e in prof.key_averages()]
     banned = ('igemm', 'miopen', 'naive_conv', 'Im2d2Col', 'Col2Im', 'batched_transpose', 'Cijk_', 'attn_fwd', 'ck::',
-              'grouped_conv', 'MIOpen', 'gemm_kernel', 'softmax_warp')
+              'grouped_conv', 'MIOpen', 'gemm_kernel', 'softmax_warp', 'SoftMax', 'upsample_nearest')
     assert not [n for n in names if any(b in n for b in banned)], [n for n in names if any(b in n for b in banned)]
     for must in ('conv3x3_f16x3_kernel', 'gemm5_f16x3_kernel', 'attn_f16x3_kernel', 'cv_im2col_split_kernel',
                  'resize_bilinear_fwd_kernel', 'resize_bilinear_bwd_kernel'):
@@ -707,3 +707,32 @@ def test_fp16_mode_kernels_vs_fp64(cuda):
     y.sum().backward()
     assert float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.abs().max()) < 2e-3
     assert float((xd.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()) < 2e-3
+
+
+def test_softmax_rows_and_upsample_fold(cuda):
+    """The last stock torch compute ops of the SDS step, replaced: the VAE mid-block attention's row softmax
+    and its adjoint (csrc/sds_elem.hip) vs fp64, and the nearest-neighbour up-sampling folded into the plane writer vs the
+    materialised F.interpolate + convolution (bit-identical: the same values reach the same kernel)."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import Upsample2D
+    gen = torch.Generator().manual_seed(9)
+    for rows, cols in ((64, 4096), (7, 1000), (3, 8192), (5, 1)):
+        S = torch.randn(rows, cols, generator=gen) * 40.0
+        dP = torch.randn(rows, cols, generator=gen)
+        Sr = S.double().requires_grad_(True)
+        Pr = torch.softmax(Sr * 0.044, -1)
+        (Pr * dP.double()).sum().backward()
+        P = ops.softmax_rows(S.to(cuda), 0.044)
+        np.testing.assert_allclose(N(P), Pr.detach().float().numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(N(P.sum(-1)), np.ones(rows, np.float32), rtol=0, atol=2e-6)
+        dS = ops.softmax_rows_backward(P, dP.to(cuda), 0.044)
+        np.testing.assert_allclose(N(dS), Sr.grad.float().numpy(), rtol=0, atol=3e-6 * float(Sr.grad.abs().max()))
+    up = Upsample2D(64).to(cuda)
+    for p in up.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 64, 8, 16, generator=gen).to(cuda)
+    with torch.no_grad():
+        folded = up(x)
+        xi = torch.nn.functional.interpolate(x, scale_factor=2.0, mode='nearest')
+        mat = ops.conv3x3_plain(xi, up.conv)
+    assert folded.shape == (2, 64, 16, 32) and torch.equal(folded, mat)
