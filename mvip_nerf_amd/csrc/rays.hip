@@ -115,21 +115,26 @@ __global__ void stratified_z4_kernel(const float *__restrict__ rows, int ncols, 
     *reinterpret_cast<float4 *>(z + r * S + s0) = out;
 }
 
-// run_nerf_helpers.py:27-52: channel c<3: x[c]; else m=c-3: octave m/6, fn (m%6)/3, dim m%3
+// run_nerf_helpers.py:27-52: channel c<3: x[c]; else m=c-3: octave m/6, fn (m%6)/3, dim m%3.
+// One thread per (point, slot): slot 0 copies the three coordinates, slot 1 + 3 oct + dim evaluates sin AND cos of
+// x[dim] * 2^oct (one argument, one range reduction) and writes channels 3 + 6 oct + dim and 6 + 6 oct + dim -- a wave's two
+// store instructions together fill whole lines of the point's 4 (3 + 6 L)-byte row.  (One thread per output element with a
+// 63-way division and a separate sinf / cosf each ran at 0.19 of HBM: profiles/r2_micro_hbm_kernels.jsonl.)
 __global__ void posenc_kernel(const float *__restrict__ x, int64_t N, int L, float *__restrict__ y) {
-    const int C = 3 + 6 * L;
+    const int SL = 1 + 3 * L, C = 3 + 6 * L;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int64_t n = i / C;
-    const int c = (int)(i % C);
-    float out;
-    if (c < 3) out = x[n * 3 + c];
-    else {
-        const int m = c - 3, oct = m / 6, rem = m % 6;
-        const float a = x[n * 3 + rem % 3] * (float)(1 << oct);
-        out = rem < 3 ? sinf(a) : cosf(a);
+    if (i >= N * SL) return;
+    const int64_t n = i / SL;
+    const int slot = (int)(i - n * SL);
+    float *yr = y + n * C;
+    if (slot == 0) {
+        yr[0] = x[n * 3]; yr[1] = x[n * 3 + 1]; yr[2] = x[n * 3 + 2];
+        return;
     }
-    y[i] = out;
+    const int m = slot - 1, oct = m / 3, dim = m - 3 * oct;
+    const float a = x[n * 3 + dim] * (float)(1 << oct);
+    yr[3 + 6 * oct + dim] = sinf(a);
+    yr[6 + 6 * oct + dim] = cosf(a);
 }
 
 static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
@@ -185,7 +190,7 @@ extern "C" int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S,
 extern "C" int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream) {
     if (N < 0 || L < 0 || L > 16 || (N > 0 && (!x || !y))) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
-    hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(N * (3 + 6 * L), 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(N * (1 + 3 * L), 256)), dim3(256), 0, as_stream(stream),
                        x, N, L, y);
     return check_launch();
 }
