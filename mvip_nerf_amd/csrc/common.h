@@ -59,4 +59,66 @@ __device__ __forceinline__ float wave_incl_suffix_sum(float v) {
     return v;
 }
 
+
+// ---- the same primitives on DPP (data-parallel primitives: cross-lane operands of ordinary VALU instructions, ~8 cycles)
+// instead of ds_bpermute shuffles (LDS crossbar, ~100 cycles of dependent latency each).  gfx9 controls: row_shr:n = 0x110+n,
+// row_ror:n = 0x120+n, wave_shl:1 = 0x130, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143, quad_perm = 0x00..0xff.
+// A lane whose DPP source does not exist (or whose row / bank is masked off) keeps `old`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const long long o = __builtin_bit_cast(long long, old), x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// lane l <- lane l - 1 (lane 0 <- first) / lane l <- lane l + 1 (lane 63 <- last)
+__device__ __forceinline__ float dpp_from_prev(float v, float first) { return dpp_f32<0x138>(first, v); }
+__device__ __forceinline__ float dpp_from_next(float v, float last) { return dpp_f32<0x130>(last, v); }
+
+// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then the row totals by row_bcast:15 (into
+// rows 1 and 3) and row_bcast:31 (into rows 2 and 3) -- six dependent VALU steps
+template <class T, class Dpp>
+__device__ __forceinline__ T dpp_incl_scan_add(T v, Dpp) {
+    v += Dpp::template f<0x111>((T)0, v);
+    v += Dpp::template f<0x112>((T)0, v);
+    v += Dpp::template f<0x114>((T)0, v);
+    v += Dpp::template f<0x118>((T)0, v);
+    v += Dpp::template f<0x142, 0xa>((T)0, v);
+    v += Dpp::template f<0x143, 0xc>((T)0, v);
+    return v;
+}
+struct DppF32 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ float f(float o, float v) { return dpp_f32<C, R, B>(o, v); } };
+struct DppF64 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ double f(double o, double v) { return dpp_f64<C, R, B>(o, v); } };
+__device__ __forceinline__ float dpp_incl_sum(float v) { return dpp_incl_scan_add<float>(v, DppF32{}); }
+__device__ __forceinline__ double dpp_incl_sum(double v) { return dpp_incl_scan_add<double>(v, DppF64{}); }
+// total over the wave, in every lane (the scan's last lane, read back through a scalar register)
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dpp_incl_sum(v)), 63));
+}
+__device__ __forceinline__ double dpp_wave_sum(double v) {
+    const long long t = __builtin_bit_cast(long long, dpp_incl_sum(v));
+    const int lo = __builtin_amdgcn_readlane((int)t, 63), hi = __builtin_amdgcn_readlane((int)(t >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// value of lane (l ^ J) for J a power of two: quad permutes, two masked row shifts (4), a row rotation (8), ds_swizzle (16),
+// the half-wave swap (32)
+template <int J>
+__device__ __forceinline__ float dpp_xor(float v) {
+    if constexpr (J == 1) return dpp_f32<0xB1>(v, v);                       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_f32<0x4E>(v, v);                  // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return dpp_f32<0x114, 0xf, 0xa>(dpp_f32<0x104, 0xf, 0x5>(v, v), v);   // banks 0,2 <- +4; banks 1,3 <- -4
+    else if constexpr (J == 8) return dpp_f32<0x128>(v, v);                 // row_ror:8
+    else if constexpr (J == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1f));
+    else {
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // a = {lo, lo}, b = {hi, hi}
+        return (threadIdx.x & 32) ? a : b;
+    }
+}
+
 }  // namespace mvip

@@ -22,7 +22,7 @@ __device__ __forceinline__ float strided_get(const float (&v)[IT], int e) {
 // bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
 // Produces samples (strided) and inds; cdf_out strided (nb entries).
 // Up to 64 bins (the reference configuration: 63 midpoints of 64 coarse samples): everything in one register
-// per lane.  The normaliser is an fp64 butterfly sum, the CDF an fp64 Hillis-Steele scan rounded to fp32 per
+// per lane.  The normaliser is an fp64 wave sum, the CDF an fp64 wave scan (DPP row operations) rounded to fp32 per
 // entry (torch's CPU cumsum accumulates in fp64 in index order; a different summation ORDER changes the fp64
 // value by ~1e-16 relative, i.e. the rounded fp32 entry in ~1 of 1e8 cases), and searchsorted(right=True) is a
 // six-step binary search on cross-lane reads of the sorted CDF.  ~150 instructions per ray instead of ~2000.
@@ -33,18 +33,15 @@ __device__ __forceinline__ bool inverse_cdf_fast(const float bins, const float w
     const int l = lane_id();
     const int nw = nb - 1;
     const float w5 = wts + 1e-5f;
-    double tot = l < nw ? (double)w5 : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    // sums and scans on DPP row operations (common.h): six dependent VALU steps each instead of six ds_bpermute round trips
+    // of two registers -- this kernel is bound by the latency of its dependent cross-lane chain, not by bandwidth
+    const double tot = dpp_wave_sum(l < nw ? (double)w5 : 0.0);
     const float total = (float)tot;
     const float pdf = l < nw ? w5 / total : 0.f;
     if (__any(pdf < 0.f)) return false;
-    double run = (double)pdf;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(run, o, 64); if (l >= o) run += t; }
+    const double run = dpp_incl_sum((double)pdf);
     const float incl = (float)run;                              // cdf[l + 1]
-    const float up = __shfl_up(incl, 1, 64);
-    const float cdf = l == 0 ? 0.f : up;                        // cdf[l], valid for l < nb
+    const float cdf = dpp_from_prev(incl, 0.f);                 // cdf[l], valid for l < nb (cdf[0] = 0)
     const float key = l < nb ? cdf : INFINITY;
     int cnt = 0;                                                // #{k < nb : cdf[k] <= u}
 #pragma unroll
@@ -159,6 +156,27 @@ __device__ __forceinline__ void bitonic_sort(float (&v)[M]) {
     }
 }
 
+// Bitonic sort of ONE value per lane (64 values), ascending: the partner exchanges on DPP / swizzle / half-wave swap
+// (common.h::dpp_xor) instead of 21 ds_bpermute shuffles.
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step64(float &v, int l) {
+    const float other = dpp_xor<J>(v);
+    const bool up = (l & K) == 0, lower = (l & J) == 0;
+    const float mn = fminf(v, other), mx = fmaxf(v, other);
+    v = (lower == up) ? mn : mx;
+}
+__device__ __forceinline__ void bitonic_sort64(float &v) {
+    const int l = lane_id();
+    bitonic_step64<2, 1>(v, l);
+    bitonic_step64<4, 2>(v, l); bitonic_step64<4, 1>(v, l);
+    bitonic_step64<8, 4>(v, l); bitonic_step64<8, 2>(v, l); bitonic_step64<8, 1>(v, l);
+    bitonic_step64<16, 8>(v, l); bitonic_step64<16, 4>(v, l); bitonic_step64<16, 2>(v, l); bitonic_step64<16, 1>(v, l);
+    bitonic_step64<32, 16>(v, l); bitonic_step64<32, 8>(v, l); bitonic_step64<32, 4>(v, l); bitonic_step64<32, 2>(v, l);
+    bitonic_step64<32, 1>(v, l);
+    bitonic_step64<64, 32>(v, l); bitonic_step64<64, 16>(v, l); bitonic_step64<64, 8>(v, l); bitonic_step64<64, 4>(v, l);
+    bitonic_step64<64, 2>(v, l); bitonic_step64<64, 1>(v, l);
+}
+
 // #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
 // +inf): six binary-search steps on cross-lane reads + one probe for the count 64.
 template <bool STRICT>
@@ -184,13 +202,11 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
     const int l = lane_id();
     const float a_key = l < na ? a : INFINITY;
     float b_key = l < nb ? b : INFINITY;
-    const float a_next = __shfl_down(a_key, 1, 64), b_next = __shfl_down(b_key, 1, 64);
+    const float a_next = dpp_from_next(a_key, a_key), b_next = dpp_from_next(b_key, b_key);
     if (__any(l < 63 && a_next < a_key)) return false;
     if (__any(l < 63 && b_next < b_key)) {
         if (!b_may_be_unsorted) return false;
-        float v[1] = {b_key};                                    // random u: sort the 64 new samples (21 stages)
-        bitonic_sort<1>(v);
-        b_key = v[0];
+        bitonic_sort64(b_key);                                   // random u: sort the 64 new samples (21 stages)
     }
     if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
     // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
@@ -218,9 +234,13 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
     // mids[e] = .5 * (z[e+1] + z[e])
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        float nxt = __shfl_down(zc[i], 1, 64);
-        const float wrap = __shfl(zc[(i + 1) % IT], 0, 64);      // all lanes take part in the shuffle
-        if (l == 63) nxt = (i + 1 < IT) ? wrap : 0.f;
+        float nxt;
+        if constexpr (IT == 1) nxt = dpp_from_next(zc[0], 0.f);
+        else {
+            nxt = __shfl_down(zc[i], 1, 64);
+            const float wrap = __shfl(zc[(i + 1) % IT], 0, 64);  // all lanes take part in the shuffle
+            if (l == 63) nxt = (i + 1 < IT) ? wrap : 0.f;
+        }
         bins[i] = .5f * (nxt + zc[i]);
     }
     inverse_cdf<IT>(bins, wts, nb, uu, Nf, smp, inds, cdf);
@@ -236,14 +256,14 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
         if (cdf_out && e < nb) cdf_out[ray * nb + e] = cdf[i];
     }
     // population std of the new samples (torch.std(unbiased=False))
-    const float mean = wave_sum(s1) / (float)Nf;
+    const float mean = dpp_wave_sum(s1) / (float)Nf;
     float s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int e = i * 64 + l;
         if (e < Nf) { const float d = smp[i] - mean; s2 += d * d; }
     }
-    s2 = wave_sum(s2);
+    s2 = dpp_wave_sum(s2);
     if (l == 0) z_std[ray] = sqrtf(s2 / (float)Nf);
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
