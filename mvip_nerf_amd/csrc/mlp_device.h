@@ -262,13 +262,29 @@ __device__ __forceinline__ f32x16 load_tile(const float *__restrict__ block, int
     return t;
 }
 
+__device__ __forceinline__ unsigned short *mask_slot(float *base, int mi, int64_t n_pt, int64_t pt, int lane) {
+    return reinterpret_cast<unsigned short *>(base + ((int64_t)(79 + (mi >> 5)) * n_pt + pt) * TILE_FLOATS + (mi & 31) * 32) + lane;
+}
+__device__ __forceinline__ unsigned tile_sign_mask(const f32x16 &t) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (t[r] > 0.f ? 1u : 0u) << r;
+    return m;
+}
+
 // row-tile indices of the activation stash (forward, STASH=true) ...
 constexpr int AT_H = 0;        // h_l at 8l .. 8l+7, l = 0..7
 constexpr int AT_FEAT = 64;    // feature_linear output (no activation)
 constexpr int AT_V = 72;       // view-branch hidden (4 tiles)
 constexpr int AT_EMB = 76;     // encoded point (2 tiles, 63 real channels)
 constexpr int AT_EDIR = 78;    // encoded direction (1 tile, 27 real channels)
-constexpr int AT_TILES = 79;
+// ReLU SIGN masks of the 64 trunk tiles (mask index = tile) and the 4 view-branch tiles (64 + t): one bit per (unit, point),
+// 16 bits per lane = 128 B per tile and 32 points instead of the tile's 4 KB.  The split-precision delta kernel needs nothing
+// else of these activations (relu'(h) = [h > 0]); its reads were 9.7 KB per point, half of that kernel's HBM traffic.
+// Written by the split-precision stash forward only; 32 mask entries (32 floats each) per 1024-float block.
+constexpr int AT_MASK = 79;
+constexpr int AT_MASK_TILES = 3;          // ceil(68 / 32)
+constexpr int AT_TILES = AT_MASK + AT_MASK_TILES;
 // ... and of the pre-activation-gradient stash written by the delta kernel
 constexpr int GT_G = 0;        // G_l at 8l .. 8l+7
 constexpr int GT_F = 64;       // grad wrt feature
