@@ -267,7 +267,20 @@ int mvip_groupnorm_forward(const void *x, const void *gamma, const void *beta, i
 int mvip_groupnorm_backward(const void *x, const void *dy, const void *gamma, const void *beta,
                             const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
                             int silu, int dtype, void *dx, void *workspace, void *stream);
-/* statistics only (mean, rstd [N, G]); the normalised tensor is then produced by another kernel */
+/* The same backward with the two passes that used to follow it folded in (the VAE encoder's data-gradient chain,
+ * vae.encode under autograd at DS_NeRF/guidance/sd_utils.py:207): dx = backward(...) + dx_add (dx_add [N, C, HW] or NULL: the
+ * gradient arriving over a ResNet block's identity shortcut, which autograd would add in a separate pass), and
+ * maxima[mvip_groupnorm_backward_maxima(N, C, HW)] (or NULL) receives one max|dx| per workgroup (plain stores; NaN / Inf
+ * skipped as mvip_absmax_scale skips them).  mvip_absmax_scale_from_maxima turns them into the scale2 = {s, 1/s} that
+ * mvip_absmax_scale(dx) would compute -- the same power of two, without re-reading dx. */
+int64_t mvip_groupnorm_backward_maxima(int64_t N, int64_t C, int64_t HW);
+int mvip_groupnorm_backward_fused(const void *x, const void *dy, const void *gamma, const void *beta,
+                                  const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
+                                  int silu, int dtype, const void *dx_add, void *dx, float *maxima, void *workspace,
+                                  void *stream);
+int mvip_absmax_scale_from_maxima(const float *maxima, int64_t count, float *scale2, void *stream);
+/* statistics only (mean, rstd [N, G]); the normalised tensor is then produced by another kernel.  mean == rstd == NULL:
+ * only the fp64 moment partials are left in `workspace`, for mvip_groupnorm_split_planes_moments. */
 int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G, float eps, int dtype,
                          float *mean, float *rstd, void *workspace, void *stream);
 
@@ -303,6 +316,13 @@ int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const fl
 int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
                                 const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
                                 int prec, void *stream);
+/* mvip_groupnorm_split_planes reading the statistics from the moment partials of mvip_groupnorm_stats(mean = rstd = NULL)
+ * (`moments` = that call's workspace): every workgroup reduces the partials of the <= 5 groups its 16 channels touch in
+ * the order mvip_groupnorm_stats itself uses, so the planes are bit-identical -- one launch less per GroupNorm when
+ * mean / rstd are not kept for a backward.  C / G >= 4. */
+int mvip_groupnorm_split_planes_moments(const float *x, const float *gamma, const float *beta, const void *moments,
+                                        float eps, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
+                                        int prec, void *stream);
 int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, int prec, void *stream);

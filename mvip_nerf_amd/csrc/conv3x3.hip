@@ -214,15 +214,48 @@ template <bool GN, bool SILU>
 __global__ void __launch_bounds__(256)
 cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ scale2,
-                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp, int prec) {
+                   int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp, int prec,
+                   const double *__restrict__ part = nullptr, int chunks = 0, float eps = 0.f) {
     __shared__ float pa[16], pb[16], pm[16];
     const int CK = C / 16;
     const int ck = (int)(blockIdx.y % CK);
     const int64_t n = blockIdx.y / CK;
     if (GN) {
-        if (threadIdx.x < 16) {
+        const int G = C / cpg;
+        if (part) {
+            // Statistics straight from the moment partials of gn_moments_kernel (csrc/group_norm.hip): each of the <= 5
+            // groups this block's 16 channels touch is summed by one wave in gn_finalize_kernel's order (lane-strided,
+            // then the xor tree), so mean / rstd are bit-identical to that kernel's -- whose launch this saves when
+            // nobody else needs them (the no-grad forwards: the whole UNet and the masked-image encode).
+            __shared__ float gmean[8], grstd[8];
+            const int g0 = (ck * 16) / cpg, g1 = (ck * 16 + 15) / cpg;
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            for (int gi = wave; gi <= g1 - g0; gi += 4) {
+                const int64_t pbase = (n * C + (int64_t)(g0 + gi) * cpg) * chunks;
+                const int P = cpg * chunks;
+                double sm = 0.0, q = 0.0;
+                for (int i = lane; i < P; i += 64) { sm += part[(pbase + i) * 2]; q += part[(pbase + i) * 2 + 1]; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+                if (lane == 0) {
+                    const double m = (double)cpg * (double)HW;
+                    const double mu = sm / m;
+                    double var = q / m - mu * mu;
+                    if (var < 0.0) var = 0.0;
+                    gmean[gi] = (float)mu;
+                    grstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 16) {
+                const int c = ck * 16 + threadIdx.x;
+                const int gi = c / cpg - g0;
+                pm[threadIdx.x] = gmean[gi];
+                pa[threadIdx.x] = grstd[gi] * (gamma ? gamma[c] : 1.f);
+                pb[threadIdx.x] = beta ? beta[c] : 0.f;
+            }
+        } else if (threadIdx.x < 16) {
             const int c = ck * 16 + threadIdx.x;
-            const int G = C / cpg;
             const int g = c / cpg;
             pm[threadIdx.x] = mean[n * G + g];
             pa[threadIdx.x] = rstd[n * G + g] * (gamma ? gamma[c] : 1.f);
@@ -1495,6 +1528,25 @@ extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, c
     else
         hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, mean,
                            rstd, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec);
+    return check_launch();
+}
+
+extern "C" int mvip_groupnorm_split_planes_moments(const float *x, const float *gamma, const float *beta,
+                                                   const void *moments, float eps, int64_t N, int64_t C, int64_t HW, int G,
+                                                   int silu, void *xs, int prec, void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N == 0 || HW == 0) return MVIP_OK;
+    if (!x || !xs || !moments || N * (C / 16) > 65535 || C / G < 4) return MVIP_EINVAL;          // <= 5 groups per 16 channels
+    const int chunks = (int)(mvip_groupnorm_workspace_bytes(1, 1, HW) / 16);
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
+    if (silu)
+        hipLaunchKernelGGL((cv_to_split_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, nullptr,
+                           nullptr, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec,
+                           (const double *)moments, chunks, eps);
+    else
+        hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, nullptr,
+                           nullptr, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec,
+                           (const double *)moments, chunks, eps);
     return check_launch();
 }
 

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(GN_THREADS)
 gn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ gamma,
                     const T *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ rstd,
                     const double *__restrict__ part, int C, int64_t HW, int cpg, int chunks, int64_t chunk_elems,
-                    T *__restrict__ dx) {
+                    T *__restrict__ dx, const T *__restrict__ dx_add, float *__restrict__ pmax) {
     const int64_t row = blockIdx.y;
     const int j = blockIdx.x;
     const int c = (int)(row % C);
@@ -256,10 +256,13 @@ gn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy, const T *
     const int64_t hi = (lo + chunk_elems < HW) ? lo + chunk_elems : HW;
     const T *xr = x + row * HW, *dr = dy + row * HW;
     T *or_ = dx + row * HW;
+    const T *ar = dx_add ? dx_add + row * HW : nullptr;
+    float mx = 0.f;
     for (int64_t i = lo + (int64_t)threadIdx.x * V; i < hi; i += (int64_t)GN_THREADS * V) {
-        float v[V], d[V];
+        float v[V], d[V], e[V];
         load_vals<T, V>(xr + i, v);
         load_vals<T, V>(dr + i, d);
+        if (ar) load_vals<T, V>(ar + i, e);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float dz = d[k];
@@ -267,8 +270,44 @@ gn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy, const T *
             const float dh = dz * gm;
             const float xh = (v[k] - mu) * rs;
             d[k] = rs * (dh - m1 - xh * m2);
+            if (ar) d[k] += e[k];
+            const float ab = fabsf(d[k]);
+            mx = (ab == ab && ab < 3.0e38f) ? fmaxf(mx, ab) : mx;           // the filter of cv_absmax_scale_kernel
         }
         store_vals<T, V>(or_ + i, d);
+    }
+    if (pmax) {                  // this workgroup's maximum of |dx|: one plain store, no atomics, no fence (see the header note)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        __shared__ float wm[GN_THREADS / 64];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) pmax[row * chunks + j] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    }
+}
+
+// scale2 = {s, 1/s} from per-workgroup maxima (one workgroup; the power-of-two rule of cv_scale_kernel in conv3x3.hip)
+__global__ void __launch_bounds__(256) gn_pmax_scale_kernel(const float *__restrict__ pmax, int64_t count, float *__restrict__ scale2) {
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += 256) m = fmaxf(m, pmax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        float sc = 1.f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);
+            int k = 10 - e;
+            if (k > 60) k = 60;
+            if (k < -60) k = -60;
+            sc = ldexpf(1.f, k);
+        }
+        scale2[0] = sc;
+        scale2[1] = 1.f / sc;
     }
 }
 
@@ -294,7 +333,7 @@ static int gn_forward_t(const void *x, const void *gamma, const void *beta, int6
 template <typename T, int V>
 static int gn_backward_t(const void *x, const void *dy, const void *gamma, const void *beta, const float *mean,
                          const float *rstd, int64_t N, int C, int64_t HW, int G, int silu, void *dx, double *ws,
-                         hipStream_t st) {
+                         const void *dx_add, float *pmax, hipStream_t st) {
     const GnPlan p = gn_plan(HW);
     const dim3 grid((unsigned)p.chunks, (unsigned)(N * C));
     const int cpg = C / G;
@@ -304,14 +343,14 @@ static int gn_backward_t(const void *x, const void *dy, const void *gamma, const
                            p.chunk_elems, ws);
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V, true>), grid, dim3(GN_THREADS), 0, st, (const T *)x,
                            (const T *)dy, (const T *)gamma, (const T *)beta, mean, rstd, ws, C, HW, cpg, p.chunks,
-                           p.chunk_elems, (T *)dx);
+                           p.chunk_elems, (T *)dx, (const T *)dx_add, pmax);
     } else {
         hipLaunchKernelGGL((gn_bwd_partials_kernel<T, V, false>), grid, dim3(GN_THREADS), 0, st, (const T *)x,
                            (const T *)dy, (const T *)gamma, (const T *)beta, mean, rstd, C, HW, cpg, p.chunks,
                            p.chunk_elems, ws);
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V, false>), grid, dim3(GN_THREADS), 0, st, (const T *)x,
                            (const T *)dy, (const T *)gamma, (const T *)beta, mean, rstd, ws, C, HW, cpg, p.chunks,
-                           p.chunk_elems, (T *)dx);
+                           p.chunk_elems, (T *)dx, (const T *)dx_add, pmax);
     }
     return check_launch();
 }
@@ -342,7 +381,7 @@ extern "C" int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t
     int rc = gn_check(N, C, HW, G, dtype);
     if (rc != MVIP_OK) return rc;
     if (N == 0 || HW == 0) return MVIP_OK;
-    if (!x || !mean || !rstd || !workspace) return MVIP_EINVAL;
+    if (!x || !workspace || (!mean) != (!rstd)) return MVIP_EINVAL;      // mean == rstd == NULL: moment partials only
     hipStream_t st = as_stream(stream);
     double *ws = (double *)workspace;
     const GnPlan p = gn_plan(HW);
@@ -362,8 +401,9 @@ extern "C" int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t
             hipLaunchKernelGGL((gn_moments_kernel<_Float16, 1>), grid, dim3(GN_THREADS), 0, st, (const _Float16 *)x, HW,
                                p.chunk_elems, p.chunks, ws);
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(N * G)), dim3(64), 0, st, ws, (int)C, HW, (int)(C / G),
-                       p.chunks, eps, mean, rstd);
+    if (mean)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(N * G)), dim3(64), 0, st, ws, (int)C, HW, (int)(C / G),
+                           p.chunks, eps, mean, rstd);
     return check_launch();
 }
 
@@ -385,20 +425,45 @@ extern "C" int mvip_groupnorm_forward(const void *x, const void *gamma, const vo
                : gn_forward_t<_Float16, 1>(x, gamma, beta, N, (int)C, HW, G, eps, silu, y, mean, rstd, ws, st);
 }
 
-extern "C" int mvip_groupnorm_backward(const void *x, const void *dy, const void *gamma, const void *beta,
-                                       const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
-                                       int silu, int dtype, void *dx, void *workspace, void *stream) {
+static int gn_backward_any(const void *x, const void *dy, const void *gamma, const void *beta, const float *mean,
+                           const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu, int dtype, void *dx,
+                           void *workspace, const void *dx_add, float *pmax, void *stream) {
     int rc = gn_check(N, C, HW, G, dtype);
     if (rc != MVIP_OK) return rc;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !dy || !dx || !mean || !rstd || !workspace) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
     double *ws = (double *)workspace;
+    const bool al = dx_add == nullptr || ((uintptr_t)dx_add & 15) == 0;
     if (dtype == 0)
-        return gn_vec_ok(x, dy, dx, HW, 4)
-                   ? gn_backward_t<float, 4>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, st)
-                   : gn_backward_t<float, 1>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, st);
-    return gn_vec_ok(x, dy, dx, HW, 8)
-               ? gn_backward_t<_Float16, 8>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, st)
-               : gn_backward_t<_Float16, 1>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, st);
+        return gn_vec_ok(x, dy, dx, HW, 4) && al
+                   ? gn_backward_t<float, 4>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, dx_add, pmax, st)
+                   : gn_backward_t<float, 1>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, dx_add, pmax, st);
+    return gn_vec_ok(x, dy, dx, HW, 8) && al
+               ? gn_backward_t<_Float16, 8>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, dx_add, pmax, st)
+               : gn_backward_t<_Float16, 1>(x, dy, gamma, beta, mean, rstd, N, (int)C, HW, G, silu, dx, ws, dx_add, pmax, st);
+}
+
+extern "C" int mvip_groupnorm_backward(const void *x, const void *dy, const void *gamma, const void *beta,
+                                       const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
+                                       int silu, int dtype, void *dx, void *workspace, void *stream) {
+    return gn_backward_any(x, dy, gamma, beta, mean, rstd, N, C, HW, G, silu, dtype, dx, workspace, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t mvip_groupnorm_backward_maxima(int64_t N, int64_t C, int64_t HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return N * C * (int64_t)gn_plan(HW).chunks;
+}
+
+extern "C" int mvip_groupnorm_backward_fused(const void *x, const void *dy, const void *gamma, const void *beta,
+                                             const float *mean, const float *rstd, int64_t N, int64_t C, int64_t HW, int G,
+                                             int silu, int dtype, const void *dx_add, void *dx, float *maxima,
+                                             void *workspace, void *stream) {
+    return gn_backward_any(x, dy, gamma, beta, mean, rstd, N, C, HW, G, silu, dtype, dx, workspace, dx_add, maxima, stream);
+}
+
+extern "C" int mvip_absmax_scale_from_maxima(const float *maxima, int64_t count, float *scale2, void *stream) {
+    if (count <= 0 || !maxima || !scale2) return MVIP_EINVAL;
+    hipLaunchKernelGGL(gn_pmax_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), maxima, count, scale2);
+    return check_launch();
 }

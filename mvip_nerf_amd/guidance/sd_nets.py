@@ -55,7 +55,7 @@ class GroupNorm(nn.GroupNorm):
         return F.silu(y) if silu else y
 
 
-def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
+def norm_act_conv(norm, conv, x, chan_add=None, residual=None, link=None):
     """conv(silu(norm(x))) [+ chan_add[:, :, None, None]] [+ residual].  Device fp32 tensors whose shape the
     split-precision MFMA convolution covers (csrc/conv3x3.hip: 3x3/s1/p1, Cout % 32 == 0, Cin % 16 == 0,
     H % 8 == 0 and W % 32 == 0, or H % 16 == 0 and W % 16 == 0) run statistics -> normalise+SiLU -> convolution (+ the additions) in four HIP
@@ -63,7 +63,8 @@ def norm_act_conv(norm, conv, x, chan_add=None, residual=None):
     if x.is_cuda:
         from .. import ops
         if USE_MFMA_CONV3X3 and ops.conv3x3_supported(conv, x):
-            return ops.norm_act_conv3x3(x, norm, conv, True, chan_add, residual)
+            return ops.norm_act_conv3x3(x, norm, conv, True, chan_add, residual, link)
+    assert link is None         # a ShortcutLink needs BOTH convolutions of the block on the HIP path (ResnetBlock2D checks)
     h = conv_any(conv, norm(x, silu=True))
     if chan_add is not None:
         h = h + chan_add[:, :, None, None]
@@ -93,7 +94,12 @@ class ResnetBlock2D(nn.Module):
             t = ops.linear_small(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, act_in=1)     # proj(silu(temb))
         else:
             t = self.time_emb_proj(F.silu(temb))
-        h = norm_act_conv(self.norm1, self.conv1, x, chan_add=t)
+        link = None
+        if (self.conv_shortcut is None and x.is_cuda and USE_MFMA_CONV3X3 and torch.is_grad_enabled() and x.requires_grad):
+            from .. import ops
+            if ops.conv3x3_supported(self.conv1, x) and ops.conv3x3_supported(self.conv2, x):
+                link = ops.ShortcutLink()        # identity shortcut: its gradient is added inside conv1's GroupNorm backward
+        h = norm_act_conv(self.norm1, self.conv1, x, chan_add=t, link=link)
         if self.conv_shortcut is None:
             sc = x
         else:
@@ -104,7 +110,7 @@ class ResnetBlock2D(nn.Module):
                     sc = ops.conv1x1(x, self.conv_shortcut)
             if sc is None:
                 sc = conv_any(self.conv_shortcut, x)            # 8 x 8 level (64 pixels): the GEMM path pads the columns
-        return norm_act_conv(self.norm2, self.conv2, h, residual=sc)
+        return norm_act_conv(self.norm2, self.conv2, h, residual=sc, link=link)
 
 
 class Attention(nn.Module):

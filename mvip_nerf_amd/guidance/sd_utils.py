@@ -265,7 +265,11 @@ class StableDiffusion(nn.Module):
         init_image = pred[:, :3, :, :]
         # F.interpolate(mask, size=(64, 64)) is mode='nearest': source index floor(dst * 512 / 64) = 8 * dst
         mask64 = mask[:, :, ::8, ::8].contiguous().to(prompt_embeds.dtype)
-        masked_image_latents = self._encode_vae_image(masked_image)                  # randn draw 1
+        # Its only consumer is the UNet input inside torch.no_grad() below (DS_NeRF/guidance/sd_utils.py:375-380: the
+        # gradient is applied to `latents` alone), so no gradient ever flows back through this encode: run it without a
+        # graph -- same values, no saved activations, and the GroupNorm statistics need not be kept (one launch less each).
+        with torch.no_grad():
+            masked_image_latents = self._encode_vae_image(masked_image)              # randn draw 1
         if cfg:
             mask64 = torch.cat([mask64] * 2)
             masked_image_latents = torch.cat([masked_image_latents] * 2)

@@ -636,6 +636,36 @@ def _with_saved_prec(backward):
     return wrapped
 
 
+class ShortcutLink:
+    """Joins the two convolutions of a ResNet block whose shortcut is the identity: the gradient arriving over the shortcut
+    (dy of the block) is added to the gradient through the block inside the GroupNorm backward of the FIRST convolution
+    (`dx_add` of mvip_groupnorm_backward_fused) instead of by autograd in a pass of its own.  The second convolution's
+    backward leaves dy here and reports no gradient for its `residual` input; the first one's picks it up."""
+    __slots__ = ('dy',)
+
+    def __init__(self):
+        self.dy = None
+
+
+# The last gradient written by mvip_groupnorm_backward_fused with its per-workgroup maxima: (dx, version, maxima).  The
+# backward that receives exactly this tensor as its dy takes the scale from the maxima instead of re-reading it.  The
+# strong reference keeps the memory from being reused under the same address; one entry, dropped at the next lookup.
+_LAST_DX = [None]
+
+
+def _scale_of_gradient(dyc):
+    """scale2 of dyc: from the maxima its producer left (same power of two) or by the absmax pass."""
+    dev = dyc.device
+    scale2 = torch.empty(4, device=dev, dtype=torch.float32)
+    last, _LAST_DX[0] = _LAST_DX[0], None
+    if (last is not None and last[0].data_ptr() == dyc.data_ptr() and last[0].numel() == dyc.numel()
+            and last[0]._version == last[1] and dyc._version == last[1] and dyc.dtype == torch.float32):
+        call('mvip_absmax_scale_from_maxima', ptr(last[2]), last[2].numel(), ptr(scale2), stream())
+    else:
+        call('mvip_absmax_scale', ptr(dyc), dyc.numel(), ptr(scale2), ptr(_zero_words(dev)[32:34], torch.int32), stream())
+    return scale2
+
+
 class _NormActConv3x3(torch.autograd.Function):
     """conv3x3(act(group_norm(x))) + bias [+ chan_add[:, :, None, None]] [+ residual]: statistics, split-plane
     writer (normalise + SiLU fused) and the MFMA convolution.  Backward: dY -> split planes (scaled by a power of
@@ -643,7 +673,7 @@ class _NormActConv3x3(torch.autograd.Function):
     Parameter gradients are not produced (frozen networks)."""
 
     @staticmethod
-    def forward(ctx, x, chan_add, residual, norm, conv, silu):
+    def forward(ctx, x, chan_add, residual, norm, conv, silu, link=None):
         ctx.prec = _prec()
         for p in (norm.weight, norm.bias, conv.weight, conv.bias):
             if p is not None and p.requires_grad:
@@ -652,39 +682,47 @@ class _NormActConv3x3(torch.autograd.Function):
         N, C, H, W = xc.shape
         HW, G, Cout = H * W, norm.num_groups, conv.out_channels
         dev = xc.device
-        mean = torch.empty((N, G), device=dev, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
         ws = _gn_workspace(N, C, HW, dev)
         gw = None if norm.weight is None else norm.weight.detach().contiguous()
         gb = None if norm.bias is None else norm.bias.detach().contiguous()
-        call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
-             ptr(ws, torch.float64), stream())
         xs = _split_buffer(N, C, HW, dev)
-        call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
-             int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
+        keep_stats = ctx.needs_input_grad[0] or C // G < 4
+        if keep_stats:
+            mean = torch.empty((N, G), device=dev, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
+                 ptr(ws, torch.float64), stream())
+            call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
+                 int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
+            ctx.save_for_backward(xc, gw, gb, mean, rstd)
+        else:       # nobody needs mean / rstd afterwards: the plane writer reduces the moment partials itself (one launch less)
+            call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
+            call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(ws, torch.float64), float(norm.eps),
+                 N, C, HW, G, int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
         y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
         bias = None if conv.bias is None else conv.bias.detach().contiguous()
         ca = None if chan_add is None else chan_add.detach().contiguous()
         rs = None if residual is None else residual.detach().contiguous()
         _conv3x3_launch(xs, _conv_packed(conv, False), bias, ca, rs, None, N, C, Cout, H, W, y)
-        ctx.save_for_backward(xc, gw, gb, mean, rstd)
         ctx.mods = (norm, conv, bool(silu))
+        ctx.link = link
+        ctx.link_tail = link is not None and residual is not None      # the block's second convolution
         return y
 
     @staticmethod
     @_with_saved_prec
     def backward(ctx, dy):
-        xc, gw, gb, mean, rstd = ctx.saved_tensors
         norm, conv, silu = ctx.mods
-        N, C, H, W = xc.shape
-        HW, Cout, dev = H * W, conv.out_channels, xc.device
         dyc = dy.contiguous().float()
         dx = None
+        link = ctx.link
         if ctx.needs_input_grad[0]:
+            xc, gw, gb, mean, rstd = ctx.saved_tensors
+            N, C, H, W = xc.shape
+            HW, Cout, dev = H * W, conv.out_channels, xc.device
             if not _lib.load().mvip_conv3x3_supported(C, Cout, H, W):
                 raise NotImplementedError(f'conv3x3 data gradient: unsupported shape Cin={C} Cout={Cout}')
-            scale2 = torch.empty(4, device=dev, dtype=torch.float32)
-            call('mvip_absmax_scale', ptr(dyc), dyc.numel(), ptr(scale2), ptr(_zero_words(dev)[32:34], torch.int32), stream())
+            scale2 = _scale_of_gradient(dyc)
             dys = _split_buffer(N, Cout, HW, dev)
             call('mvip_split_planes', ptr(dyc), N, Cout, HW, ptr(scale2), ptr(dys, torch.float16), _prec(), stream())
             dact = torch.empty_like(xc)
@@ -692,11 +730,18 @@ class _NormActConv3x3(torch.autograd.Function):
             del dys
             dx = torch.empty_like(xc)
             ws = _gn_workspace(N, C, HW, dev)
-            call('mvip_groupnorm_backward', ptr(xc), ptr(dact), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW,
-                 norm.num_groups, int(silu), 0, ptr(dx), ptr(ws, torch.float64), stream())
+            add = None
+            if link is not None and not ctx.link_tail:           # first convolution of a linked block: + the shortcut's gradient
+                add, link.dy = link.dy, None
+            maxima = torch.empty(int(_lib.load().mvip_groupnorm_backward_maxima(N, C, HW)), device=dev, dtype=torch.float32)
+            call('mvip_groupnorm_backward_fused', ptr(xc), ptr(dact), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW,
+                 norm.num_groups, int(silu), 0, ptr(add), ptr(dx), ptr(maxima), ptr(ws, torch.float64), stream())
+            _LAST_DX[0] = (dx, dx._version, maxima)
         d_ca = dyc.sum((2, 3)) if ctx.needs_input_grad[1] else None
         d_rs = dyc if ctx.needs_input_grad[2] else None
-        return dx, d_ca, d_rs, None, None, None
+        if ctx.link_tail and d_rs is not None:
+            link.dy, d_rs = dyc, None                            # handed to the first convolution's GroupNorm backward
+        return dx, d_ca, d_rs, None, None, None, None
 
 
 def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, H, W, y):
@@ -730,10 +775,10 @@ def conv3x3_plain(x, conv, upsample2=False):
     return y
 
 
-def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None):
+def norm_act_conv3x3(x, norm, conv, silu=True, chan_add=None, residual=None, link=None):
     """conv(act(norm(x))) [+ chan_add[:, :, None, None]] [+ residual] on the HIP kernels; the caller checks
-    conv3x3_supported first."""
-    return _NormActConv3x3.apply(x, chan_add, residual, norm, conv, silu)
+    conv3x3_supported first.  link: a ShortcutLink shared by the two convolutions of an identity-shortcut block."""
+    return _NormActConv3x3.apply(x, chan_add, residual, norm, conv, silu, link)
 
 
 # Hash-grid model (NeRF_TCNN) -----------------------------------------------------------------------------

@@ -347,6 +347,98 @@ def test_resnet_block_fused_equals_library_path(cuda):
     np.testing.assert_allclose(N(fused), ref.float().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
 
 
+def test_identity_shortcut_chain_gradient(cuda):
+    """Three VAE-style ResNet blocks in a row (identity shortcuts) under autograd: the shortcut gradient is added inside the
+    first convolution's GroupNorm backward (ops.ShortcutLink) and every block's dy takes its power-of-two scale from the
+    per-workgroup maxima its producer left (mvip_groupnorm_backward_fused / mvip_absmax_scale_from_maxima).  Checked
+    against the same chain in fp64 on the host, and bit for bit against the unlinked path with the absmax passes (the
+    scales are the same powers of two; only the order of one fp32 addition differs... none does: a + b is commutative)."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_nets import ResnetBlock2D
+    torch.manual_seed(11)
+    blks = [ResnetBlock2D(128, 128, eps=1e-6) for _ in range(3)]
+    for b in blks:
+        for p in b.parameters():
+            p.requires_grad_(False)
+    x = torch.randn(1, 128, 40, 64) * 1.5 + 0.3
+    dy = torch.randn(1, 128, 40, 64) * 1e-5
+    xr = x.double().requires_grad_(True)
+    h = xr
+    for b in blks:
+        h = b.double()(h)
+    h.backward(dy.double())
+    blks = [b.float().to(cuda) for b in blks]
+
+    def run(linked):
+        xd = x.to(cuda).requires_grad_(True)
+        old = ops.ShortcutLink
+        calls = []
+        orig_call = ops.call
+
+        def counting(name, *a):
+            calls.append(name)
+            return orig_call(name, *a)
+        ops.call = counting
+        try:
+            if not linked:
+                class _NoLink:                      # never picked up: norm_act_conv gets link=None
+                    def __new__(cls):
+                        return None
+                ops.ShortcutLink = _NoLink
+            hd = xd
+            for b in blks:
+                hd = b(hd)
+            if not linked:
+                ops._LAST_DX[0] = None
+            hd.backward(dy.to(cuda))
+        finally:
+            ops.ShortcutLink, ops.call = old, orig_call
+        return hd.detach(), xd.grad, calls
+    y1, g1, calls1 = run(True)
+    assert calls1.count('mvip_absmax_scale_from_maxima') == 5 and calls1.count('mvip_absmax_scale') == 1, calls1
+    np.testing.assert_allclose(N(y1), h.detach().float().numpy(), rtol=0, atol=2e-5 * float(h.abs().max()))
+    np.testing.assert_allclose(N(g1), xr.grad.float().numpy(), rtol=0, atol=2e-5 * float(xr.grad.abs().max()))
+    # the unlinked path: autograd adds the shortcut gradient, every dy is re-read for its maximum
+    orig = ops._scale_of_gradient
+
+    def always_absmax(dyc):
+        ops._LAST_DX[0] = None
+        return orig(dyc)
+    ops._scale_of_gradient = always_absmax
+    try:
+        y0, g0, calls0 = run(False)
+    finally:
+        ops._scale_of_gradient = orig
+    assert calls0.count('mvip_absmax_scale_from_maxima') == 0 and calls0.count('mvip_absmax_scale') == 6
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
+
+
+def test_groupnorm_planes_from_moment_partials(cuda):
+    """mvip_groupnorm_split_planes_moments (statistics reduced inside the plane writer) writes the same bytes as
+    mvip_groupnorm_stats + mvip_groupnorm_split_planes, for group sizes that do and do not divide 16."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.ops import call, ptr, stream
+    for (N_, C, H, W, G) in [(2, 320, 16, 16, 32), (1, 128, 72, 64, 32), (2, 960, 8, 32, 32), (1, 640, 32, 32, 32)]:
+        g = torch.Generator(device=cuda).manual_seed(C + H)
+        x = torch.randn(N_, C, H, W, device=cuda, generator=g) * 2 + 0.5
+        gw = torch.randn(C, device=cuda, generator=g)
+        gb = torch.randn(C, device=cuda, generator=g)
+        HW = H * W
+        ws = ops._gn_workspace(N_, C, HW, cuda)
+        mean = torch.empty((N_, G), device=cuda)
+        rstd = torch.empty_like(mean)
+        a = torch.zeros(N_ * C * HW * 2, device=cuda, dtype=torch.float16)
+        b = torch.zeros_like(a)
+        call('mvip_groupnorm_stats', ptr(x), N_, C, HW, G, 1e-5, 0, ptr(mean), ptr(rstd), ptr(ws, torch.float64), stream())
+        call('mvip_groupnorm_split_planes', ptr(x), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N_, C, HW, G, 1,
+             ptr(a, torch.float16), 0, stream())
+        ws2 = torch.zeros_like(ws)
+        call('mvip_groupnorm_stats', ptr(x), N_, C, HW, G, 1e-5, 0, None, None, ptr(ws2, torch.float64), stream())
+        call('mvip_groupnorm_split_planes_moments', ptr(x), ptr(gw), ptr(gb), ptr(ws2, torch.float64), 1e-5, N_, C, HW, G, 1,
+             ptr(b, torch.float16), 0, stream())
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (N_, C, H, W)
+
+
 def test_gemm_f16x3(cuda):
     """Y = A X on the split-precision GEMM with strided operand sources vs fp64; tiny-magnitude operands (the
     gradients of the SDS step are ~1e-6) keep fp32-grade accuracy through the power-of-two scaling."""

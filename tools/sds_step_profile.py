@@ -16,7 +16,7 @@ def main():
     fp16 = '--fp16' in sys.argv            # the reference's --fp16 mode on the single-product kernels
     graphs = '--graphs' in sys.argv        # also time the captured-hipGraph replay of the same step
     out_name = next((a.split('=', 1)[1] for a in sys.argv if a.startswith('--out=')), 'sds_step_profile.json')
-    sd = StableDiffusion(dev, fp16, False)
+    sd = StableDiffusion(dev, fp16, False, use_graphs=False)    # eager for the per-kernel table; graphs timed below
     g = torch.Generator(device=dev).manual_seed(2)
     H, W = 378, 504
     pred = torch.rand(1, 3, H, W, device=dev, generator=g).requires_grad_(True)
@@ -44,7 +44,7 @@ def main():
     n_all = sum(e.count for e in ev)
     print(f'== train_step_sd: median wall {sorted(ts)[len(ts) // 2]:.2f} ms {[round(t, 1) for t in ts]}, device-busy {total:.2f} ms, {n} kernels / copies ({n_all} profiler events)')
     rows = []
-    for e in ev[:40]:
+    for e in ev[:70]:
         print(f'  {e.device_time_total / 1e3:8.3f} ms  x{e.count:4d}  {e.key[:120]}')
         rows.append([round(e.device_time_total / 1e3, 3), e.count, e.key[:120]])
     own = sum(e.device_time_total for e in ev if 'mvip::' in e.key) / 1e3
