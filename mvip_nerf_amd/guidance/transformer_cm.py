@@ -181,8 +181,8 @@ _UNIT_SECTIONS = {}
 
 def _scales(x, outer, sections, length):
     """Power-of-two scales of the q / k / v sections: 1 for every section when the UNet's forward activations are
-    split at a fixed scale (ops.FORWARD_UNIT_SCALE), else measured in one launch."""
-    if ops.FORWARD_UNIT_SCALE:
+    split at a fixed scale (ops.forward_unit_scale()), else measured in one launch."""
+    if ops.forward_unit_scale():
         key = (x.device, sections)
         if key not in _UNIT_SECTIONS:
             _UNIT_SECTIONS[key] = ops.unit_scale(x.device).repeat(sections)

@@ -761,7 +761,7 @@ def conv3x3_plain(x, conv, upsample2=False):
     xc = _f32c(x.detach())
     N, C, H, W = xc.shape
     Cout, dev = conv.out_channels, xc.device
-    scale2 = unit_scale(dev) if FORWARD_UNIT_SCALE else absmax_scale(xc)
+    scale2 = unit_scale(dev) if forward_unit_scale() else absmax_scale(xc)
     if upsample2:
         xs = _split_buffer(N, C, 4 * H * W, dev)
         call('mvip_split_planes_upsample2', ptr(xc), N, C, H, W, ptr(scale2), ptr(xs, torch.float16), _prec(), stream())
@@ -986,8 +986,16 @@ def unit_scale(device):
     return _UNIT[device]
 
 
+def forward_unit_scale():
+    """True when FORWARD activations are split at scale 1: the opt-in above, and always in the reference's --fp16 mode
+    (PREC = 1) -- there the single hi plane fp16(x) IS the fp16 tensor the reference's half-precision networks hold
+    (DS_NeRF/guidance/sd_utils.py:66), so a measured scale would buy nothing the mode promises.  Gradients keep their
+    measured scale in both modes (they are ~1e-5 and would underflow)."""
+    return FORWARD_UNIT_SCALE or _prec() == 1
+
+
 def _scaled_planes(x, N, K, P, sn, sc, sp, forward_activation=False):
-    s2 = unit_scale(x.device) if (forward_activation and FORWARD_UNIT_SCALE) else absmax_scale(x)
+    s2 = unit_scale(x.device) if (forward_activation and forward_unit_scale()) else absmax_scale(x)
     return split_planes_strided(x, N, K, P, sn, sc, sp, s2), s2
 
 
@@ -1045,14 +1053,14 @@ class _VAEAttention(torch.autograd.Function):
         probs, O = [], torch.empty((N, C, L), device=dev, dtype=torch.float32)
         for n in range(N):
             q, k, v = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:]
-            ks, s2 = _scaled_planes(k, 1, C, L, 0, L, 1)
+            ks, s2 = _scaled_planes(k, 1, C, L, 0, L, 1, forward_activation=_prec() == 1)
             S = gemm_f16x3(ks, gemm_pack_a(q, L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]        # S[i][j] = q_i . k_j
             Pm = softmax_rows(S, C ** -0.5)
             del S
-            pts, s2 = _scaled_planes(Pm, 1, L, L, 0, 1, L)                                    # X[k=j][p=i] = P[i][j]
+            pts, s2 = _scaled_planes(Pm, 1, L, L, 0, 1, L, forward_activation=_prec() == 1)   # X[k=j][p=i] = P[i][j]
             O[n] = gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]
             probs.append(Pm)
-        os_, s2 = _scaled_planes(O, N, C, L, C * L, L, 1)
+        os_, s2 = _scaled_planes(O, N, C, L, C * L, L, 1, forward_activation=_prec() == 1)
         out = gemm_f16x3(os_, wts['o'], N, C, C, L, bias=wts['bo'], residual=xc.reshape(N, C, L), x_scale2=s2)
         ctx.save_for_backward(xc, gw, gb, mean, rstd, qkv, *probs)
         ctx.mod = mod
@@ -1131,7 +1139,7 @@ class _Conv1x1(torch.autograd.Function):
         xc = x.contiguous()
         N, C, H, W = xc.shape
         L, Cout = H * W, conv.out_channels
-        xs, s2 = _scaled_planes(xc, N, C, L, C * L, L, 1, forward_activation=not x.requires_grad)
+        xs, s2 = _scaled_planes(xc, N, C, L, C * L, L, 1, forward_activation=(not x.requires_grad) or _prec() == 1)
         bias = None if conv.bias is None else conv.bias.detach().contiguous()
         rs = None if residual is None else residual.detach().contiguous()
         y = gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, Cout, L, bias=bias, residual=rs, x_scale2=s2)
@@ -1209,7 +1217,7 @@ class _ConvGemm(torch.autograd.Function):
         Cout, K = conv.out_channels, Cin * k * k
         MP, KP, P, PP = _up(Cout, 32), _up(K, 32), OH * OW, _up(OH * OW, 256)
         a_fwd, _, bias = _conv_gemm_packed(conv)
-        s2 = absmax_scale(xc)
+        s2 = unit_scale(xc.device) if forward_unit_scale() else absmax_scale(xc)
         xs = _split_buffer(N, KP, PP, xc.device)
         call('mvip_im2col_split_planes', ptr(xc), N, Cin, H, W, k, k, st, pt, pl, OH, OW, KP, PP, ptr(s2),
              ptr(xs, torch.float16), _prec(), stream())
