@@ -636,6 +636,14 @@ def _with_saved_prec(backward):
     return wrapped
 
 
+def _gn_stats(xc, N, C, H, W, G, eps, ws):
+    """mean, rstd [N, G] of xc by a pass over it (fp64 moments, csrc/group_norm.hip)."""
+    mean = torch.empty((N, G), device=xc.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    call('mvip_groupnorm_stats', ptr(xc), N, C, H * W, G, float(eps), 0, ptr(mean), ptr(rstd), ptr(ws, torch.float64), stream())
+    return mean, rstd
+
+
 class ShortcutLink:
     """Joins the two convolutions of a ResNet block whose shortcut is the identity: the gradient arriving over the shortcut
     (dy of the block) is added to the gradient through the block inside the GroupNorm backward of the FIRST convolution
@@ -688,10 +696,7 @@ class _NormActConv3x3(torch.autograd.Function):
         xs = _split_buffer(N, C, HW, dev)
         keep_stats = ctx.needs_input_grad[0] or C // G < 4
         if keep_stats:
-            mean = torch.empty((N, G), device=dev, dtype=torch.float32)
-            rstd = torch.empty_like(mean)
-            call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
-                 ptr(ws, torch.float64), stream())
+            mean, rstd = _gn_stats(xc, N, C, H, W, G, norm.eps, ws)
             call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
                  int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
             ctx.save_for_backward(xc, gw, gb, mean, rstd)
@@ -1039,12 +1044,9 @@ class _VAEAttention(torch.autograd.Function):
         L, dev, norm = H * W, xc.device, mod.group_norm
         G = norm.num_groups
         wts = _attn_weights(mod)
-        mean = torch.empty((N, G), device=dev, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
         ws = _gn_workspace(N, C, L, dev)
         gw, gb = norm.weight.detach().contiguous(), norm.bias.detach().contiguous()
-        call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, ptr(mean), ptr(rstd),
-             ptr(ws, torch.float64), stream())
+        mean, rstd = _gn_stats(xc, N, C, H, W, G, norm.eps, ws)
         hs = _split_buffer(N, C, L, dev)
         call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, L, G, 0,
              ptr(hs, torch.float16), _prec(), stream())
@@ -1261,14 +1263,17 @@ def norm_conv1x1(x, norm, conv):
     xc = x.detach().contiguous()
     N, C, H, W = xc.shape
     L, G, dev = H * W, norm.num_groups, xc.device
-    mean = torch.empty((N, G), device=dev, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
     ws = _gn_workspace(N, C, L, dev)
-    call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, ptr(mean), ptr(rstd), ptr(ws, torch.float64),
-         stream())
     xs = _split_buffer(N, C, L, dev)
-    call('mvip_groupnorm_split_planes', ptr(xc), ptr(norm.weight.detach().contiguous()),
-         ptr(norm.bias.detach().contiguous()), ptr(mean), ptr(rstd), N, C, L, G, 0, ptr(xs, torch.float16), _prec(), stream())
+    gw, gb = norm.weight.detach().contiguous(), norm.bias.detach().contiguous()
+    if C // G < 4:
+        mean, rstd = _gn_stats(xc, N, C, H, W, G, norm.eps, ws)
+        call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, L, G, 0,
+             ptr(xs, torch.float16), _prec(), stream())
+    else:           # forward only: the plane writer reduces the moment partials itself
+        call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
+        call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(ws, torch.float64), float(norm.eps),
+             N, C, L, G, 0, ptr(xs, torch.float16), _prec(), stream())
     bias = None if conv.bias is None else conv.bias.detach().contiguous()
     return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias)     # [N, Cout, L]
 
