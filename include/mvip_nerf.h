@@ -327,6 +327,17 @@ int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, co
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, int prec, void *stream);
 int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+/* Channel-split launches can leave the GroupNorm moments of their OUTPUT (the norm -> silu -> conv chains of the ResNet
+ * blocks): mvip_conv3x3_f16x3_ws_moments's reduction launch also writes `row_moments` [N][Cout][2] fp64 = {sum, sum of
+ * squares} of every output row -- the layout mvip_groupnorm_stats(mean = rstd = NULL) leaves in its workspace for
+ * H * W <= 4096, so mvip_groupnorm_split_planes_moments(y, ..., row_moments, ...) needs no pass over y for its statistics.
+ * mvip_conv3x3_row_moments_doubles: N * Cout * 2 when the shape qualifies (channel-split launch; H * W = 64, 256, 1024 or
+ * 4096), else 0 (then only mvip_conv3x3_f16x3_ws applies).  y is bit-identical to mvip_conv3x3_f16x3_ws's. */
+int64_t mvip_conv3x3_row_moments_doubles(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+int mvip_conv3x3_f16x3_ws_moments(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                  const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                                  int64_t H, int64_t W, float *y, void *workspace, void *row_moments, int prec,
+                                  void *stream);
 int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                           int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream);

@@ -750,6 +750,46 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
     *reinterpret_cast<f32x4 *>(y + i4) = v;
 }
 
+// The same reduction that also leaves the GroupNorm moments of its OUTPUT rows, in the layout gn_moments_kernel
+// (csrc/group_norm.hip) writes for HW <= 4096 (one {sum, sum of squares} fp64 pair per (sample, channel) row): the next
+// layer's GroupNorm then needs no pass over y for its statistics.  A row (HW = 64, 256, 1024 or 4096 values) is owned by
+// LPR = min(HW / 4, 256) consecutive threads (rows of 1024+ values: one workgroup, looping), so the sums are formed in a
+// fixed order: per thread in index order, xor tree over the row's lanes, then the four waves in order.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, int64_t total, int Cout, int64_t HW,
+                               const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
+                               const float *__restrict__ bias, const float *__restrict__ chan_add,
+                               const float *__restrict__ residual, float *__restrict__ y, double *__restrict__ moments) {
+    constexpr int ROWS = 256 / LPR;                           // rows per workgroup
+    const int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x / LPR;             // n * Cout + co
+    const int lr = threadIdx.x % LPR;
+    const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
+    const float bv = bias ? bias[row % Cout] : 0.f, cv = chan_add ? chan_add[row] : 0.f;
+    double sm = 0.0, q = 0.0;
+    for (int64_t i4 = row * HW + (int64_t)lr * 4; i4 < (row + 1) * HW; i4 += (int64_t)LPR * 4) {
+        f32x4 sum = *reinterpret_cast<const f32x4 *>(partial + i4);
+        for (int sp = 1; sp < splits; ++sp) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)sp * total + i4);
+        f32x4 v = sum * inv;                               // same order of roundings as cv_split_reduce_kernel
+        if (bias) v += bv;
+        if (chan_add) v += cv;
+        if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i4);
+        *reinterpret_cast<f32x4 *>(y + i4) = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double d = (double)v[k]; sm += d; q += d * d; }
+    }
+#pragma unroll
+    for (int o = (LPR < 64 ? LPR : 64) / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+    if constexpr (LPR == 256) {
+        __shared__ double red[2][4];
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = q; }
+        __syncthreads();
+        sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    if (lr == 0) { moments[row * 2] = sm; moments[row * 2 + 1] = q; }
+}
+
 // The same reduction whose result leaves as split planes [N][M/16][2][2][P][8 halves] * out_scale (an operand sink behind a
 // split-K launch): thread = (sample, 8-row block, column); the 8 rows of a fragment are 8 coalesced row reads per split.
 __global__ void __launch_bounds__(256)
@@ -1586,7 +1626,8 @@ extern "C" int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t 
 
 static int conv3x3_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
-                          int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream) {
+                          int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream,
+                          double *row_moments = nullptr) {
     if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W) || (prec != 0 && prec != 1)) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
@@ -1647,12 +1688,40 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     } while (0)
     if (prec) MVIP_CV_LAUNCH(true); else MVIP_CV_LAUNCH(false);
 #undef MVIP_CV_LAUNCH
+    if (row_moments && !a.partial) return MVIP_EINVAL;         // callers ask mvip_conv3x3_row_moments_doubles first
     if (a.partial) {
-        const int64_t total = N * Cout * H * W;
-        hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
-                           a.splits, total, (int)Cout, H * W, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+        const int64_t total = N * Cout * H * W, HW = H * W;
+        if (row_moments) {
+#define MVIP_RM(LPR_) hipLaunchKernelGGL((cv_split_reduce_moments_kernel<LPR_>), dim3((unsigned)(N * Cout / (256 / LPR_))), dim3(256), 0, \
+                                         st, a.partial, a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, bias, chan_add,    \
+                                         residual, y, row_moments)
+            if (HW == 64) MVIP_RM(16); else if (HW == 256) MVIP_RM(64); else MVIP_RM(256);
+#undef MVIP_RM
+        } else {
+            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
+                               a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+        }
     }
     return check_launch();
+}
+
+// Doubles of `row_moments` ([N][Cout][2]) when this shape's launch is channel-split AND its rows fit the one-pair-per-row
+// layout of mvip_groupnorm_stats (H * W = 64, 256, 1024 or 4096; N * Cout a multiple of 16), else 0.
+extern "C" int64_t mvip_conv3x3_row_moments_doubles(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    if (mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W) == 0) return 0;
+    const int64_t HW = H * W;
+    if (!(HW == 64 || HW == 256 || HW == 1024 || HW == 4096) || (N * Cout) % 16 != 0) return 0;
+    if (mvip_groupnorm_workspace_bytes(1, 1, HW) != 16) return 0;              // one moment pair per row in that layout
+    return N * Cout * 2;
+}
+
+extern "C" int mvip_conv3x3_f16x3_ws_moments(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                             const float *residual, const float *x_scale2, int64_t N, int64_t Cin,
+                                             int64_t Cout, int64_t H, int64_t W, float *y, void *workspace, void *row_moments,
+                                             int prec, void *stream) {
+    if (!workspace || !row_moments || mvip_conv3x3_row_moments_doubles(N, Cin, Cout, H, W) == 0) return MVIP_EINVAL;
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, workspace, prec, stream,
+                          (double *)row_moments);
 }
 
 extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,

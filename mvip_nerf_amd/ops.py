@@ -701,14 +701,17 @@ class _NormActConv3x3(torch.autograd.Function):
                  int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
             ctx.save_for_backward(xc, gw, gb, mean, rstd)
         else:       # nobody needs mean / rstd afterwards: the plane writer reduces the moment partials itself (one launch less)
-            call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
-            call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(ws, torch.float64), float(norm.eps),
+            rm = _row_moments_of(xc)                  # ... and the producing convolution may have left them already
+            if rm is None:
+                call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
+                rm = ws
+            call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(rm, torch.float64), float(norm.eps),
                  N, C, HW, G, int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
         y = torch.empty((N, Cout, H, W), device=dev, dtype=torch.float32)
         bias = None if conv.bias is None else conv.bias.detach().contiguous()
         ca = None if chan_add is None else chan_add.detach().contiguous()
         rs = None if residual is None else residual.detach().contiguous()
-        _conv3x3_launch(xs, _conv_packed(conv, False), bias, ca, rs, None, N, C, Cout, H, W, y)
+        _conv3x3_launch(xs, _conv_packed(conv, False), bias, ca, rs, None, N, C, Cout, H, W, y, moments=True)
         ctx.mods = (norm, conv, bool(silu))
         ctx.link = link
         ctx.link_tail = link is not None and residual is not None      # the block's second convolution
@@ -749,10 +752,34 @@ class _NormActConv3x3(torch.autograd.Function):
         return dx, d_ca, d_rs, None, None, None, None
 
 
-def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, H, W, y):
-    """mvip_conv3x3_f16x3_ws with the split-K workspace the library asks for this shape (none for most)."""
+# The last convolution output whose channel-split reduction also left its GroupNorm row moments: (y, version, moments).
+# A forward-only GroupNorm that is handed exactly this tensor skips its pass over y (mvip_groupnorm_split_planes_moments
+# reads the moments directly).  One entry; the strong reference keeps the address from being reused.
+_LAST_Y = [None]
+ROW_MOMENTS = True             # A/B switch: False = every GroupNorm computes its moments from its input
+
+
+def _row_moments_of(xc):
+    last, _LAST_Y[0] = _LAST_Y[0], None
+    if (last is not None and last[0].data_ptr() == xc.data_ptr() and last[0].shape == xc.shape and xc.dtype == torch.float32
+            and xc._version == last[1] and last[0]._version == last[1]):
+        return last[2]
+    return None
+
+
+def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, H, W, y, moments=False):
+    """mvip_conv3x3_f16x3_ws with the split-K workspace the library asks for this shape (none for most).  moments: a
+    channel-split launch also leaves y's GroupNorm row moments for the next layer (registered in _LAST_Y)."""
     nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W))
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
+    if moments and ROW_MOMENTS and nbytes:
+        nd = int(_lib.load().mvip_conv3x3_row_moments_doubles(N, Cin, Cout, H, W))
+        if nd:
+            rm = torch.empty(nd, device=y.device, dtype=torch.float64)
+            call('mvip_conv3x3_f16x3_ws_moments', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
+                 ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), ptr(rm, torch.float64), _prec(), stream())
+            _LAST_Y[0] = (y, y._version, rm)
+            return
     call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
          ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), _prec(), stream())
 
@@ -1271,8 +1298,11 @@ def norm_conv1x1(x, norm, conv):
         call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, L, G, 0,
              ptr(xs, torch.float16), _prec(), stream())
     else:           # forward only: the plane writer reduces the moment partials itself
-        call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
-        call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(ws, torch.float64), float(norm.eps),
+        rm = _row_moments_of(xc)
+        if rm is None:
+            call('mvip_groupnorm_stats', ptr(xc), N, C, L, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
+            rm = ws
+        call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(rm, torch.float64), float(norm.eps),
              N, C, L, G, 0, ptr(xs, torch.float16), _prec(), stream())
     bias = None if conv.bias is None else conv.bias.detach().contiguous()
     return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias)     # [N, Cout, L]

@@ -413,6 +413,61 @@ def test_identity_shortcut_chain_gradient(cuda):
     assert torch.equal(y0, y1) and torch.equal(g0, g1)
 
 
+@pytest.mark.parametrize('N_,cin,cout,H,W', [(2, 320, 320, 64, 64), (2, 640, 640, 32, 32), (2, 320, 640, 16, 16), (2, 1280, 1280, 8, 8)])
+def test_split_reduction_leaves_row_moments(cuda, N_, cin, cout, H, W):
+    """A channel-split convolution's reduction launch also writes the GroupNorm row moments of its output
+    (mvip_conv3x3_f16x3_ws_moments): y bit-identical to the plain launch, moments equal to mvip_groupnorm_stats' partials
+    (fp64, a different summation order: 1e-12), and the next forward-only GroupNorm uses them (no gn_moments pass)."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd.ops import call, ptr, stream
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm, norm_act_conv
+    lib = _lib.load()
+    assert int(lib.mvip_conv3x3_row_moments_doubles(N_, cin, cout, H, W)) == N_ * cout * 2
+    g = torch.Generator(device=cuda).manual_seed(cin + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(cuda)
+    x = torch.randn(N_, cin, H, W, device=cuda, generator=g)
+    rs = torch.randn(N_, cout, H, W, device=cuda, generator=g) * 2 + 1.5
+    ca = torch.randn(N_, cout, device=cuda, generator=g)
+    s2 = ops.absmax_scale(x)
+    xs = ops._split_buffer(N_, cin, H * W, cuda)
+    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
+    packed, bias = ops._conv_packed(conv, False), conv.bias.detach().contiguous()
+    y0, y1 = torch.empty(N_, cout, H, W, device=cuda), torch.empty(N_, cout, H, W, device=cuda)
+    ops._conv3x3_launch(xs, packed, bias, ca, rs, s2, N_, cin, cout, H, W, y0)
+    ops._LAST_Y[0] = None
+    ops._conv3x3_launch(xs, packed, bias, ca, rs, s2, N_, cin, cout, H, W, y1, moments=True)
+    assert torch.equal(y0, y1)
+    assert ops._LAST_Y[0] is not None and ops._LAST_Y[0][0] is y1
+    rm = ops._LAST_Y[0][2]
+    ws = ops._gn_workspace(N_, cout, H * W, cuda)
+    assert ws.numel() == rm.numel()
+    call('mvip_groupnorm_stats', ptr(y1), N_, cout, H * W, 32, 1e-5, 0, None, None, ptr(ws, torch.float64), stream())
+    np.testing.assert_allclose(rm.cpu().numpy(), ws.cpu().numpy(), rtol=1e-11, atol=1e-9)
+    # the consumer: a forward-only norm -> silu -> conv takes the registered moments (and no gn_moments pass runs)
+    norm = GroupNorm(32, cout).to(cuda)
+    conv2 = torch.nn.Conv2d(cout, 64, 3, padding=1).to(cuda)
+    for p in list(norm.parameters()) + list(conv2.parameters()):
+        p.requires_grad_(False)
+    calls = []
+    orig = ops.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    ops.call = counting
+    try:
+        with torch.no_grad():
+            z1 = norm_act_conv(norm, conv2, y1)
+            z0 = norm_act_conv(norm, conv2, y0)            # nothing registered for y0: the ordinary path
+    finally:
+        ops.call = orig
+    assert calls.count('mvip_groupnorm_stats') == 1 and calls.count('mvip_groupnorm_split_planes_moments') == 2
+    np.testing.assert_allclose(N(z1), N(z0), rtol=0, atol=1e-6 * float(z0.abs().max()))
+    y1.add_(1.0)                                           # modified in place: registered moments no longer describe it
+    ops._LAST_Y[0] = (y1, 0, rm)
+    assert ops._row_moments_of(y1) is None
+
+
 def test_groupnorm_planes_from_moment_partials(cuda):
     """mvip_groupnorm_split_planes_moments (statistics reduced inside the plane writer) writes the same bytes as
     mvip_groupnorm_stats + mvip_groupnorm_split_planes, for group sizes that do and do not divide 16."""

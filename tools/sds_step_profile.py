@@ -12,6 +12,9 @@ from mvip_nerf_amd.guidance.sd_utils import StableDiffusion          # noqa: E40
 
 
 def main():
+    if os.environ.get('MVIP_ROW_MOMENTS') == '0':          # A/B: every GroupNorm computes its moments from its input
+        from mvip_nerf_amd import ops
+        ops.ROW_MOMENTS = False
     dev = torch.device('cuda', 0)
     fp16 = '--fp16' in sys.argv            # the reference's --fp16 mode on the single-product kernels
     graphs = '--graphs' in sys.argv        # also time the captured-hipGraph replay of the same step
