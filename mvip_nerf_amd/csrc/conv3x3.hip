@@ -754,8 +754,8 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
 // (csrc/group_norm.hip) writes for HW <= 4096 (one {sum, sum of squares} fp64 pair per (sample, channel) row): the next
 // layer's GroupNorm then needs no pass over y for its statistics.  A row (HW = 64, 256, 1024 or 4096 values) is owned by
 // LPR = min(HW / 4, 256) consecutive threads (rows of 1024+ values: one workgroup, looping), so the sums are formed in a
-// fixed order: per thread in index order, xor tree over the row's lanes, then the four waves in order.
-template <int LPR>
+// fixed order: per thread in index order, a DPP scan over the row's lanes, then the four waves in order.
+template <int LPR, int IT = 1>
 __global__ void __launch_bounds__(256)
 cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, int64_t total, int Cout, int64_t HW,
                                const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
@@ -767,27 +767,48 @@ cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, in
     const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
     const float bv = bias ? bias[row % Cout] : 0.f, cv = chan_add ? chan_add[row] : 0.f;
     double sm = 0.0, q = 0.0;
-    for (int64_t i4 = row * HW + (int64_t)lr * 4; i4 < (row + 1) * HW; i4 += (int64_t)LPR * 4) {
-        f32x4 sum = *reinterpret_cast<const f32x4 *>(partial + i4);
-        for (int sp = 1; sp < splits; ++sp) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)sp * total + i4);
-        f32x4 v = sum * inv;                               // same order of roundings as cv_split_reduce_kernel
+    const int64_t i0 = row * HW + (int64_t)lr * 4;        // IT pieces of LPR * 4 values per row, all loads of a split in flight
+    f32x4 sum[IT], rv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        sum[it] = *reinterpret_cast<const f32x4 *>(partial + i0 + (int64_t)it * LPR * 4);
+        if (residual) rv[it] = *reinterpret_cast<const f32x4 *>(residual + i0 + (int64_t)it * LPR * 4);
+    }
+    for (int sp = 1; sp < splits; ++sp) {
+        f32x4 t[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) t[it] = *reinterpret_cast<const f32x4 *>(partial + (int64_t)sp * total + i0 + (int64_t)it * LPR * 4);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) sum[it] += t[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        f32x4 v = sum[it] * inv;                           // same order of roundings as cv_split_reduce_kernel
         if (bias) v += bv;
         if (chan_add) v += cv;
-        if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i4);
-        *reinterpret_cast<f32x4 *>(y + i4) = v;
+        if (residual) v += rv[it];
+        *reinterpret_cast<f32x4 *>(y + i0 + (int64_t)it * LPR * 4) = v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double d = (double)v[k]; sm += d; q += d * d; }
     }
-#pragma unroll
-    for (int o = (LPR < 64 ? LPR : 64) / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+    // totals over the row's lanes on DPP row operations (common.h; a dozen VALU steps instead of 24 dependent ds_bpermute round
+    // trips): the four row_shr steps leave a 16-lane row's total in its last lane, the two broadcasts the wave's in lane 63
+    sm += dpp_f64<0x111>(0.0, sm); q += dpp_f64<0x111>(0.0, q);
+    sm += dpp_f64<0x112>(0.0, sm); q += dpp_f64<0x112>(0.0, q);
+    sm += dpp_f64<0x114>(0.0, sm); q += dpp_f64<0x114>(0.0, q);
+    sm += dpp_f64<0x118>(0.0, sm); q += dpp_f64<0x118>(0.0, q);
+    if constexpr (LPR >= 64) {
+        sm += dpp_f64<0x142, 0xa>(0.0, sm); q += dpp_f64<0x142, 0xa>(0.0, q);
+        sm += dpp_f64<0x143, 0xc>(0.0, sm); q += dpp_f64<0x143, 0xc>(0.0, q);
+    }
     if constexpr (LPR == 256) {
         __shared__ double red[2][4];
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = q; }
+        if ((threadIdx.x & 63) == 63) { red[0][threadIdx.x >> 6] = sm; red[1][threadIdx.x >> 6] = q; }
         __syncthreads();
         sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
-    if (lr == 0) { moments[row * 2] = sm; moments[row * 2 + 1] = q; }
+    if (lr == LPR - 1) { moments[row * 2] = sm; moments[row * 2 + 1] = q; }
 }
 
 // The same reduction whose result leaves as split planes [N][M/16][2][2][P][8 halves] * out_scale (an operand sink behind a
@@ -1692,10 +1713,10 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     if (a.partial) {
         const int64_t total = N * Cout * H * W, HW = H * W;
         if (row_moments) {
-#define MVIP_RM(LPR_) hipLaunchKernelGGL((cv_split_reduce_moments_kernel<LPR_>), dim3((unsigned)(N * Cout / (256 / LPR_))), dim3(256), 0, \
-                                         st, a.partial, a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, bias, chan_add,    \
-                                         residual, y, row_moments)
-            if (HW == 64) MVIP_RM(16); else if (HW == 256) MVIP_RM(64); else MVIP_RM(256);
+#define MVIP_RM(LPR_, IT_) hipLaunchKernelGGL((cv_split_reduce_moments_kernel<LPR_, IT_>), dim3((unsigned)(N * Cout / (256 / LPR_))), \
+                                              dim3(256), 0, st, a.partial, a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, \
+                                              bias, chan_add, residual, y, row_moments)
+            if (HW == 64) MVIP_RM(16, 1); else if (HW == 256) MVIP_RM(64, 1); else if (HW == 1024) MVIP_RM(256, 1); else MVIP_RM(256, 4);
 #undef MVIP_RM
         } else {
             hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
