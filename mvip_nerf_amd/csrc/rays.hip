@@ -2,6 +2,7 @@
 // All HBM-bound, one element per thread, arithmetic written in the reference's operation order
 // (the library is built with -ffp-contract=off so a*b+c stays two roundings like torch's).
 #include "rays_device.h"
+#include <stdlib.h>
 
 namespace mvip {
 
@@ -115,6 +116,64 @@ __global__ void stratified_z4_kernel(const float *__restrict__ rows, int ncols, 
     *reinterpret_cast<float4 *>(z + r * S + s0) = out;
 }
 
+// One wavefront per 16 rays, lane = sample (S <= 64 IT): the kernels above are bound by IEEE divides (two per sample even
+// in the quad version: every depth is recomputed by its neighbours), not by memory.  Here each depth is computed ONCE --
+// one divide per sample in lindisp mode -- and the stratum bounds come from the neighbouring lanes (DPP wave shifts); the
+// two per-ray reciprocals are computed for the wave's rays at once, lane = ray, and broadcast through scalar registers.
+// Four rays per trip with their loads issued together; a ray's row of S depths is one contiguous 4 S-byte store per
+// register.  Same expressions in the same order as z_at: identical bits.
+constexpr int ZW_RAYS = 16;
+template <int IT>
+__global__ void __launch_bounds__(256)
+stratified_zw_kernel(const float *__restrict__ rows, int ncols, int64_t B, int S, const float *__restrict__ t_vals,
+                     int lindisp, const float *__restrict__ t_rand, float *__restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ZW_RAYS;
+    if (r0 >= B) return;
+    const int nr = (int)((B - r0 < ZW_RAYS) ? B - r0 : ZW_RAYS);
+    const int64_t rl = r0 + (lane < nr ? lane : nr - 1);
+    const float near_l = rows[rl * ncols + 6], far_l = rows[rl * ncols + 7];
+    const float inear_l = 1.f / near_l, ifar_l = 1.f / far_l;
+    float t[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) t[i] = (i * 64 + lane < S) ? t_vals[i * 64 + lane] : 0.f;
+    auto bc = [](float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
+    for (int k0 = 0; k0 < nr; k0 += 4) {
+        float tr[4][IT];
+        if (t_rand) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+                    tr[kk][i] = (k0 + kk < nr && i * 64 + lane < S) ? t_rand[(r0 + k0 + kk) * S + i * 64 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = k0 + kk;
+            if (k >= nr) break;
+            const float near = bc(near_l, k), far = bc(far_l, k), inear = bc(inear_l, k), ifar = bc(ifar_l, k);
+            float zc[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                zc[i] = lindisp ? 1.f / (inear * (1.f - t[i]) + ifar * t[i]) : near * (1.f - t[i]) + far * t[i];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int sidx = i * 64 + lane;
+                float o = zc[i];
+                if (t_rand) {
+                    const float prev_reg = i > 0 ? bc(zc[i > 0 ? i - 1 : 0], 63) : zc[i];        // sample 64 i - 1
+                    const float next_reg = i + 1 < IT ? bc(zc[i + 1 < IT ? i + 1 : i], 0) : zc[i];
+                    const float zl = dpp_from_prev(zc[i], prev_reg), zr = dpp_from_next(zc[i], next_reg);
+                    const float upper = sidx < S - 1 ? .5f * (zr + zc[i]) : zc[i];
+                    const float lower = sidx > 0 ? .5f * (zc[i] + zl) : zc[i];
+                    o = lower + (upper - lower) * tr[kk][i];
+                }
+                if (sidx < S) z[(r0 + k) * S + sidx] = o;
+            }
+        }
+    }
+}
+
 // run_nerf_helpers.py:27-52: channel c<3: x[c]; else m=c-3: octave m/6, fn (m%6)/3, dim m%3.
 // One thread per (point, slot): slot 0 copies the three coordinates, slot 1 + 3 oct + dim evaluates sin AND cos of
 // x[dim] * 2^oct (one argument, one range reduction) and writes channels 3 + 6 oct + dim and 6 + 6 oct + dim -- a wave's two
@@ -178,7 +237,14 @@ extern "C" int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S,
     if (B < 0 || S <= 0 || ncols < 8 || !t_vals || (B > 0 && (!rows || !z))) return MVIP_EINVAL;
     if (B == 0) return MVIP_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(t_rand)) & 15) == 0;
-    if (S % 4 == 0 && aligned)
+    static const int wave_env = [] { const char *e = getenv("MVIP_STRATIFIED_WAVE"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (wave_env && S >= 32 && S <= 256 && B >= 4096) {
+        const dim3 grid(blocks_for((B + ZW_RAYS - 1) / ZW_RAYS, 4));
+#define MVIP_ZW(I) hipLaunchKernelGGL((stratified_zw_kernel<I>), grid, dim3(256), 0, as_stream(stream), rows, ncols, B, S, t_vals, \
+                                      lindisp, t_rand, z)
+        if (S <= 64) MVIP_ZW(1); else if (S <= 128) MVIP_ZW(2); else MVIP_ZW(4);
+#undef MVIP_ZW
+    } else if (S % 4 == 0 && aligned)
         hipLaunchKernelGGL(stratified_z4_kernel, dim3(blocks_for(B * (S / 4), 256)), dim3(256), 0, as_stream(stream),
                            rows, ncols, B, S, t_vals, lindisp, t_rand, z);
     else

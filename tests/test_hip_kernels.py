@@ -75,6 +75,26 @@ def test_stratified_z(cuda, lindisp, perturb):
     np.testing.assert_allclose(N(z), ref.numpy(), rtol=3e-7, atol=0)
 
 
+@pytest.mark.parametrize('S', [64, 128, 96, 192, 40])
+@pytest.mark.parametrize('lindisp', [True, False])
+@pytest.mark.parametrize('perturb', [True, False])
+def test_stratified_z_wave_kernel_equals_quad_kernel(cuda, S, lindisp, perturb):
+    """Launches of >= 4096 rays take the one-divide-per-sample kernel (a wavefront per 16 rays, stratum bounds from the
+    neighbouring lanes); smaller launches the per-thread kernels.  Same expressions in the same order: bit-identical,
+    ragged ray counts and sample counts that do not fill the last register included; vs the oracle to 3e-7."""
+    from mvip_nerf_amd import ops
+    B = 8192 + 37
+    rows = torch.from_numpy(bench_like_rays(B, seed=9)).to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(S)
+    t_rand = torch.rand(B, S, device=cuda, generator=g) if perturb else None
+    z = ops.stratified_z(rows, S, lindisp, t_rand)
+    parts = [ops.stratified_z(rows[a:a + 2048].contiguous(), S, lindisp, None if t_rand is None else t_rand[a:a + 2048].contiguous())
+             for a in range(0, B, 2048)]
+    assert torch.equal(z, torch.cat(parts, 0))
+    ref = O.stratified_z(rows[:64, 6:7].cpu(), rows[:64, 7:8].cpu(), S, lindisp, None if t_rand is None else t_rand[:64].cpu())
+    np.testing.assert_allclose(N(z[:64]), ref.numpy(), rtol=3e-7, atol=0)
+
+
 # ---------------------------------------------------------------------------------------------- posenc
 @pytest.mark.parametrize('name,L', [('posenc_pts', 10), ('posenc_dirs', 4)])
 def test_posenc_golden(golden, cuda, name, L):
