@@ -192,8 +192,10 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t N, int L, flo
     }
     const int m = slot - 1, oct = m / 3, dim = m - 3 * oct;
     const float a = x[n * 3 + dim] * (float)(1 << oct);
-    yr[3 + 6 * oct + dim] = sinf(a);
-    yr[6 + 6 * oct + dim] = cosf(a);
+    float sn, cs;
+    sincosf(a, &sn, &cs);                  // one range reduction for both (same values as sinf / cosf: same ocml kernels)
+    yr[3 + 6 * oct + dim] = sn;
+    yr[6 + 6 * oct + dim] = cs;
 }
 
 static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }

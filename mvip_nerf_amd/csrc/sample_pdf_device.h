@@ -197,22 +197,38 @@ __device__ __forceinline__ int count_below(const float key, const float x) {
 // j + #{a <= b_j} (ties: the coarse depth first; the VALUES equal those of sort(cat[a, b]) in every case).  12
 // cross-lane reads and two scattered 4-byte stores into the ray's own 512-byte row instead of the 28-stage / 54-shuffle
 // bitonic network over 128 values.  Returns false (nothing written) if either list is not sorted.
+// below_hint (>= 0, or -1 for none): lane j's sample b_j was interpolated between the midpoints below_hint and below_hint + 1
+// (or sits on the last one) of the depths a -- what the inverse CDF knows anyway.  Then a_0 .. a_below <= b_j, so
+// #{a <= b_j} is below + 1 or below + 2, decided by ONE cross-lane read instead of a seven-step search; a second read
+// checks that the depth after that is strictly greater (it is, unless depths coincide or the interpolation rounded past
+// the upper midpoint), and the wave falls back to the search if any lane fails the check.  Only meaningful while b is in
+// its original lane order, i.e. when it did not have to be sorted.
 __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int nb, bool b_may_be_unsorted,
-                                             float *__restrict__ out_row) {
+                                             float *__restrict__ out_row, int below_hint = -1) {
     const int l = lane_id();
     const float a_key = l < na ? a : INFINITY;
     float b_key = l < nb ? b : INFINITY;
     const float a_next = dpp_from_next(a_key, a_key), b_next = dpp_from_next(b_key, b_key);
     if (__any(l < 63 && a_next < a_key)) return false;
+    bool b_in_lane_order = true;
     if (__any(l < 63 && b_next < b_key)) {
         if (!b_may_be_unsorted) return false;
         bitonic_sort64(b_key);                                   // random u: sort the 64 new samples (21 stages)
+        b_in_lane_order = false;
     }
     if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
     // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
     // +inf padding lanes of the other list and land beyond the ray's own row
     const int pa = l + min(count_below<true>(b_key, a_key), nb);
-    const int pb = l + min(count_below<false>(a_key, b_key), na);
+    int cb = -1;
+    if (b_in_lane_order && below_hint >= 0) {
+        const int r0 = below_hint + 1;                           // a_0 .. a_{r0 - 1} <= b_j
+        const float a0 = __shfl(a_key, r0 & 63, 64), a1 = __shfl(a_key, (r0 + 1) & 63, 64);
+        const float e0 = r0 < 64 ? a0 : INFINITY, e1 = r0 + 1 < 64 ? a1 : INFINITY;
+        cb = r0 + (e0 <= b_key ? 1 : 0);
+        if (__any(l < nb && !(e1 > b_key))) cb = -1;             // wave-uniform: the ballot covers every valid lane
+    }
+    const int pb = l + min(cb >= 0 ? cb : count_below<false>(a_key, b_key), na);
     if (l < na) out_row[pa] = a_key;
     if (l < nb) out_row[pb] = b_key;
     return true;
@@ -268,7 +284,7 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
     if constexpr (IT == 1) {
-        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf))) return;
+        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1))) return;
     }
     constexpr int M = 2 * IT;
     float v[M];

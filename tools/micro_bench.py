@@ -51,6 +51,8 @@ zc = ops.stratified_z(rows, 64, True)
 w = torch.rand(B, 64, device=dev, generator=g)
 u = torch.rand(B, 64, device=dev, generator=g)
 report('sample_pdf_merge Nc=Nf=64 (768 in + 772 out B/ray)', B * (768 + 772), timeit(lambda: ops.sample_pdf_merge(zc, w, u)))
+u_det = torch.linspace(0., 1., 64, device=dev)          # test-mode renders (perturb = 0): one sorted row shared by all rays, no sort of the new samples
+report('sample_pdf_merge Nc=Nf=64, deterministic u row (512 in + 772 out B/ray)', B * (512 + 772), timeit(lambda: ops.sample_pdf_merge(zc, w, u_det)))
 x = torch.randn(B * 16, 3, device=dev, generator=g)
 report('posenc L=10 (12 in + 252 out B/point)', x.shape[0] * 264, timeit(lambda: ops.posenc(x, 10)))
 # reference point: a plain device copy of 1 GB
