@@ -198,6 +198,67 @@ __global__ void posenc_kernel(const float *__restrict__ x, int64_t N, int L, flo
     yr[6 + 6 * oct + dim] = cs;
 }
 
+// The same encoding with the arithmetic the structure allows: the arguments of a coordinate are x, 2x, 4x, ... -- EXACT
+// doublings -- so ONE range reduction per coordinate (fp64: r = x - n 2 pi) serves all octaves: the reduced angle is doubled
+// and wrapped back into [-pi, pi] in fp64 (error 2^-53 per step, doubled L - 1 times: nothing at fp32), reduced to a quadrant,
+// and a degree-7 / degree-8 polynomial pair (Cephes sinf / cosf coefficients, |r| <= pi/4) gives sin and cos -- ~35
+// instruction-equivalents per octave instead of ~150 for an accurate sincosf of a large argument (posenc_kernel is bound by
+// exactly that: 0.26 of HBM).  Agreement with fp64 sin / cos of the exact argument: <= 1.5e-7 absolute (sinf / cosf: <= 6e-8);
+// |x| > 2^20 keeps the library functions.  thread = point; the workgroup's 256 x C tile is assembled in LDS (row stride C = 3 +
+// 6 L is odd: conflict-free) and leaves as one contiguous run of 16-byte stores.
+__device__ __forceinline__ void sincos_quadrant(double r, float &sn, float &cs) {
+    const double q = rint(r * 0.63661977236758134308);                  // 2 / pi
+    const float f = (float)fma(-q, 1.57079632679489661923, r);          // |f| <= pi / 4
+    const float z = f * f;
+    const float ps = f + f * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float pc = 1.f - .5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const int qi = (int)q & 3;
+    const float a = (qi & 1) ? pc : ps, b = (qi & 1) ? ps : pc;
+    sn = (qi & 2) ? -a : a;                                             // q = 1: sin = cos f, cos = -sin f; q = 2: both negated
+    cs = ((qi + 1) & 2) ? -b : b;
+}
+
+template <int LMAX>
+__global__ void __launch_bounds__(256) posenc_tile_kernel(const float *__restrict__ x, int64_t N, int L, float *__restrict__ y) {
+    extern __shared__ float tile[];                                     // [256][C]
+    const int C = 3 + 6 * L;
+    const int64_t n0 = (int64_t)blockIdx.x * 256, n = n0 + threadIdx.x;
+    if (n < N) {
+        float *row = tile + threadIdx.x * C;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float xv = x[n * 3 + d];
+            row[d] = xv;
+            if (fabsf(xv) <= 1048576.f) {
+                const double k = rint((double)xv * 0.15915494309189533577);                 // 1 / (2 pi)
+                double r = fma(-k, 6.28318530717958647692, (double)xv);
+                for (int o = 0; o < L; ++o) {
+                    float sn, cs;
+                    sincos_quadrant(r, sn, cs);
+                    row[3 + 6 * o + d] = sn;
+                    row[6 + 6 * o + d] = cs;
+                    r += r;                                                                 // the next octave's angle, wrapped
+                    r = r > 3.14159265358979323846 ? r - 6.28318530717958647692 : (r < -3.14159265358979323846 ? r + 6.28318530717958647692 : r);
+                }
+            } else {
+                for (int o = 0; o < L; ++o) {
+                    float sn, cs;
+                    sincosf(xv * (float)(1 << o), &sn, &cs);
+                    row[3 + 6 * o + d] = sn;
+                    row[6 + 6 * o + d] = cs;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t cnt = ((N - n0 < 256) ? N - n0 : 256) * C;             // floats of this tile; its base n0 * C * 4 B is 16-byte aligned
+    float *dst = y + n0 * C;
+    const int64_t c4 = cnt >> 2;
+    for (int64_t i = threadIdx.x; i < c4; i += 256)
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(tile[4 * i], tile[4 * i + 1], tile[4 * i + 2], tile[4 * i + 3]);
+    for (int64_t i = (c4 << 2) + threadIdx.x; i < cnt; i += 256) dst[i] = tile[i];
+}
+
 static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace mvip
@@ -258,7 +319,12 @@ extern "C" int mvip_stratified_z(const float *rows, int ncols, int64_t B, int S,
 extern "C" int mvip_posenc(const float *x, int64_t N, int L, float *y, void *stream) {
     if (N < 0 || L < 0 || L > 16 || (N > 0 && (!x || !y))) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
-    hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(N * (1 + 3 * L), 256)), dim3(256), 0, as_stream(stream),
-                       x, N, L, y);
+    static const int tile_env = [] { const char *e = getenv("MVIP_POSENC_TILE"); return e ? atoi(e) : 1; }();       // A/B switch
+    if (tile_env && L >= 1 && L <= 10 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)        // 256 x (3 + 6 L) floats of LDS <= 64 KB
+        hipLaunchKernelGGL((posenc_tile_kernel<16>), dim3(blocks_for(N, 256)), dim3(256), 256 * (3 + 6 * L) * sizeof(float),
+                           as_stream(stream), x, N, L, y);
+    else
+        hipLaunchKernelGGL(posenc_kernel, dim3(blocks_for(N * (1 + 3 * L), 256)), dim3(256), 0, as_stream(stream),
+                           x, N, L, y);
     return check_launch();
 }

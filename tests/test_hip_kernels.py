@@ -75,6 +75,26 @@ def test_stratified_z(cuda, lindisp, perturb):
     np.testing.assert_allclose(N(z), ref.numpy(), rtol=3e-7, atol=0)
 
 
+@pytest.mark.parametrize('L', [10, 4, 1])
+def test_posenc_vs_fp64(cuda, L):
+    """The materialised encoding against fp64 sin / cos of the EXACT arguments x 2^k (the products are exact in fp32):
+    <= 1.5e-7 absolute (one shared range reduction per coordinate + quadrant polynomials, csrc/rays.hip), ragged point
+    counts, a zero, negative and large coordinates (|x| > 2^20 takes the library sincosf)."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(1000 + 37, 3, generator=g) * 4.0
+    x[0] = torch.tensor([0.0, -0.0, 3.14159274])
+    x[1] = torch.tensor([1e-8, -7.5, 100.25])
+    x[2] = torch.tensor([2.0e6, -3.0e7, 1048576.0])
+    y = N(ops.posenc(x.to(cuda), L)).astype(np.float64)
+    xd = x.numpy().astype(np.float64)
+    ref = [xd]
+    for k in range(L):
+        ref += [np.sin(xd * 2.0 ** k), np.cos(xd * 2.0 ** k)]
+    ref = np.concatenate(ref, -1)
+    assert np.abs(y - ref).max() <= 1.5e-7, np.abs(y - ref).max()
+
+
 @pytest.mark.parametrize('S', [64, 128, 96, 192, 40])
 @pytest.mark.parametrize('lindisp', [True, False])
 @pytest.mark.parametrize('perturb', [True, False])
