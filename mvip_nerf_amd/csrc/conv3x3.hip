@@ -335,10 +335,14 @@ cv_to_split_up2_kernel(const float *__restrict__ x, const float *__restrict__ sc
 // filled), so the convolution is mvip_gemm_f16x3 with the natural weight [Cout][Cin*KH*KW] as the A operand; the data
 // gradient is the GEMM with A^T into col[N][KP][PP] followed by the gather below.
 // grid (ceil(PP/256), N*KP/16): thread = output pixel, 16 consecutive k.
+// KH_T, KW_T > 0: the kernel size as a compile-time constant (3 x 3 and 1 x 1: every layer of the SDS networks) -- the 32
+// divisions by `taps` and KW per thread become multiplications; with run-time divisors this writer was bound by them.
+template <int KH_T, int KW_T>
 __global__ void __launch_bounds__(256)
-cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int KH, int KW, int stride, int pad_top,
+cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int KH_, int KW_, int stride, int pad_top,
                        int pad_left, int OH, int OW, int KP, int64_t PP, const float *__restrict__ scale2,
                        uint4 *__restrict__ xs, int prec) {
+    const int KH = KH_T > 0 ? KH_T : KH_, KW = KW_T > 0 ? KW_T : KW_;
     const int CKP = KP / 16;
     const int ck = (int)(blockIdx.y % CKP);
     const int64_t n = blockIdx.y / CKP;
@@ -347,7 +351,8 @@ cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int K
     const float s = scale2 ? scale2[0] : 1.f;
     const int taps = KH * KW, K = Cin * taps;
     const bool inside = p < (int64_t)OH * OW;
-    const int oy = inside ? (int)(p / OW) : 0, ox = inside ? (int)(p % OW) : 0;
+    const unsigned pu = (unsigned)p;                                   // OH * OW <= 2^30 (checked by the caller)
+    const int oy = inside ? (int)(pu / (unsigned)OW) : 0, ox = inside ? (int)(pu - (unsigned)oy * (unsigned)OW) : 0;
     const float *xn = x + n * Cin * H * W;
     // all 16 gathers are issued before any is used: a load under its own `if` is followed by s_waitcnt vmcnt(0), i.e. 16
     // exposed memory latencies per thread (invalid taps read element 0 and are zeroed afterwards)
@@ -382,22 +387,28 @@ cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int K
 }
 
 // dx[n][ci][iy][ix] = sum over the (ky, kx) whose output pixel exists of col[n][ci*KH*KW + ky*KW + kx][oy*OW + ox]:
-// a gather (deterministic), one thread per input element
+// a gather (deterministic), one thread per input element; grid (ceil(H W / 256), N * Cin).  KH_T, KW_T, ST_T > 0: kernel
+// size and stride as compile-time constants (the tap loops unroll, `% stride` and `/ stride` become shifts, and the flat
+// 64-bit index with its four divisions per thread is gone: that arithmetic, not memory, bounded the run-time version).
+template <int KH_T, int KW_T, int ST_T>
 __global__ void __launch_bounds__(256)
-cv_col2im_kernel(const float *__restrict__ col, int64_t total, int Cin, int H, int W, int KH, int KW, int stride,
-                 int pad_top, int pad_left, int OH, int OW, int KP, int64_t PP, float *__restrict__ dx) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int ix = (int)(idx % W), iy = (int)((idx / W) % H);
-    const int ci = (int)((idx / ((int64_t)W * H)) % Cin);
-    const int64_t n = idx / ((int64_t)W * H * Cin);
+cv_col2im_kernel(const float *__restrict__ col, int Cin, int H, int W, int KH_, int KW_, int stride_, int pad_top, int pad_left,
+                 int OH, int OW, int KP, int64_t PP, float *__restrict__ dx) {
+    const int KH = KH_T > 0 ? KH_T : KH_, KW = KW_T > 0 ? KW_T : KW_, stride = ST_T > 0 ? ST_T : stride_;
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;                  // H * W <= 2^30 (checked by the caller)
+    if (p >= (unsigned)(H * W)) return;
+    const int iy = (int)(p / (unsigned)W), ix = (int)(p - (unsigned)iy * (unsigned)W);
+    const int ci = (int)(blockIdx.y % (unsigned)Cin);
+    const int64_t n = blockIdx.y / (unsigned)Cin;
     const float *cn = col + n * KP * PP;
     float acc = 0.f;
+#pragma unroll
     for (int ky = 0; ky < KH; ++ky) {
         const int ty = iy + pad_top - ky;
         if (ty < 0 || ty % stride != 0) continue;
         const int oy = ty / stride;
         if (oy >= OH) continue;
+#pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             const int tx = ix + pad_left - kx;
             if (tx < 0 || tx % stride != 0) continue;
@@ -406,7 +417,7 @@ cv_col2im_kernel(const float *__restrict__ col, int64_t total, int Cin, int H, i
             acc += cn[(int64_t)(ci * KH * KW + ky * KW + kx) * PP + (int64_t)oy * OW + ox];
         }
     }
-    dx[idx] = acc;
+    dx[((n * Cin + ci) * H + iy) * (int64_t)W + ix] = acc;
 }
 
 // ---- the convolution -------------------------------------------------------------------------------------
@@ -1548,8 +1559,11 @@ extern "C" int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, 
     if (N == 0) return MVIP_OK;
     if (!x || !xs || N * (KP / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((PP + 255) / 256), (unsigned)(N * (KP / 16)));
-    hipLaunchKernelGGL(cv_im2col_split_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)Cin, (int)H, (int)W, KH, KW,
-                       stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, scale2, (uint4 *)xs, prec);
+#define MVIP_I2C(A, B) hipLaunchKernelGGL((cv_im2col_split_kernel<A, B>), grid, dim3(256), 0, as_stream(stream), x, (int)Cin, (int)H, \
+                                          (int)W, KH, KW, stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, scale2,      \
+                                          (uint4 *)xs, prec)
+    if (KH == 3 && KW == 3) MVIP_I2C(3, 3); else if (KH == 1 && KW == 1) MVIP_I2C(1, 1); else MVIP_I2C(0, 0);
+#undef MVIP_I2C
     return check_launch();
 }
 
@@ -1561,9 +1575,15 @@ extern "C" int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, 
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!col || !dx) return MVIP_EINVAL;
-    const int64_t total = N * Cin * H * W;
-    hipLaunchKernelGGL(cv_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), col, total,
-                       (int)Cin, (int)H, (int)W, KH, KW, stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, dx);
+    if (N * Cin > 65535) return MVIP_EINVAL;
+    const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)(N * Cin));
+#define MVIP_C2I(A, B, C) hipLaunchKernelGGL((cv_col2im_kernel<A, B, C>), grid, dim3(256), 0, as_stream(stream), col, (int)Cin, (int)H, \
+                                             (int)W, KH, KW, stride, pad_top, pad_left, (int)OH, (int)OW, (int)KP, PP, dx)
+    if (KH == 3 && KW == 3 && stride == 2) MVIP_C2I(3, 3, 2);
+    else if (KH == 3 && KW == 3 && stride == 1) MVIP_C2I(3, 3, 1);
+    else if (KH == 1 && KW == 1 && stride == 1) MVIP_C2I(1, 1, 1);
+    else MVIP_C2I(0, 0, 0);
+#undef MVIP_C2I
     return check_launch();
 }
 
