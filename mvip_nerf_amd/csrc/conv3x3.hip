@@ -742,9 +742,14 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
                                        const float *__restrict__ w_scale2, const float *__restrict__ x_scale2,
                                        const float *__restrict__ bias, const float *__restrict__ chan_add,
                                        const float *__restrict__ residual, float *__restrict__ y) {
-    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;        // HW % 4 == 0: four pixels of one channel
-    if (i4 >= total) return;
+    // grid (ceil(HW / 1024), N * Cout): the row (n, co) is the block's y index -- a flat 64-bit index cost two 64-bit
+    // divisions per thread, as much time as the memory traffic of these small tensors
+    const int64_t p4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;        // HW % 4 == 0: four pixels of one channel
+    if (p4 >= HW) return;
     const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
+    const unsigned rows = (unsigned)(total / HW);      // wave-uniform; N * Cout < 2^31
+  for (unsigned nc = blockIdx.y; nc < rows; nc += gridDim.y) {                      // n * Cout + co (one trip unless rows > 65535)
+    const int64_t i4 = (int64_t)nc * HW + p4;
     f32x4 sum = *reinterpret_cast<const f32x4 *>(partial + i4);
     int s = 1;
     for (; s + 3 < splits; s += 4) {                   // four loads in flight, added in index order
@@ -755,12 +760,12 @@ __global__ void cv_split_reduce_kernel(const float *__restrict__ partial, int sp
         sum += p0; sum += p1; sum += p2; sum += p3;
     }
     for (; s < splits; ++s) sum += *reinterpret_cast<const f32x4 *>(partial + (int64_t)s * total + i4);
-    const int64_t nc = i4 / HW;                        // n * Cout + co
     f32x4 v = sum * inv;                               // same order of roundings as the unsplit epilogue
-    if (bias) v += bias[nc % Cout];
+    if (bias) v += bias[nc % (unsigned)Cout];
     if (chan_add) v += chan_add[nc];
     if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i4);
     *reinterpret_cast<f32x4 *>(y + i4) = v;
+  }
 }
 
 // The same reduction that also leaves the GroupNorm moments of its OUTPUT rows, in the layout gn_moments_kernel
@@ -778,7 +783,7 @@ cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, in
     const int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x / LPR;             // n * Cout + co
     const int lr = threadIdx.x % LPR;
     const float inv = w_scale2[1] * (x_scale2 ? x_scale2[1] : 1.f);
-    const float bv = bias ? bias[row % Cout] : 0.f, cv = chan_add ? chan_add[row] : 0.f;
+    const float bv = bias ? bias[(unsigned)row % (unsigned)Cout] : 0.f, cv = chan_add ? chan_add[row] : 0.f;      // N * Cout < 2^31
     double sm = 0.0, q = 0.0;
     const int64_t i0 = row * HW + (int64_t)lr * 4;        // IT pieces of LPR * 4 values per row, all loads of a split in flight
     f32x4 sum[IT], rv[IT];
@@ -1741,8 +1746,8 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
             if (HW == 64) MVIP_RM(16, 1); else if (HW == 256) MVIP_RM(64, 1); else if (HW == 1024) MVIP_RM(256, 1); else MVIP_RM(256, 4);
 #undef MVIP_RM
         } else {
-            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
-                               a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)(N * Cout > 65535 ? 65535 : N * Cout)), dim3(256), 0, st,
+                               a.partial, a.splits, total, (int)Cout, HW, a.w_scale2, x_scale2, bias, chan_add, residual, y);
         }
     }
     return check_launch();
@@ -1898,8 +1903,8 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
             hipLaunchKernelGGL((gemm_f16x3_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         if (a.partial) {
             const int64_t total = N * M * P;
-            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a.partial,
-                               a.splits, total, (int)M, P, a.w_scale2, x_scale2, bias, chan_add, residual, y);
+            hipLaunchKernelGGL(cv_split_reduce_kernel, dim3((unsigned)((P / 4 + 255) / 256), (unsigned)(N * M > 65535 ? 65535 : N * M)), dim3(256), 0, st,
+                               a.partial, a.splits, total, (int)M, P, a.w_scale2, x_scale2, bias, chan_add, residual, y);
         }
     }
     return check_launch();
