@@ -235,7 +235,7 @@ def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path):
     tr, te, _, grad_vars, opt = run.create_nerf(args, device=cuda)
     kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
     g = torch.Generator(device=cuda).manual_seed(0)
-    for it in range(300):
+    for it in range(1500):
         v = i_train[int(torch.randint(0, len(i_train), (1,), generator=g, device=cuda))]
         sel = torch.randint(0, H * W, (4096,), generator=g, device=cuda)
         rows = ops.ray_rows_from_pose(poses[v], H, W, focal, near, far, sel=sel)
@@ -263,6 +263,7 @@ def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path):
     gt = images[held].cpu().reshape(-1, 3)[sel]
     psnr = lambda x: float(-10 * torch.log10(((x - gt) ** 2).mean()))
     p_h, p_o = psnr(hip[sel]), psnr(ora)
-    assert p_h > 14.0                                          # 300 iterations already explain the view
+    assert p_h > 20.0                                          # 1,500 iterations of 4,096 rays: past the coarse fit (3,000: 24.7 dB,
+                                                               # profiles/r3_real_scene1.json)
     assert abs(p_h - p_o) < 0.05, (p_h, p_o)
     assert float(-10 * torch.log10(((hip[sel] - ora) ** 2).mean())) > 60.0        # HIP vs oracle, same weights
