@@ -3,8 +3,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one pass of the hot path over one batch of synthetic input: one 378x504 frame
-(190,512 rays), coarse 64 + fine 128 samples, test-mode kwargs, per rank.  `value` = rays/s over all ranks (weak
-scaling: every rank renders its own frames, no data-path collective).  Further legs in the same JSON line: the
+(190,512 rays), coarse 64 + fine 128 samples, test-mode kwargs.
+  N = 1: `value` = rays/s of whole frames on the one GPU.
+  N > 1: `value` = STRONG-scaling rays/s of the SAME frame sequence -- each frame's rays cut into N contiguous blocks
+         (run.render_sharded: rank r renders block r, ONE all_gather of [rays, 6] = (rgb, disp, acc, depth) leaves the
+         maps on every rank), `scaling: "strong"`; a scaling curve that CAN fail.  Beside it: `weak_rays_per_sec` (every
+         rank renders its own whole frames, no collective: N x by construction), `value_1_same_run` (one rank's
+         whole-frame rate from that weak leg) and `strong_efficiency = value / (N * value_1_same_run)`.
+Further legs in the same JSON line: the
 second-stage training iteration (rays sharded, ONE 4.77 MB gradient all-reduce), the SDS step with its own roofline
 (FLOPs counted from the layer shapes), the full BASELINE configs[1]/[2]/[3] iterations (SDS terms owned by different
 ranks), and the CPU baseline (oracle on the host cores: render, train and SDS legs, >= 3 warm-ups, median of >= 5).
@@ -160,7 +166,7 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
     tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
     traffic, src = None, None
-    for name in ('r2_pmc_mlp_forward.json', 'r1_pmc_mlp_forward.json'):     # separate --pmc passes of this launch
+    for name in ('r4_pmc_mlp_forward.json', 'r3_pmc_mlp_forward.json', 'r2_pmc_mlp_forward.json'):     # separate --pmc passes of this launch, newest first
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
@@ -299,8 +305,25 @@ def dry_run(world, rank, args):
         t = torch.tensor([float(rank)])
         dist.all_reduce(t)
         assert float(t) == world * (world - 1) / 2
+    # the strong-scaling headline's collective on CPU tensors: a 7 x 5 "frame" of ray rows rendered by a stand-in
+    from mvip_nerf_amd import run as run_mod
+    Hd, Wd = 7, 5
+    rows_all = torch.arange(Hd * Wd * 11, dtype=torch.float32).reshape(Hd * Wd, 11)
+
+    def fake_render_rays(ray_batch, **kw):
+        v = ray_batch[:, 0]
+        return {'rgb_map': torch.stack([v, v + 1, v + 2], -1), 'disp_map': v * 2, 'acc_map': v * 3, 'depth_map': v * 4}
+    real_rr, run_mod.render_rays = run_mod.render_rays, fake_render_rays
+    try:
+        maps = run_mod.render_sharded(Hd, Wd, 1.0, None, rank, world, dist if world > 1 else None, chunk=4,
+                                      row_fn=lambda lo, hi: rows_all[lo:hi])
+    finally:
+        run_mod.render_rays = real_rr
+    v = rows_all[:, 0]
+    assert torch.equal(maps[0], torch.stack([v, v + 1, v + 2], -1).reshape(Hd, Wd, 3)) and torch.equal(maps[3], (v * 4).reshape(Hd, Wd))
     result.update({'metric': 'dry-run (launcher only)', 'value': 0.0, 'unit': 'rays/s', 'n_gpus': world,
-              'steps': args.steps, 'warmup': args.warmup,
+              'steps': args.steps, 'warmup': args.warmup, 'scaling': 'strong' if world > 1 else 'weak',
+              'weak_rays_per_sec': 0.0, 'strong_efficiency': None, 'sharded_frame_assembled': True,
               'multi_gpu': {'rccl_world': dist.get_world_size() if world > 1 else 1,
                             'backend': dist.get_backend() if world > 1 else None}})
 
@@ -366,41 +389,67 @@ def main():
     torch.manual_seed(0)
     tr, te, start, grad_vars, opt = run.create_nerf(make_args(), device=device)
 
-    def step(k):
+    def step(k):                                    # one WHOLE frame on this rank (N = 1 headline; the weak leg at N > 1)
         with torch.no_grad():
             out = run.render(H, W, FOCAL, chunk=1 << 15, c2w=orbit_pose(k * world + rank, device), near=NEAR,
                              far=FAR, **te)
         return out[0]
+
+    def step_strong(k):                             # ONE frame over all ranks: rays in contiguous blocks, maps all-gathered
+        with torch.no_grad():
+            return run.render_sharded(H, W, FOCAL, orbit_pose(k, device), rank, world, dist, chunk=1 << 15, near=NEAR,
+                                      far=FAR, **te)[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(fn):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        for k in range(args.warmup):
+            fn(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            fn(args.warmup + k)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
 
-    rays_per_step = H * W * world
+    rays_per_step = H * W * world                    # of the weak form (one frame per rank)
+    workload = ('render 378x504 frame, 64 coarse + 128 fine samples, 8x256 MLP x2, lindisp, '
+                'white_bkgd, test-mode kwargs (BASELINE configs[1] geometry at the metric resolution)')
+    if world == 1:
+        dt = timed(step)
+        value, scaling, extra = H * W * args.steps / dt, 'weak', {}
+        par = 'rays x1 (whole frames on one GPU)'
+    else:
+        dt_weak = timed(step)                        # every rank its own frames, no collective: N x by construction
+        dt = timed(step_strong)                      # the headline at N > 1: fixed work, one frame over all ranks
+        value, scaling = H * W * args.steps / dt, 'strong'
+        v1 = H * W * args.steps / dt_weak            # one rank's whole-frame rate in this same run (slowest rank)
+        extra = {'weak_rays_per_sec': rays_per_step * args.steps / dt_weak, 'weak_ms_per_step': dt_weak / args.steps * 1e3,
+                 'value_1_same_run': v1, 'strong_efficiency': value / (world * v1),
+                 'strong_what': 'each frame cut into N contiguous ray blocks (run.render_sharded), ONE all_gather of '
+                                f'[{H * W}, 6] fp32 = {H * W * 24 / 1e6:.2f} MB per frame so every rank holds rgb / disp / acc / depth; '
+                                'value_1_same_run = whole frames on one rank (the weak leg, slowest rank)'}
+        par = (f'one frame over {world} ranks: contiguous ray blocks of {-(-H * W // world)} rays, one all_gather of the maps '
+               'per frame (RCCL over xGMI)')
     result.update({
-        'metric': 'rays_per_sec (coarse+fine, 64+128 samples, 504x378)', 'value': rays_per_step * args.steps / dt,
+        'metric': 'rays_per_sec (coarse+fine, 64+128 samples, 504x378)', 'value': value,
         'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'render 378x504 frame, 64 coarse + 128 fine samples, 8x256 MLP x2, lindisp, '
-                               'white_bkgd, test-mode kwargs (BASELINE configs[1] geometry at the metric resolution)',
-                   'rays_per_step_per_gpu': H * W, 'points_per_ray': 192, 'chunk': 1 << 15,
-                   'parallelism': f'rays x{world} (one frame per rank, no data-path collective)'},
+        'config': {'workload': workload,
+                   'rays_per_step_per_gpu': H * W if world == 1 else -(-H * W // world), 'points_per_ray': 192, 'chunk': 1 << 15,
+                   'parallelism': par},
     })
+    result.update(extra)
     mg = {'rccl_world': dist.get_world_size() if dist is not None else 1,
           'backend': dist.get_backend() if dist is not None else None}
     result['multi_gpu'] = mg
@@ -577,7 +626,8 @@ def main():
             # (StableDiffusion.use_graphs defaults to True for the built-in networks; thread-local capture, so a live RCCL
             # communicator's watchdog thread does not disturb it) -- and the same step launch by launch
             n_sds = max(args.sds_steps, 3)
-            sds_times = timed_steps(sd, 1e-4, world == 1, n_sds)       # (eager next to a live multi-rank group, as the default is)
+            graphs_ok = world == 1 or os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') == '1'    # eager next to a live multi-rank group unless asked
+            sds_times = timed_steps(sd, 1e-4, graphs_ok, n_sds)
             dt_sds = float(np.median(sds_times)) * args.sds_steps
             ms_eager32 = float(np.median(timed_steps(sd, 1e-4, False, n_sds))) * 1e3
             # the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66) on the SAME hand-written kernels in their
@@ -592,7 +642,7 @@ def main():
                 except Exception as e:                            # reported, never fatal for the bench line
                     print(f'[bench] fp16-mode leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
                 torch.cuda.empty_cache()
-            sd.use_graphs = world == 1
+            sd.use_graphs = graphs_ok
             opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                         text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                         colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
@@ -658,10 +708,12 @@ def main():
             sds_ms = dt_sds / args.sds_steps * 1e3
             ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc_sds = os.path.join(ROOT, 'profiles', 'r3_pmc_sds_traffic.json')
-            if os.path.exists(pmc_sds):
-                traffic = json.load(open(pmc_sds)).get('hbm_bytes_per_step')
-                traffic_src = 'profiles/r3_pmc_sds_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one eager step, per kernel)'
+            for name in ('r4_pmc_sds_traffic.json', 'r3_pmc_sds_traffic.json'):                 # newest first
+                pmc_sds = os.path.join(ROOT, 'profiles', name)
+                if os.path.exists(pmc_sds):
+                    traffic = json.load(open(pmc_sds)).get('hbm_bytes_per_step')
+                    traffic_src = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over eager steps, per kernel)'
+                    break
             sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
                         'algorithmic_hbm_bytes': fl['bytes_per_step'], 'traffic': traffic, 'traffic_unit': 'HBM bytes per step',
                         'traffic_source': traffic_src,
@@ -680,7 +732,8 @@ def main():
                              'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 relative)',
                              'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
                              'mode': ('one captured hipGraph per (shape, prompt): the default of StableDiffusion for the built-in networks'
-                                      if world == 1 else 'eager (the default next to a live multi-rank process group)'),
+                                      + ('' if world == 1 else ' (MVIP_GRAPHS_WITH_DIST=1: replay beside a live multi-rank process group)')
+                                      if graphs_ok else 'eager (the default next to a live multi-rank process group)'),
                              'ms_per_step_eager': ms_eager32,
                              'ms_per_step_fp16_hipgraph': ms_graph16, 'ms_per_step_fp16_eager': ms_eager16,
                              'fp16_what': "the reference's --fp16 mode on the same hand-written kernels, single fp16 product per "
@@ -691,7 +744,7 @@ def main():
             mg['what'] = ('STRONG-scaling legs (fixed work, rays and SDS terms sharded over the ranks): train_ms = second-stage '
                           'iteration without the prior, train_with_sds_ms = configs[1] iteration, config2_ms / config3_ms = '
                           'configs[2] / configs[3] iterations at the metric resolution; allreduce_ms = the 4.77 MB gradient '
-                          'bucket alone.  The headline `value` is weak scaling (one frame per rank, no collective)')
+                          'bucket alone.  The headline `value` at N > 1 is strong scaling too (one frame over all ranks)')
             result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
                                         'iterations_per_sec': args.sds_steps / dt_full,
                                         'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '

@@ -31,9 +31,12 @@ extern "C" {
 #define MVIP_ELAUNCH  -2   /* hipLaunch / runtime error (see mvip_last_hip_error) */
 #define MVIP_EUNSUP   -3   /* shape outside what the kernels are built for */
 
-#define MVIP_ABI_VERSION 2      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points */
+#define MVIP_ABI_VERSION 3      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points;
+                                   3: prec = 2 (two products for fp16-exact weights), mvip_packed_weights_two_product,
+                                      mvip_build_is_experiment */
 
 int         mvip_abi_version(void);
+int         mvip_build_is_experiment(void); /* 1: compiled with a -DMVIP_EXPERIMENT_* macro (timing build, WRONG results) */
 const char *mvip_strerror(int code);
 const char *mvip_last_hip_error(void);      /* text of the last HIP error seen by this thread */
 int         mvip_device_info(int *n_cu, int *lds_bytes, char *arch_out, int arch_cap);
@@ -310,6 +313,12 @@ int mvip_groupnorm_stats(const void *x, int64_t N, int64_t C, int64_t HW, int G,
 int mvip_conv3x3_supported(int64_t Cout, int64_t Cin, int64_t H, int64_t W);
 int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin);
 int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed, void *stream);
+/* Pack-time query (round 4): *two_product_host = 1 when every lo fragment of a packed WEIGHT image is zero, i.e. the
+ * (power-of-two scaled) weights are exact fp16 values -- true for every weight the reference loads
+ * (DS_NeRF/guidance/sd_utils.py:69-74: `revision="fp16"`, cast up to fp32 in the default mode).  Such an image may be
+ * contracted with prec = 2.  fragment_bytes = the image's size without its 256-byte tail: Cout * Cin * 36
+ * (mvip_conv3x3_pack) or M * K * 4 (mvip_gemm_pack_a).  Synchronises `stream` and reads one word back: not for the step. */
+int mvip_packed_weights_two_product(const void *packed, int64_t fragment_bytes, int *two_product_host, void *stream);
 int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *zero_words2, void *stream);
 int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs,
                       int prec, void *stream);
@@ -441,7 +450,14 @@ int mvip_attention_f16x3(const void *qs, const void *ks, const void *vp, const f
  * the fp32 networks); 1 = the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66, DS_NeRF/run.py:251): ONE fp16
  * product per step, fp32 accumulate -- producers write the hi planes only, contractions fetch hi planes / hi weight
  * fragments only (a third of the matrix work, half the operand traffic; ~1e-3 relative, fp16-grade).  Operand buffers have
- * the same size and layout in both modes. */
+ * the same size and layout in both modes.
+ * 2 (round 4; the CONTRACTIONS that take a packed weight image: mvip_conv3x3_f16x3*, mvip_gemm_f16x3*,
+ * mvip_gemm_geglu_f16x3*, mvip_gemm_f16x3_sinks, mvip_gemm_f16x3_planes_ws) = TWO products, Wh.Xh + Wh.Xl: the caller
+ * asserts that the image's lo fragments are zero (mvip_packed_weights_two_product said 1).  The third product of prec 0
+ * would add exact zeros, so every output bit equals prec 0's, with a third less matrix work and half the weight-operand
+ * bytes.  Activations are split and fetched as for prec 0 (producers take 0 or 1, and treat 2 as 0); a launch shape
+ * without a two-product instantiation silently runs the three-product kernel (same result).  With prec = 1 a shape
+ * without a single-product instantiation returns MVIP_EUNSUP (its lo planes were never written). */
 /* Contractions that hand each other OPERANDS (round 3; same call sites: the unet(...) call of
  * DS_NeRF/guidance/sd_utils.py:390-403 / :240).  Between two contractions of a transformer block the reference
  * materialises an fp32 tensor; rounds 1-2 of this library followed it with an absolute-maximum pass and a split pass.

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmvipnerf.so')
+# MVIP_LIB_PATH: another build of the same library (tools/: the -DMVIP_EXPERIMENT_* timing builds live in lib_experiment/)
+LIB_PATH = os.environ.get('MVIP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libmvipnerf.so')
 
 _c_f = ctypes.c_void_p      # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -18,6 +19,7 @@ _flt = ctypes.c_float
 
 _SIGNATURES = {
     'mvip_abi_version': (_int, []),
+    'mvip_build_is_experiment': (_int, []),
     'mvip_strerror': (ctypes.c_char_p, [_int]),
     'mvip_last_hip_error': (ctypes.c_char_p, []),
     'mvip_device_info': (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.c_char_p, _int]),
@@ -74,6 +76,7 @@ _SIGNATURES = {
     'mvip_conv3x3_supported': (_int, [_i64, _i64, _i64, _i64]),
     'mvip_conv3x3_packed_bytes': (_i64, [_i64, _i64]),
     'mvip_conv3x3_pack': (_int, [_c_f, _i64, _i64, _int, _c_f, _c_f]),
+    'mvip_packed_weights_two_product': (_int, [_c_f, _i64, ctypes.POINTER(_int), _c_f]),
     'mvip_absmax_scale': (_int, [_c_f, _i64, _c_f, _c_f, _c_f]),
     'mvip_split_planes': (_int, [_c_f, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
     'mvip_groupnorm_split_planes': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _c_f, _int, _c_f]),
@@ -138,6 +141,7 @@ _SIGNATURES = {
 DECLARED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
+ABI_VERSION = 3
 
 
 class MvipError(RuntimeError):
@@ -158,8 +162,11 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mvip_abi_version() != 2:
+    if lib.mvip_abi_version() != ABI_VERSION:
         raise MvipError('libmvipnerf.so ABI version mismatch')
+    if lib.mvip_build_is_experiment() and os.environ.get('MVIP_ALLOW_EXPERIMENT_BUILD') != '1':
+        raise MvipError(f'{LIB_PATH} was compiled with -DMVIP_EXPERIMENT_* (timing experiment, wrong results): rebuild with '
+                        '`python -m mvip_nerf_amd.csrc.build`, or set MVIP_ALLOW_EXPERIMENT_BUILD=1 for the experiment itself')
     _lib = lib
     return lib
 

@@ -9,6 +9,17 @@ void set_last_error(hipError_t e) { g_last = e; }
 
 extern "C" int mvip_abi_version(void) { return MVIP_ABI_VERSION; }
 
+// 1 when the library was compiled with a -DMVIP_EXPERIMENT_* macro (timing experiments: parts of kernels switched off, the
+// results are WRONG).  The Python loader refuses such a library unless explicitly allowed.
+extern "C" int mvip_build_is_experiment(void) {
+#if defined(MVIP_EXPERIMENT_NO_FUSE_TAIL) || defined(MVIP_EXPERIMENT_CONV) || defined(MVIP_EXPERIMENT_GEMM) || \
+    defined(MVIP_EXPERIMENT_NO_BARRIER) || defined(MVIP_EXPERIMENT_NO_EPILOGUE) || defined(MVIP_EXPERIMENT_HG_ONE_ATOMIC)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char *mvip_strerror(int code) {
     switch (code) {
         case MVIP_OK: return "ok";

@@ -275,7 +275,7 @@ attn_pack_v_kernel(const float *__restrict__ v, int heads, int DP, int Lk, int L
     // [n][head][dt][s16][hl][lane]
     const int64_t base = ((((n * heads + head) * DT + dt) * (LkP / 16) + s16) * 2) * 64 + lane;
     out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    if (prec == 0) out[base + 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (prec != 1) out[base + 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
 // ---- absolute maxima of several equally long sections at once -> one power-of-two scale per section ----
@@ -365,7 +365,7 @@ extern "C" int64_t mvip_attention_v_bytes(int64_t N, int64_t heads, int64_t D, i
 extern "C" int mvip_attention_pack_v(const float *v, int64_t N, int64_t heads, int64_t D, int64_t DP, int64_t Lk,
                                      int64_t LkP, int64_t sn, int64_t sr, int64_t sk, const float *scale2, void *vp,
                                      int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || heads <= 0 || D <= 0 || DP < D || Lk <= 0 || LkP < Lk || LkP % 32 != 0) return MVIP_EINVAL;
+    if ((prec < 0 || prec > 2) || N < 0 || heads <= 0 || D <= 0 || DP < D || Lk <= 0 || LkP < Lk || LkP % 32 != 0) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!v || !vp || !scale2) return MVIP_EINVAL;
     const int DT = (int)((D + 31) / 32);
@@ -395,7 +395,7 @@ static int attention_launch(const void *qs, const void *ks, const void *vp, cons
                             const float *v_scale2, int64_t N, int64_t heads, int64_t D, int64_t Lq, int64_t LqP, int64_t Lk,
                             int64_t LkP, int64_t q_stride, int64_t k_stride, int64_t v_groups, float softmax_scale, int flags,
                             float *out, void *out_planes, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0 ||
+    if ((prec < 0 || prec > 2) || N < 0 || heads <= 0 || Lq <= 0 || LqP < Lq || Lk <= 0 || LkP < Lk || LkP % 64 != 0 || Lq % 32 != 0 ||
         q_stride < Lq || k_stride < LkP || v_groups < LkP / 16)
         return MVIP_EINVAL;
     if (!mvip_attention_supported(D)) return MVIP_EUNSUP;
@@ -423,7 +423,7 @@ static int attention_launch(const void *qs, const void *ks, const void *vp, cons
         else if (D == 80) hipLaunchKernelGGL((attn_f16x3_kernel<5, 3, 32, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);   \
         else hipLaunchKernelGGL((attn_f16x3_kernel<10, 5, 32, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);               \
     } while (0)
-    if (prec) MVIP_ATTN(true); else MVIP_ATTN(false);
+    if (prec == 1) MVIP_ATTN(true); else MVIP_ATTN(false);      // (2 = two-product WEIGHT contractions: no weights here, same as 0)
 #undef MVIP_ATTN
     return check_launch();
 }

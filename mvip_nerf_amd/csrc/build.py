@@ -13,14 +13,18 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-LIB_DIR = os.path.join(PKG, 'lib')
+EXTRA_FLAGS = os.environ.get('MVIP_EXTRA_FLAGS', '').split()      # experiments only
+# A build with any -DMVIP_EXPERIMENT_* macro (timing experiments whose RESULTS ARE WRONG) never lands in lib/: it goes to
+# lib_experiment/, which _lib.load() opens only when MVIP_LIB_PATH points there AND MVIP_ALLOW_EXPERIMENT_BUILD=1.
+EXPERIMENT = any(f.startswith('-DMVIP_EXPERIMENT') for f in EXTRA_FLAGS)
+LIB_DIR = os.path.join(PKG, 'lib_experiment' if EXPERIMENT else 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libmvipnerf.so')
 
 SOURCES = ['api.hip', 'rays.hip', 'composite.hip', 'sample_pdf.hip', 'mlp_pack.hip', 'mlp_fwd.hip', 'mlp_fwd16.hip', 'mlp_fwd_f16x3.hip',
            'mlp_bwd.hip', 'mlp_bwd16.hip', 'mlp_bwd_f16x3.hip', 'normal_fit.hip', 'sds_elem.hip', 'group_norm.hip', 'conv3x3.hip', 'attention.hip', 'transformer.hip', 'hashgrid.hip', 'hashgrid_fused.hip', 'skinny_gemm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
-         '-Wno-unused-function'] + os.environ.get('MVIP_EXTRA_FLAGS', '').split()      # experiments only
+         '-Wno-unused-function'] + EXTRA_FLAGS
 
 
 def _hipcc():

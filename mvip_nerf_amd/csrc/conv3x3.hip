@@ -20,6 +20,12 @@
 //     K loop: 16 input channels x one kernel row per stage (3 taps, 72 MFMAs per wave at MT=4), weights
 //     and the input tile double-buffered in LDS, one barrier per stage.
 //   * epilogue: x 1/scale, + bias, + per-(sample, channel) addend (time embedding), + residual, NCHW fp32.
+//   * NP (template; `prec` of the C ABI): products per contraction step.  3 = Wh.Xh + Wh.Xl + Wl.Xh (prec 0); 1 = Wh.Xh only
+//     (prec 1, the reference's --fp16 mode); 2 = Wh.Xh + Wh.Xl (prec 2) for weights that are EXACTLY fp16 values -- every
+//     weight the reference ever loads is one (DS_NeRF/guidance/sd_utils.py:69-74: `revision="fp16"`, cast up in the default
+//     fp32 mode), so the packed image's lo fragments are all zero, the third product adds exact zeros, and leaving it out
+//     changes no bit of the result while a third of the matrix work and half of the weight-operand bytes go away.  The
+//     packers record whether any lo fragment is non-zero (tail word 12; mvip_packed_weights_two_product reads it).
 #include "common.h"
 #include "plane_sink.h"
 #include <stdlib.h>
@@ -157,8 +163,13 @@ __global__ void cv_scale_kernel(const unsigned *__restrict__ bits, float *__rest
 // ---- weight packing ----------------------------------------------------------------------------------
 // one thread per 16-byte fragment piece.  transpose = 1 packs the data-gradient operator:
 // W'[co'][ci'][ky][kx] = W[ci'][co'][2-ky][2-kx]  (Cout' = Cin, Cin' = Cout of the forward layer).
+// *lo_flag |= 1 when a lo fragment holds a non-zero half (looked at before the atomic: once set, nobody writes again)
+__device__ __forceinline__ void note_lo(const uint4 &lo, unsigned *lo_flag) {
+    if (((lo.x | lo.y | lo.z | lo.w) & 0x7fff7fffu) && *reinterpret_cast<volatile unsigned *>(lo_flag) == 0u) atomicOr(lo_flag, 1u);
+}
+
 __global__ void cv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int transpose,
-                               const float *__restrict__ scale2, uint4 *__restrict__ out) {
+                               const float *__restrict__ scale2, uint4 *__restrict__ out, unsigned *__restrict__ lo_flag) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int CK = Cin / 16;
     const int64_t total = (int64_t)(Cout / 32) * CK * 9 * 2 * 64;
@@ -183,11 +194,12 @@ __global__ void cv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, i
     uint4 hi, lo;
     split8(v, hi, lo);
     out[idx] = hl ? lo : hi;
+    if (hl) note_lo(lo, lo_flag);
 }
 
 // A operand of the plain GEMM (1x1 "convolution"): A[m][k] = src[m*sm + k*sk], packed [M/32][K/16][hl][lane][8]
 __global__ void gm_pack_kernel(const float *__restrict__ src, int M, int K, int64_t sm, int64_t sk,
-                               const float *__restrict__ scale2, uint4 *__restrict__ out) {
+                               const float *__restrict__ scale2, uint4 *__restrict__ out, unsigned *__restrict__ lo_flag) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int CK = K / 16;
     const int64_t total = (int64_t)(M / 32) * CK * 2 * 64;
@@ -205,6 +217,7 @@ __global__ void gm_pack_kernel(const float *__restrict__ src, int M, int K, int6
     uint4 hi, lo;
     split8(v, hi, lo);
     out[idx] = hl ? lo : hi;
+    if (hl) note_lo(lo, lo_flag);
 }
 
 // ---- activation producers ------------------------------------------------------------------------------
@@ -290,7 +303,7 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
         uint4 hi, lo;
         split8(t, hi, lo);
         dst[(kg * 2 + 0) * HW] = hi;
-        if (prec == 0) dst[(kg * 2 + 1) * HW] = lo;          // prec 1 (fp16 mode): consumers fetch the hi plane only
+        if (prec != 1) dst[(kg * 2 + 1) * HW] = lo;          // prec 1 (fp16 mode): consumers fetch the hi plane only
     }
 }
 
@@ -323,7 +336,7 @@ cv_to_split_up2_kernel(const float *__restrict__ x, const float *__restrict__ sc
         uint4 hi, lo;
         split8(t, hi, lo);
         dst[(kg * 2 + 0) * OHW] = hi;
-        if (prec == 0) dst[(kg * 2 + 1) * OHW] = lo;
+        if (prec != 1) dst[(kg * 2 + 1) * OHW] = lo;
     }
 }
 
@@ -382,7 +395,7 @@ cv_im2col_split_kernel(const float *__restrict__ x, int Cin, int H, int W, int K
         uint4 hi, lo;
         split8(t8, hi, lo);
         dst[(kg * 2 + 0) * PP] = hi;
-        if (prec == 0) dst[(kg * 2 + 1) * PP] = lo;
+        if (prec != 1) dst[(kg * 2 + 1) * PP] = lo;
     }
 }
 
@@ -453,8 +466,10 @@ struct ConvArgs {
 // F16 (the reference's --fp16 mode, DS_NeRF/guidance/sd_utils.py:66): ONE fp16 product per contraction step -- only the hi
 // plane of the activations and the hi fragments of the weights are fetched (the lo halves of both operand images are
 // neither read nor, by the producers, written), fp32 accumulation; a third of the matrix work and half the operand traffic.
-template <int MT, int TW = CV_TW, int NW = 4, bool F16 = false>
+// NP = 3 / 2 / 1 products per step (see the file header): 2 = the weights' lo fragments are zero and not fetched.
+template <int MT, int TW = CV_TW, int NW = 4, int NP = 3>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <= 2 ? 2 : 1))) conv3x3_f16x3_kernel(const ConvArgs a) {
+    constexpr bool F16 = NP == 1;
     constexpr int NT = NW * 64;
     constexpr int TH = NT / TW, HW = TW + 2, RPB = 32 / TW;                         // RPB: image rows per column block
     constexpr int PIX = TW == 8 ? 4 * 10 * HW : (TH + 2) * HW;
@@ -533,7 +548,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
 #pragma unroll
         for (int b0 = 0; b0 < 6 * MT; b0 += NW) {       // LDS block b = m*6 + kx*2 + hl
             const int b = b0 + wave;
-            if (b < 6 * MT && !(F16 && (b & 1)))           // b odd = lo fragments
+            if (b < 6 * MT && !(NP < 3 && (b & 1)))        // b odd = lo fragments (fetched by the three-product kernel only)
                 glds16b(src + (int64_t)(b / 6) * a.CK * 3 * WROW + (b % 6) * 1024, dst + b * 1024);
         }
     };
@@ -566,7 +581,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
     auto load_a = [&](const char *wb, int g, int set) {
         const int kx = g / MT, m = g % MT;
         Ah[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 0) * 1024);
-        if constexpr (!F16) Al[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
+        if constexpr (NP == 3) Al[set] = *reinterpret_cast<const h16x8 *>(wb + ((m * 3 + kx) * 2 + 1) * 1024);
     };
     auto load_b = [&](const char *inb, int ky, int kx) {
 #pragma unroll
@@ -647,9 +662,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!F16) {
+            if constexpr (NP >= 2) {
                 acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][0], acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[set], Bl[kx][1], acc[m][1], 0, 0, 0);
+            }
+            if constexpr (NP == 3) {               // NP == 2: Al == 0 -- this pair would add exact zeros
                 acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][0], acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[set], Bh[kx][1], acc[m][1], 0, 0, 0);
             }
@@ -864,7 +881,7 @@ cv_split_reduce_planes_kernel(const float *__restrict__ partial, int splits, int
     sink_split8(v, hi, lo);
     uint4 *dst = planes + (((int64_t)n * (M / 16) + (blk >> 1)) * 4 + (blk & 1) * 2) * P + p;
     dst[0] = hi;
-    if (prec == 0) dst[P] = lo;
+    if (prec != 1) dst[P] = lo;
 }
 
 // ---- plain GEMM (1x1 convolution, attention products) on the same operand formats -----------------------
@@ -873,6 +890,7 @@ cv_split_reduce_planes_kernel(const float *__restrict__ partial, int splits, int
 // columns, stage = 32 k (two 16-channel chunks: 48 MFMAs per wave at MT=4), double-buffered DMA.
 constexpr int GM_PIX = 256;
 constexpr int GM_KC = 2;
+constexpr int64_t GM_P_MAX = (int64_t)1 << 26;      // columns per sample: the streamed kernel's per-lane 32-bit plane offsets
 
 struct GemmArgs {
     const char *xs, *wp;
@@ -922,7 +940,7 @@ __device__ __forceinline__ void gemm_epilogue_vfrag(const GemmArgs &a, f32x16 (&
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[m][j][r] * mul + bs;
-            sink_store_vfrag(vt, (int)((p0 + (2 * wave + j) * 32) / 16), lane, v, a.prec == 0);
+            sink_store_vfrag(vt, (int)((p0 + (2 * wave + j) * 32) / 16), lane, v, a.prec != 1);
         }
     }
 }
@@ -977,7 +995,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                         if (hr) t += rv[j][r];
                         v[r] = t * sc.scale;
                     }
-                    sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v, true, a.prec == 0);
+                    sink_store_planes(pn, a.P, (row0 - sec_row0) / 8 + m * 4, n_blk8, p0 + (2 * wave + j) * 32 + l32, kg, v, true, a.prec != 1);
                 }
             }
         }
@@ -1010,7 +1028,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                     const float t = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
                     v[r] = px >= a.geglu_L ? 0.f : t * os;
                 }
-                sink_store_planes(pn, a.P, mb * 4, n_blk8, px, kg, v, true, a.prec == 0);
+                sink_store_planes(pn, a.P, mb * 4, n_blk8, px, kg, v, true, a.prec != 1);
             }
             return;
         }
@@ -1189,9 +1207,12 @@ __device__ __forceinline__ void cv_static_for(F &&f) {
 }
 constexpr int G5_DB = 6;        // B prefetch depth in 16-k chunks
 constexpr int G5_CA = 4;        // 16-k chunks per A ring slot
-template <int MT, bool SWAP = false, bool F16 = false>
+template <int MT, bool SWAP = false, int NP = 3>
 __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const GemmArgs a) {
-    constexpr int NHL = F16 ? 1 : 2;                        // operand halves fetched per fragment
+    constexpr bool F16 = NP == 1;
+    constexpr bool AHI = NP < 3;                            // the weights' hi fragments only (NP 2: the lo ones are zero)
+    constexpr int NHL = F16 ? 1 : 2;                        // halves of the B (activation) operand fetched per fragment
+    constexpr int NHA = AHI ? 1 : 2;                        // halves of the A (weight) operand fetched per fragment
     constexpr int SLOT = G5_CA * MT * 2 * 1024;            // bytes of a ring slot: [u][m][hl][lane][16 B]
     // three separate arrays, not one: the compiler's wait-count pass then knows that an LDS-DMA into one slot cannot
     // alias the fragment reads of another and puts no vmcnt(0) in front of them
@@ -1222,19 +1243,21 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
     const int nck = nall < a.sks * GM_KC ? nall : a.sks * GM_KC;
     const int nchunk = (nck + G5_CA - 1) / G5_CA;
 
-    // B: this lane's fragment of column block j, hi / lo, for chunk ck: bsrc[j] + (ck*4 + hl) * plane
-    const char *bsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        bsrc[j] = a.xs + (((int64_t)n * a.CK + ck0) * 4 + kg * 2) * plane + (p0 + (2 * wave + j) * 32 + l32) * 16;
+    // B: this lane's fragment of column block j, hi / lo, for chunk ck.  The address is split into a WAVE-UNIFORM 64-bit
+    // part (sample, chunk, plane, column tile, wave: scalar registers, scalar arithmetic) and ONE loop-invariant 32-bit
+    // per-lane offset (kg and the lane's column), i.e. the saddr form of global_load_dwordx4 -- the compiler otherwise keeps
+    // a 64-bit VGPR pointer per load of the unrolled trip (48 of them) and the two-product instantiation spilled.
+    const char *bbase = a.xs + (((int64_t)n * a.CK + ck0) * 4) * plane + (p0 + (int64_t)wave * 64) * 16;
+    const unsigned bvoff = (unsigned)(kg * 2) * (unsigned)plane + (unsigned)l32 * 16u;     // < 2^32: P <= 2^26 columns
     h16x8 Bq[G5_DB][2][NHL];
     auto load_b = [&](int ck, auto slot_) {
         constexpr int slot = decltype(slot_)::value;
+        const char *cb = bbase + (int64_t)ck * 4 * plane;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int hl = 0; hl < NHL; ++hl)
-                Bq[slot][j][hl] = *reinterpret_cast<const h16x8 *>(bsrc[j] + ((int64_t)ck * 4 + hl) * plane);
+                Bq[slot][j][hl] = *reinterpret_cast<const h16x8 *>(cb + (int64_t)hl * plane + j * 512 + bvoff);
     };
     // A: ring slot `slot` <- 16-k chunks c*CA .. c*CA+CA-1 of the MT row blocks; piece q = (u*MT + m)*2 + hl.  The slot
     // is a compile-time constant so that the DMA provably does not alias the fragment reads of the other slots.
@@ -1242,13 +1265,13 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
         constexpr int slot = decltype(slot_)::value;
         if (always || c < nchunk) {
 #pragma unroll
-            for (int q0 = 0; q0 < G5_CA * MT * NHL; q0 += 4) {
-                const int qq = q0 + wave;                    // F16: the hi pieces only, spread over the four waves
-                const int q = F16 ? qq * 2 : qq;
+            for (int q0 = 0; q0 < G5_CA * MT * NHA; q0 += 4) {
+                const int qq = q0 + wave;                    // AHI: the hi pieces only, spread over the four waves
+                const int q = AHI ? qq * 2 : qq;
                 const int hl = q & 1, m = (q >> 1) % MT, u = (q >> 1) / MT;
                 int ck = c * G5_CA + u;
                 if (ck >= nck) ck = nck - 1;                 // partial last chunk: a valid address, never multiplied
-                if (!F16 || qq < G5_CA * MT)
+                if (!AHI || qq < G5_CA * MT)
                     glds16b(a.wp + ((((int64_t)(mb * MT + m) * a.CK + ck0 + ck) * 2 + hl) * 1024) + lane * 16,
                             ring(slot_) + q * 1024);
             }
@@ -1289,25 +1312,20 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const h16x8 ah = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 0) * 1024);
-            if constexpr (F16) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (SWAP) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], ah, acc[m][j], 0, 0, 0);
-                    else acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
-                }
-                continue;
-            }
-            const h16x8 al = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 1) * 1024);
+            h16x8 al;
+            if constexpr (NP == 3) al = *reinterpret_cast<const h16x8 *>(ab + ((u * MT + m) * 2 + 1) * 1024);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                // products in the order hi.hi, hi.lo (NP >= 2), lo.hi (NP == 3: with NP == 2 the weights' lo half is zero
+                // and this product would add exact zeros); SWAP trades the MFMA operands (transposed accumulator)
                 if constexpr (SWAP) {
                     acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], ah, acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][1], ah, acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], al, acc[m][j], 0, 0, 0);
+                    if constexpr (NP >= 2) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][NHL - 1], ah, acc[m][j], 0, 0, 0);
+                    if constexpr (NP == 3) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bq[bs][j][0], al, acc[m][j], 0, 0, 0);
                 } else {
                     acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][0], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][1], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bq[bs][j][0], acc[m][j], 0, 0, 0);
+                    if constexpr (NP >= 2) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bq[bs][j][NHL - 1], acc[m][j], 0, 0, 0);
+                    if constexpr (NP == 3) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bq[bs][j][0], acc[m][j], 0, 0, 0);
                 }
             }
         }
@@ -1501,7 +1519,7 @@ extern "C" int64_t mvip_conv3x3_packed_bytes(int64_t Cout, int64_t Cin) {
     return Cout * Cin * 9 * 4 + 256;       // tail: {scale, 1/scale, absmax bits}, then a 16-byte zero page
 }
 
-// tail layout (byte offsets from Cout*Cin*36): 0 scale, 4 1/scale, 8 absmax bits, 128..143 zeros
+// tail layout (byte offsets from Cout*Cin*36): 0 scale, 4 1/scale, 8 absmax bits, 12 "a lo fragment is non-zero", 128..143 zeros
 extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin, int transpose, void *packed,
                                  void *stream) {
     const int64_t co = transpose ? Cin : Cout, ci = transpose ? Cout : Cin;      // operator dims
@@ -1514,8 +1532,23 @@ extern "C" int mvip_conv3x3_pack(const float *weight, int64_t Cout, int64_t Cin,
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
     const int64_t total = (co / 32) * (ci / 16) * 9 * 2 * 64;
     hipLaunchKernelGGL(cv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, (int)co, (int)ci,
-                       transpose, (const float *)tail, (uint4 *)packed);
+                       transpose, (const float *)tail, (uint4 *)packed, (unsigned *)(tail + 12));
     return check_launch();
+}
+
+// 1 in *two_product_host when every lo fragment of a packed weight image is zero, i.e. the scaled weights are exact fp16
+// values and `prec = 2` (two products) gives the three-product result bit for bit.  `fragment_bytes` = the image's size
+// without its 256-byte tail (Cout * Cin * 36 for mvip_conv3x3_pack, M * K * 4 for mvip_gemm_pack_a).  Reads ONE word back
+// to the host after synchronising `stream`: a pack-time query, not for the step.
+extern "C" int mvip_packed_weights_two_product(const void *packed, int64_t fragment_bytes, int *two_product_host, void *stream) {
+    if (!packed || !two_product_host || fragment_bytes <= 0) return MVIP_EINVAL;
+    unsigned flag = 1u;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemcpyAsync(&flag, (const char *)packed + fragment_bytes + 12, sizeof(flag), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_last_error(e); return MVIP_ELAUNCH; }
+    *two_product_host = flag == 0u ? 1 : 0;
+    return MVIP_OK;
 }
 
 extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void *zero_words2, void *stream) {
@@ -1534,7 +1567,7 @@ extern "C" int mvip_absmax_scale(const float *x, int64_t n, float *scale2, void 
 
 extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t HW, const float *scale2, void *xs, int prec,
                                  void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec < 0 || prec > 2)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
@@ -1545,7 +1578,7 @@ extern "C" int mvip_split_planes(const float *x, int64_t N, int64_t C, int64_t H
 
 extern "C" int mvip_split_planes_upsample2(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, const float *scale2,
                                            void *xs, int prec, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || H <= 0 || W <= 0 || H * W > (1 << 26) || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || H <= 0 || W <= 0 || H * W > (1 << 26) || (prec < 0 || prec > 2)) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((4 * H * W + 255) / 256), (unsigned)(N * (C / 16)));
@@ -1557,7 +1590,7 @@ extern "C" int mvip_split_planes_upsample2(const float *x, int64_t N, int64_t C,
 extern "C" int mvip_im2col_split_planes(const float *x, int64_t N, int64_t Cin, int64_t H, int64_t W, int KH, int KW,
                                         int stride, int pad_top, int pad_left, int64_t OH, int64_t OW, int64_t KP,
                                         int64_t PP, const float *scale2, void *xs, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
+    if ((prec < 0 || prec > 2) || N < 0 || Cin <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 ||
         OH <= 0 || OW <= 0 || KP <= 0 || KP % 16 != 0 || KP < Cin * KH * KW || PP < OH * OW || H * W > (1 << 30) ||
         OH * OW > (1 << 30))
         return MVIP_EINVAL;
@@ -1594,7 +1627,7 @@ extern "C" int mvip_col2im(const float *col, int64_t N, int64_t Cin, int64_t H, 
 
 extern "C" int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, int64_t HW, int64_t sn, int64_t sc,
                                          int64_t sp, const float *scale2, void *xs, int prec, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || (prec < 0 || prec > 2)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
@@ -1606,7 +1639,7 @@ extern "C" int mvip_split_planes_strided(const float *x, int64_t N, int64_t C, i
 extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float *beta, const float *mean,
                                            const float *rstd, int64_t N, int64_t C, int64_t HW, int G, int silu,
                                            void *xs, int prec, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec < 0 || prec > 2)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || !mean || !rstd || N * (C / 16) > 65535) return MVIP_EINVAL;
     const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
@@ -1622,7 +1655,7 @@ extern "C" int mvip_groupnorm_split_planes(const float *x, const float *gamma, c
 extern "C" int mvip_groupnorm_split_planes_moments(const float *x, const float *gamma, const float *beta,
                                                    const void *moments, float eps, int64_t N, int64_t C, int64_t HW, int G,
                                                    int silu, void *xs, int prec, void *stream) {
-    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec < 0 || prec > 2)) return MVIP_EINVAL;
     if (N == 0 || HW == 0) return MVIP_OK;
     if (!x || !xs || !moments || N * (C / 16) > 65535 || C / G < 4) return MVIP_EINVAL;          // <= 5 groups per 16 channels
     const int chunks = (int)(mvip_groupnorm_workspace_bytes(1, 1, HW) / 16);
@@ -1676,7 +1709,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                           int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream,
                           double *row_moments = nullptr) {
-    if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W) || (prec != 0 && prec != 1)) return MVIP_EINVAL;
+    if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W) || prec < 0 || prec > 2) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
     int tw, MT;
@@ -1726,7 +1759,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     }
     blocks *= a.splits;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-#define MVIP_CV_LAUNCH(F16_)                                                                                                   \
+#define MVIP_CV_LAUNCH(F16_)   /* F16_ = NP: products per step */                                                                                             \
     do {                                                                                                                      \
         if (tw == 8) hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 8, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);         \
         else if (tw == 16) hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 16, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);  \
@@ -1734,7 +1767,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
         else if (MT == 2) hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);             \
     } while (0)
-    if (prec) MVIP_CV_LAUNCH(true); else MVIP_CV_LAUNCH(false);
+    if (prec == 1) MVIP_CV_LAUNCH(1); else if (prec == 2) MVIP_CV_LAUNCH(2); else MVIP_CV_LAUNCH(3);
 #undef MVIP_CV_LAUNCH
     if (row_moments && !a.partial) return MVIP_EINVAL;         // callers ask mvip_conv3x3_row_moments_doubles first
     if (a.partial) {
@@ -1803,7 +1836,7 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
     const int64_t total = (M / 32) * (K / 16) * 2 * 64;
     hipLaunchKernelGGL(gm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, (int)M, (int)K, sm,
-                       sk, (const float *)tail, (uint4 *)packed);
+                       sk, (const float *)tail, (uint4 *)packed, (unsigned *)(tail + 12));
     return check_launch();
 }
 
@@ -1834,7 +1867,7 @@ static inline int gm_auto_cfg(int64_t N, int64_t M, int64_t P) {
 }
 
 extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, int64_t P) {
-    if (N <= 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0) return 0;
+    if (N <= 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX) return 0;
     if (gm_auto_cfg(N, M, P) != 1) return 0;
     const int64_t tiles = P / GM_PIX;
     const int MT = gm_mt(M, N * tiles);
@@ -1845,7 +1878,7 @@ extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, in
 static int gemm_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                        float *y, int cfg, void *workspace, int prec, void *stream) {
-    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || (prec != 0 && prec != 1))
+    if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || prec < 0 || prec > 2)
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
@@ -1861,7 +1894,10 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
 #endif
     hipStream_t st = as_stream(stream);
     const bool auto_cfg = cfg == 0;
-    if (cfg == 0) cfg = prec ? 1 : gm_auto_cfg(N, M, P);     // the single-product instantiation exists for the 32/64-row kernel
+    if (cfg == 0) cfg = prec ? 1 : gm_auto_cfg(N, M, P);     // the one- / two-product instantiations exist for the 32/64-row kernel
+    // prec 1 (fp16 mode): the producers wrote NO lo planes, so a three-product kernel would read uninitialised halves --
+    // refuse every configuration without a single-product instantiation (prec 2 may fall back: the result is identical)
+    if (prec == 1 && (cfg == 2 || cfg == 3 || cfg == 4)) return MVIP_EUNSUP;
     if (cfg < 0 || cfg > 5) return MVIP_EINVAL;
     if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
     if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
@@ -1888,9 +1924,13 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
         // cfg 5 (and the automatic choice unless MVIP_GEMM_STREAM=0): the B-in-registers kernel
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
         const bool stream = cfg == 5 || (auto_cfg && stream_env);
-        if (prec && MT <= 2 && stream) {
-            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if (prec == 1 && !(MT <= 2 && stream)) return MVIP_EUNSUP;             // (see above: no lo planes in fp16 mode)
+        if (prec == 1) {
+            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        } else if (prec == 2 && MT <= 2 && stream) {
+            if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         } else if (MT == 4)
             hipLaunchKernelGGL((gemm_f16x3_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else if (MT == 2 && stream)
@@ -1941,7 +1981,7 @@ extern "C" int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const floa
 extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const float *bias, const float *x_scale2,
                                      int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, float *out, float *scale2,
                                      void *zero_word, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+    if (prec < 0 || prec > 2 || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || L <= 0 || L > P ||
         !scale2 || !zero_word)
         return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -1957,7 +1997,8 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
-        if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if (prec == 1) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (prec == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else if (stream_env) hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
@@ -1974,7 +2015,7 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
 extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const float *bias, const float *x_scale2, int64_t N,
                                      int64_t K, int64_t M, int64_t P, int nsec, const int64_t *sec_rows, const int *sec_kind,
                                      void *const *sec_ptr, const float *sec_scale, int v_dt, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || M <= 0 || M % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || nsec < 1 || nsec > 3 ||
+    if (prec < 0 || prec > 2 || N < 0 || M <= 0 || M % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || nsec < 1 || nsec > 3 ||
         !sec_rows || !sec_kind || !sec_ptr || !sec_scale)
         return MVIP_EINVAL;
     int64_t end = 0, plane_rows = 0;
@@ -2014,8 +2055,9 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
 #define MVIP_G5(MT_, SW_)                                                                                                    \
         do {                                                                                                                    \
-            if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);    \
-            else hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);        \
+            if (prec == 1) hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);  \
+            else if (prec == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((gemm5_f16x3_kernel<MT_, SW_, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);            \
         } while (0)
         if (swap) { if (MT == 2) MVIP_G5(2, true); else MVIP_G5(1, true); }
         else { if (MT == 2) MVIP_G5(2, false); else MVIP_G5(1, false); }
@@ -2050,7 +2092,7 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
 extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, const float *bias, const float *x_scale2,
                                           int64_t N, int64_t K, int64_t M2, int64_t P, int64_t L, void *out_planes,
                                           float out_scale, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || L <= 0 || L > P ||
+    if (prec < 0 || prec > 2 || N < 0 || M2 <= 0 || M2 % 64 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || L <= 0 || L > P ||
         !(out_scale > 0.f) || (M2 / 2) % 16 != 0)
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
@@ -2069,7 +2111,8 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
 #endif
     const int64_t blocks = N * a.tiles * a.MB;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
-    if (prec) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    if (prec == 1) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 1>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    else if (prec == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((gemm5_f16x3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     return check_launch();
 }
@@ -2080,7 +2123,7 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
 extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, const float *bias, const float *residual,
                                          const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P, void *out_planes,
                                          float out_scale, void *workspace, int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || !(out_scale > 0.f))
+    if (prec < 0 || prec > 2 || N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || !(out_scale > 0.f))
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !out_planes) return MVIP_EINVAL;
@@ -2109,9 +2152,12 @@ extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, con
     blocks *= a.splits;
     if (blocks > 0x7fffffffLL || N * (M / 8) > 65535) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (prec) {
-        if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (prec == 1) {
+        if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else if (prec == 2) {
+        if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else {
         if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm5_f16x3_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -99,7 +99,7 @@ ln_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
         uint4 hi, lo;
         split8(t, hi, lo);
         dst[(int64_t)(kg * 2 + 0) * LP] = hi;
-        if (prec == 0) dst[(int64_t)(kg * 2 + 1) * LP] = lo;        // fp16 mode: hi planes only
+        if (prec != 1) dst[(int64_t)(kg * 2 + 1) * LP] = lo;        // fp16 mode: hi planes only
     }
 }
 
@@ -229,7 +229,7 @@ extern "C" int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t 
 extern "C" int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
                                            int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
                                            int prec, void *stream) {
-    if ((prec != 0 && prec != 1) || N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535) return MVIP_EINVAL;
+    if ((prec < 0 || prec > 2) || N < 0 || C <= 0 || C % 64 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!x || !xs || !workspace) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);

@@ -45,6 +45,35 @@ def all_gather_ragged(local, n_total, rank, world, dist):
     return torch.cat(parts, 0)[unshard_order(n_total, world).to(local.device)]
 
 
+def block_bounds(n, rank, world):
+    """Contiguous block [lo, hi) of rank `rank` when n items are cut into `world` blocks of ceil(n / world) (the last
+    ones may be short or empty).  Contiguous rather than strided: a block of a frame's rays is a run of whole image rows,
+    so the rank's ray rows, its chunks and its slice of the gathered image are dense."""
+    per = -(-n // world)
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def all_gather_blocks(local, n_total, rank, world, dist):
+    """Every rank holds rows block_bounds(n_total, rank, world) of an [n_total, ...] tensor; returns the whole tensor on
+    every rank with ONE all_gather of equal (zero-padded) blocks -- the frame assembly of the ray-sharded render
+    (STRONG scaling: one frame's rays over all GPUs, DS_NeRF/run.py:1131 batchify_rays is the loop being split).  No
+    autograd: inference path."""
+    if world == 1:
+        return local
+    per = -(-n_total // world)
+    pad = local.detach().contiguous()
+    if pad.shape[0] < per:
+        pad = torch.cat([pad, pad.new_zeros((per - pad.shape[0],) + tuple(pad.shape[1:]))], 0)
+    out = pad.new_empty((world * per,) + tuple(pad.shape[1:]))
+    try:
+        dist.all_gather_into_tensor(out, pad)
+    except (RuntimeError, NotImplementedError, AttributeError):       # a backend without the flat form
+        parts = list(out.view((world, per) + tuple(pad.shape[1:])).unbind(0))
+        dist.all_gather(parts, pad)
+    return out[:n_total]
+
+
 class FlatGradBucket:
     """One contiguous fp32 bucket for all parameters: grads are copied in, all-reduced once, and
     handed back as views (so the optimizer reads the reduced values without another copy).

@@ -530,7 +530,12 @@ def scaled_linear_alphas_cumprod(n=1000, b0=0.00085, b1=0.012):
 class SDNetworks:
     """Bundle used by guidance.sd_utils.StableDiffusion: vae, unet, prompt encoder, scheduler table."""
 
-    def __init__(self, device, dtype=torch.float32, seed=3):
+    def __init__(self, device, dtype=torch.float32, seed=3, fp16_weights=True):
+        """fp16_weights (default): the random parameters are rounded to fp16-REPRESENTABLE values, kept in fp32 containers
+        -- what the reference's networks hold in its default mode: it always loads the `revision="fp16"` checkpoint and
+        casts it up to fp32 (DS_NeRF/guidance/sd_utils.py:69-74).  The split-precision kernels then run two products per
+        contraction step instead of three with bit-identical results (ops.TWO_PRODUCT, csrc/conv3x3.hip NP = 2).  False
+        keeps full fp32 random values (the three-product path: tests of both)."""
         g = torch.random.get_rng_state()
         torch.manual_seed(seed)
         # dtype float16 = the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66: every network in half).  On the
@@ -548,8 +553,9 @@ class SDNetworks:
         for m in (self.vae, self.unet, self.text_encoder):
             for p in m.parameters():
                 p.requires_grad_(False)
-                if on_kernels:
+                if on_kernels or (fp16_weights and p.dtype == torch.float32):
                     p.data = p.data.half().float()
+        self.fp16_weights = bool(fp16_weights) or dtype == torch.float16
         if on_kernels:
             self.vae.mfma_prec = self.unet.mfma_prec = 1
         self.tokenizer = ByteTokenizer()

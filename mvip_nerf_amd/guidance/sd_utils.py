@@ -222,9 +222,13 @@ class StableDiffusion(nn.Module):
         if use_graphs is None:
             use_graphs = builtin and torch.device(device).type == 'cuda'
             # next to a live multi-rank process group the default stays eager: a capture beside RCCL's own threads and
-            # streams has not been exercised on hardware (the build boxes have one GPU); use_graphs=True forces it
+            # streams has not been exercised on multi-GPU hardware (the build boxes have one GPU).  use_graphs=True or
+            # MVIP_GRAPHS_WITH_DIST=1 turn the replay on there too (thread-local capture; the step itself contains no
+            # collective -- bench.py reports which mode ran, profiles/r4_bench_2rank_single_device.json has the 2-rank run)
+            import os
             import torch.distributed as dist
-            if use_graphs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if (use_graphs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                    and os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') != '1'):
                 use_graphs = False
         self.use_graphs = bool(use_graphs)
         self._graphs = {}

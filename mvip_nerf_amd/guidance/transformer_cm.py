@@ -83,7 +83,7 @@ class _Packed:
         dev = mod.proj_in.weight.device
         self.C, self.heads, self.D, self.DP, self.R = C, heads, D, DP, R
         self.key = self.version_key(mod)
-        pack = ops.gemm_pack_a
+        pack = lambda *a: ops.gemm_pack_a(*a, weights=True)     # frozen weights: two-product contractions when fp16-exact
         wqkv = torch.cat([_pad_head_rows(w.weight, heads, D, DP) for w in (a1.to_q, a1.to_k, a1.to_v)], 0).contiguous()
         self.qkv1 = pack(wqkv, 3 * R, C, C, 1)
         self.o1 = pack(a1.to_out[0].weight.detach().contiguous(), C, C, C, 1)
@@ -221,8 +221,14 @@ def _prompt_kv(pk, ctx, want_vmax=False):
     flat = kv.reshape(-1)
     ks = ops.split_planes_strided(flat, N, pk.R, TP, 2 * pk.R * GP, GP, 1, sc[0:4])
     vp = ops.attention_pack_v(flat[pk.R * GP:], N, pk.heads, pk.D, pk.DP, T, TP, 2 * pk.R * GP, GP, 1, sc[4:8])
-    vmax = 1024.0 / float(sc[4])                                 # host read-back once per prompt (not in a capture: the
-    hit = (ks, vp, sc[0:4], sc[4:8], T, TP, vmax)                # graphed step fills this cache in its eager warm-up)
+    # The power of two above |v|max, MEASURED whatever scale the split used (under ops.forward_unit_scale() -- always in
+    # fp16 mode -- `sc` is 1 and says nothing about the values; the residual-stream bound of _h3_scale must not rest on an
+    # assumed range).  With the measured split scale this equals 1024 / sc[4] bit for bit.  Host read-back once per prompt
+    # (not in a capture: the graphed step fills this cache in its eager warm-up).
+    import math
+    v_abs = float(kv.reshape(N, 2, -1)[:, 1].abs().max())
+    vmax = 2.0 ** math.frexp(v_abs)[1] if v_abs > 0 and math.isfinite(v_abs) else 1.0
+    hit = (ks, vp, sc[0:4], sc[4:8], T, TP, vmax)
     # One entry per prompt, kept for the life of the module: a captured hipGraph replays against the addresses of the
     # entry it was captured with, so an entry must never be freed while another prompt runs (RGB text / text_normal
     # alternate inside one iteration).  The entry holds `ctx` itself: the key is an address, and a live tensor keeps it

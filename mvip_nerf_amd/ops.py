@@ -185,20 +185,27 @@ STASH_FREE_FRACTION = 0.6          # of the currently free bytes, after the back
 _stash_live = {}                   # device index -> bytes of live stashes
 
 
-_FREE_CACHE = {}                   # device index -> (bytes reserved by torch at query time, free bytes from the driver)
+_FREE_CACHE = {}                   # device index -> (bytes reserved by torch at query time, free bytes from the driver, time)
+# The cached answer also EXPIRES: another process on the device (mvip_nerf_amd/replicas.py with --devices 0,0, any other
+# tenant) moves the free memory without touching this process's counters.  MVIP_SHARED_DEVICE=1 (set by replicas.launch
+# when several replicas share a device) shortens the lifetime to every query.
+FREE_CACHE_SECONDS = 0.0 if _os.environ.get('MVIP_SHARED_DEVICE') == '1' else 0.25
 
 
 def _device_free_bytes(device):
-    """hipMemGetInfo through torch, asked again only when torch's own reservation has changed since the last answer: the
-    driver call costs milliseconds once tens of GB are mapped (five stash allocations per iteration turned a 54 ms training
-    iteration into 75-94 ms of wall time: tools/train_step_profile.py --after-hashgrid), and between two queries the
-    device's free memory moves only when torch itself maps or unmaps memory -- which `memory_reserved` (a host-side counter)
-    shows.  (Another process on the device can still move it: the allocation itself is guarded, see _take_stash.)"""
+    """hipMemGetInfo through torch, asked again only when torch's own reservation has changed since the last answer or the
+    answer is older than FREE_CACHE_SECONDS: the driver call costs milliseconds once tens of GB are mapped (five stash
+    allocations per iteration turned a 54 ms training iteration into 75-94 ms of wall time: tools/train_step_profile.py
+    --after-hashgrid), and between two queries the device's free memory moves only when torch itself maps or unmaps memory
+    -- which `memory_reserved` (a host-side counter) shows -- or when ANOTHER process does, which only time can cover (the
+    allocation itself is guarded as well, see _take_stash)."""
+    import time
     key = device.index if device.index is not None else torch.cuda.current_device()
     reserved = torch.cuda.memory_reserved(device)
+    now = time.monotonic()
     hit = _FREE_CACHE.get(key)
-    if hit is None or hit[0] != reserved:
-        hit = (reserved, torch.cuda.mem_get_info(device)[0])
+    if hit is None or hit[0] != reserved or now - hit[2] > FREE_CACHE_SECONDS:
+        hit = (reserved, torch.cuda.mem_get_info(device)[0], now)
         _FREE_CACHE[key] = hit
     return hit[1]
 
@@ -602,6 +609,30 @@ def _prec():
     return int(PREC)
 
 
+# Two products instead of three for weights that are exact fp16 values (prec = 2 of the C ABI; csrc/conv3x3.hip NP = 2).
+# The reference always loads `revision="fp16"` weights and, in its default fp32 mode, casts them UP
+# (DS_NeRF/guidance/sd_utils.py:69-74): the lo half of every frozen UNet / VAE weight is zero, the third product
+# W_lo . x_hi adds exact zeros, and skipping it (and the lo fragments' fetch) changes no bit of any result.  Decided per
+# packed image at PACK time (one word read back from the packer: `_note_two_product`); images of anything else -- weights
+# with a non-zero lo half, activations packed as an A operand -- keep the three-product kernels.
+TWO_PRODUCT = bool(int(_os.environ.get('MVIP_TWO_PRODUCT', '1')))          # A/B switch
+
+
+def _note_two_product(packed, fragment_bytes):
+    """Ask the library whether the packed WEIGHT image's lo fragments are all zero and remember it on the tensor."""
+    import ctypes
+    flag = ctypes.c_int(0)
+    call('mvip_packed_weights_two_product', ptr(packed, torch.uint8), int(fragment_bytes), ctypes.byref(flag), stream())
+    packed._mvip_two_product = bool(flag.value)
+    return packed
+
+
+def _prec_w(packed):
+    """`prec` for a contraction whose A operand is the packed weight image `packed`."""
+    p = _prec()
+    return 2 if (p == 0 and TWO_PRODUCT and getattr(packed, '_mvip_two_product', False)) else p
+
+
 def conv3x3_pack(weight, transpose=False):
     """Packed split-precision image of a [Cout, Cin, 3, 3] weight (transpose: the data-gradient operator)."""
     Cout, Cin = weight.shape[0], weight.shape[1]
@@ -609,7 +640,7 @@ def conv3x3_pack(weight, transpose=False):
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
     w = weight.detach().contiguous()
     call('mvip_conv3x3_pack', ptr(w), Cout, Cin, int(bool(transpose)), ptr(packed, torch.uint8), stream())
-    return packed
+    return _note_two_product(packed, Cout * Cin * 36)
 
 
 def _conv_packed(conv, transpose):
@@ -777,11 +808,11 @@ def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, 
         if nd:
             rm = torch.empty(nd, device=y.device, dtype=torch.float64)
             call('mvip_conv3x3_f16x3_ws_moments', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
-                 ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), ptr(rm, torch.float64), _prec(), stream())
+                 ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), ptr(rm, torch.float64), _prec_w(packed), stream())
             _LAST_Y[0] = (y, y._version, rm)
             return
     call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
-         ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), _prec(), stream())
+         ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), _prec_w(packed), stream())
 
 
 def conv3x3_plain(x, conv, upsample2=False):
@@ -968,13 +999,15 @@ def absmax_scale(t):
     return scale2
 
 
-def gemm_pack_a(src, M, K, sm, sk):
-    """A[m][k] = src.flatten()[m*sm + k*sk] (src a dense block of M*K floats) -> packed split-precision image."""
+def gemm_pack_a(src, M, K, sm, sk, weights=False):
+    """A[m][k] = src.flatten()[m*sm + k*sk] (src a dense block of M*K floats) -> packed split-precision image.
+    weights=True: a frozen layer's weights, packed once -- the packer's "lo fragments are zero" word is read back (a host
+    synchronisation, which is why activations packed per step never ask) so that its contractions can run two products."""
     s = src.contiguous()
     assert s.numel() == M * K
     packed = torch.empty(int(_lib.load().mvip_gemm_packed_bytes(M, K)), device=s.device, dtype=torch.uint8)
     call('mvip_gemm_pack_a', ptr(s), M, K, sm, sk, ptr(packed, torch.uint8), stream())
-    return packed
+    return _note_two_product(packed, M * K * 4) if weights else packed
 
 
 def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
@@ -993,12 +1026,12 @@ def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, 
     y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
     if GEMM_CFG:
         call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
-             ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), _prec(), stream())
+             ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), _prec_w(packed), stream())
         return y
     nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))            # split-K partial sums (few shapes)
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
     call('mvip_gemm_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
-         ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), _prec(), stream())
+         ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), _prec_w(packed), stream())
     return y
 
 
@@ -1048,8 +1081,8 @@ def _attn_weights(mod):
         wo = ws[3].detach().contiguous()
         cache.clear()
         cache.update(key=key,
-                     qkv=gemm_pack_a(wqkv, 3 * C, C, C, 1), qkv_t=gemm_pack_a(wqkv, C, 3 * C, 1, C),
-                     o=gemm_pack_a(wo, C, C, C, 1), o_t=gemm_pack_a(wo, C, C, 1, C),
+                     qkv=gemm_pack_a(wqkv, 3 * C, C, C, 1, weights=True), qkv_t=gemm_pack_a(wqkv, C, 3 * C, 1, C, weights=True),
+                     o=gemm_pack_a(wo, C, C, C, 1, weights=True), o_t=gemm_pack_a(wo, C, C, 1, C, weights=True),
                      bqkv=torch.cat([mod.to_q.bias.detach(), mod.to_k.bias.detach(), mod.to_v.bias.detach()]).contiguous(),
                      bo=mod.to_out[0].bias.detach().contiguous())
     return cache
@@ -1153,7 +1186,7 @@ def _conv1x1_packed(conv, transpose):
     if transpose not in cache:
         Cout, Cin = conv.out_channels, conv.in_channels
         w = conv.weight.detach().reshape(Cout, Cin).contiguous()
-        cache[transpose] = gemm_pack_a(w, Cin, Cout, 1, Cin) if transpose else gemm_pack_a(w, Cout, Cin, Cin, 1)
+        cache[transpose] = gemm_pack_a(w, Cin, Cout, 1, Cin, weights=True) if transpose else gemm_pack_a(w, Cout, Cin, Cin, 1, weights=True)
     return cache[transpose]
 
 
@@ -1223,8 +1256,8 @@ def _conv_gemm_packed(conv):
         MP, KP = _up(Cout, 32), _up(K, 32)
         w = torch.zeros((MP, KP), device=conv.weight.device, dtype=torch.float32)
         w[:Cout, :K] = conv.weight.detach().reshape(Cout, K)
-        cache['fwd'] = gemm_pack_a(w, MP, KP, KP, 1)
-        cache['bwd'] = gemm_pack_a(w, KP, MP, 1, KP)
+        cache['fwd'] = gemm_pack_a(w, MP, KP, KP, 1, weights=True)
+        cache['bwd'] = gemm_pack_a(w, KP, MP, 1, KP, weights=True)
         b = torch.zeros(MP, device=w.device, dtype=torch.float32)
         if conv.bias is not None:
             b[:Cout] = conv.bias.detach()
@@ -1401,7 +1434,7 @@ def gemm_geglu_f16x3(xs, packed, bias, N, K, M2, P, L, x_scale2=None):
     out = torch.empty((N, M2 // 2, P), device=xs.device, dtype=_F32)
     scale2 = torch.empty(4, device=xs.device, dtype=_F32)
     call('mvip_gemm_geglu_f16x3', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
-         int(K), int(M2), int(P), int(L), ptr(out), ptr(scale2), ptr(_zero_words(xs.device), torch.int32), _prec(), stream())
+         int(K), int(M2), int(P), int(L), ptr(out), ptr(scale2), ptr(_zero_words(xs.device), torch.int32), _prec_w(packed), stream())
     return out, scale2
 
 
@@ -1451,7 +1484,7 @@ def gemm_f16x3_sinks(xs, packed, N, K, P, sections, bias=None, x_scale2=None, v_
             bufs.append(torch.empty(N * r * P * 4, device=xs.device, dtype=torch.uint8))
     ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bufs])
     call('mvip_gemm_f16x3_sinks', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N), int(K),
-         int(M), int(P), n, rows, kinds, ptrs, scales, int(v_dt), _prec(), stream())
+         int(M), int(P), n, rows, kinds, ptrs, scales, int(v_dt), _prec_w(packed), stream())
     return bufs
 
 
@@ -1460,7 +1493,7 @@ def gemm_geglu_f16x3_sink(xs, packed, bias, N, K, M2, P, L, out_scale, x_scale2=
     [N][(M2/2)/16][2][2][P][8]; columns >= L are zero."""
     out = _split_buffer(N, M2 // 2, P, xs.device)
     call('mvip_gemm_geglu_f16x3_sink', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(x_scale2), int(N),
-         int(K), int(M2), int(P), int(L), ptr(out, torch.float16), float(out_scale), _prec(), stream())
+         int(K), int(M2), int(P), int(L), ptr(out, torch.float16), float(out_scale), _prec_w(packed), stream())
     return out
 
 
@@ -1483,7 +1516,7 @@ def gemm_f16x3_planes(xs, packed, N, K, M, P, out_scale, bias=None, residual=Non
     nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))
     ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32) if nbytes else None
     call('mvip_gemm_f16x3_planes_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(residual), ptr(x_scale2),
-         int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), _prec(), stream())
+         int(N), int(K), int(M), int(P), ptr(out, torch.float16), float(out_scale), ptr(ws), _prec_w(packed), stream())
     return out
 
 

@@ -108,6 +108,8 @@ def launch(n_scenes, iters, basedir, devices=None, datadirs=None, fixture=None, 
             os.remove(stale)
         env = dict(os.environ)
         env['HIP_VISIBLE_DEVICES'] = str(devices[s % len(devices)])
+        if len(set(devices[i % len(devices)] for i in range(n_scenes))) < n_scenes:
+            env['MVIP_SHARED_DEVICE'] = '1'          # several replicas on one GPU: never trust a cached free-memory answer (ops.py)
         for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):       # a replica is not a rank
             env.pop(k, None)
         cmd = [sys.executable, '-m', 'mvip_nerf_amd.replicas', '--child', str(s), '--iters', str(iters), '--basedir', basedir,

@@ -93,6 +93,34 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     return ret_list + [ret_dict]
 
 
+def render_sharded(H, W, focal, c2w, rank, world, dist, chunk=1024 * 32, near=0., far=1., row_fn=None, **kwargs):
+    """ONE frame over all ranks (strong scaling; extension, no reference counterpart -- the reference's only multi-GPU
+    mechanism is nn.DataParallel around the MLPs, DS_NeRF/run.py:1491, :1527): rank r renders the contiguous block
+    dist_utils.block_bounds(H*W, r, world) of the frame's rays through batchify_rays (DS_NeRF/run.py:1127-1140, the loop
+    being split), then ONE all_gather of [rays, 6] = (rgb, disp, acc, depth) blocks assembles the maps on every rank.
+    Returns [rgb_map [H,W,3], disp_map [H,W], acc_map [H,W], depth_map [H,W]] -- render()'s first four outputs; the
+    per-sample extras stay sharded (nobody reads them across ranks).  Rays of different blocks are independent, so the
+    values equal render()'s (bit for bit when the chunk boundaries coincide; the kernels are chunk-invariant anyway,
+    tests/test_configs_large.py).  `row_fn(lo, hi)` overrides the ray-row source (CPU tests of the collective)."""
+    from .dist_utils import block_bounds, all_gather_blocks
+    n = H * W
+    lo, hi = block_bounds(n, rank, world)
+    if row_fn is not None:
+        rows = row_fn(lo, hi)
+    else:
+        c2w = torch.as_tensor(c2w)
+        sel = torch.arange(lo, hi, device=c2w.device, dtype=torch.int64)
+        rows = ops.ray_rows_from_pose(c2w, H, W, focal, near, far, sel=sel)
+    kwargs = {k: v for k, v in kwargs.items() if k not in ('use_viewdirs', 'ndc')}
+    if rows.shape[0] > 0:
+        ret = batchify_rays(rows, chunk, **kwargs)
+        local = torch.cat([ret['rgb_map'], ret['disp_map'][:, None], ret['acc_map'][:, None], ret['depth_map'][:, None]], -1)
+    else:
+        local = rows.new_zeros((0, 6))
+    full = all_gather_blocks(local, n, rank, world, dist)
+    return [full[:, 0:3].reshape(H, W, 3), full[:, 3].reshape(H, W), full[:, 4].reshape(H, W), full[:, 5].reshape(H, W)]
+
+
 def _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_viewdirs, c2w_staticcam, depths):
     """The uncommon branches of render()'s row assembly (ndc, static camera, per-ray bounds,
     depth column), DS_NeRF/run.py:1182-1207, as tensor algebra."""
@@ -118,8 +146,12 @@ def _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_view
 
 
 # render_rays as two launches per chunk for no-grad renders of the native networks (64 coarse + <= 64 fine samples);
-# MVIP_FUSED_RENDER=0 restores the six-launch chain (A/B switch; the outputs are bit-identical either way)
+# MVIP_FUSED_RENDER=0 restores the six-launch chain (A/B switch; the outputs are bit-identical either way).
+# The two-launch form is chosen BY CHUNK SIZE: it exists to cut launches where launches matter (small renders); at frame
+# size its compositing tail -- one wave of the workgroup at work, seven gone -- costs 0.5 % of the frame
+# (profiles/r3_fused_render_ab.json: 303.3-303.8 vs 301.5-301.9 ms), so chunks above FUSED_RENDER_MAX_RAYS take the chain.
 FUSED_RENDER = bool(int(os.environ.get('MVIP_FUSED_RENDER', '1')))
+FUSED_RENDER_MAX_RAYS = int(os.environ.get('MVIP_FUSED_RENDER_MAX_RAYS', '4096'))
 
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
@@ -162,7 +194,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     coarse_net = network_fn if network_fn is not None else (
         network_fine.alpha_model if getattr(network_fine, 'alpha_model', None) is not None else network_fine)
     fine_net = network_fn if network_fine is None else network_fine
-    if (FUSED_RENDER and not torch.is_grad_enabled() and N_rays > 0 and N_samples == 64 and 0 < N_importance <= 64
+    if (FUSED_RENDER and not torch.is_grad_enabled() and 0 < N_rays <= FUSED_RENDER_MAX_RAYS and N_samples == 64 and 0 < N_importance <= 64
             and ncols == 11 and sigma_loss is None and getattr(network_query_fn, '_mvip_native', False)
             and isinstance(coarse_net, NeRF) and isinstance(fine_net, NeRF)):
         c16, f16 = coarse_net._infer16(), fine_net._infer16()

@@ -28,7 +28,8 @@ CASES = [
     ('mvip_resize_bilinear', (P0, 3, 0, 8, 16, 16, P0, P0), (P0, 0, 8, 8, 16, 16, P0, P0), (P0, 3, 8, 8, 16, 16, P0, P0)),
     ('mvip_absmax_scale', (P0, -1, P0, P0, P0), None, (P0, 16, P0, P0, P0)),
     ('mvip_split_planes', (P0, 1, 24, 64, P0, P0, 0, P0), (P0, 0, 32, 64, P0, P0, 0, P0), (P0, 1, 32, 64, P0, P0, 0, P0)),
-    ('mvip_split_planes', (P0, 1, 32, 64, P0, P0, 2, P0), None, None),                 # prec is 0 (f16x3) or 1 (fp16 mode)
+    ('mvip_split_planes', (P0, 1, 32, 64, P0, P0, 3, P0), None, (P0, 1, 32, 64, P0, P0, 2, P0)),     # prec is 0 (f16x3), 1 (fp16 mode) or 2 (= 0 for a producer)
+    ('mvip_packed_weights_two_product', (P0, 0, None, P0), None, (P0, 1024, None, P0)),
     ('mvip_groupnorm_stats', (P0, 1, 30, 64, 32, 1e-6, 0, P0, P0, P0, P0), (P0, 0, 64, 64, 32, 1e-6, 0, P0, P0, P0, P0),
      (P0, 1, 64, 64, 32, 1e-6, 0, P0, P0, P0, P0)),
     # 3x3 convolution: 33 output channels / a 12 x 12 image are not tileable

@@ -83,3 +83,48 @@ def test_shard_helpers():
     assert [len(shard(idx, r, 4)) for r in range(4)] == shard_sizes(11, 4) == [3, 3, 3, 2]
     assert torch.equal(shard(idx, 0, 1), idx)
     assert torch.equal(torch.cat([idx[r::4] for r in range(4)])[unshard_order(11, 4)], idx)
+
+
+def _blocks_worker(rank, world, port, out):
+    from mvip_nerf_amd import run
+    from mvip_nerf_amd.dist_utils import all_gather_blocks, block_bounds
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        for n in (10, 7, 2, 1):                      # ragged, and blocks that are EMPTY on the last ranks
+            full = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+            lo, hi = block_bounds(n, rank, world)
+            got = all_gather_blocks(full[lo:hi], n, rank, world, dist)
+            assert torch.equal(got, full), (n, rank)
+        # the ray-sharded frame: render_sharded over a stand-in render_rays equals the unsharded maps on every rank
+        H, W = 5, 7
+        rows_all = torch.randn(H * W, 11, generator=torch.Generator().manual_seed(3))
+
+        def fake(ray_batch, **kw):
+            c = torch.tanh(ray_batch[:, :3] * 2 + ray_batch[:, 3:6])
+            return {'rgb_map': c, 'disp_map': c.sum(-1), 'acc_map': c[:, 0] * 0.5, 'depth_map': ray_batch[:, 6],
+                    'weights': ray_batch[:, :4]}
+        real, run.render_rays = run.render_rays, fake
+        try:
+            maps = run.render_sharded(H, W, 1.0, None, rank, world, dist, chunk=4, row_fn=lambda lo, hi: rows_all[lo:hi],
+                                      use_viewdirs=True, ndc=False)
+        finally:
+            run.render_rays = real
+        torch.save([m.clone() for m in maps], os.path.join(out, f'maps{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_block_sharded_frame_is_assembled_on_every_rank(tmp_path, world):
+    """Strong-scaling render (bench.py --gpus N headline, run.render_sharded): contiguous ray blocks, one all_gather of
+    (rgb, disp, acc, depth); every rank ends with the whole maps, equal to the unsharded result."""
+    mp.spawn(_blocks_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    H, W = 5, 7
+    rows = torch.randn(H * W, 11, generator=torch.Generator().manual_seed(3))
+    c = torch.tanh(rows[:, :3] * 2 + rows[:, 3:6])
+    want = [c.reshape(H, W, 3), c.sum(-1).reshape(H, W), (c[:, 0] * 0.5).reshape(H, W), rows[:, 6].reshape(H, W)]
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f'maps{r}.pt'))
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)

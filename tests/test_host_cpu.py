@@ -112,6 +112,10 @@ def test_bench_launcher_spawns_ranks_itself():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+    rec = json.loads(lines[0])
+    # the N > 1 headline is the STRONG-scaling form: the dry run passed a frame of ray rows through run.render_sharded
+    # (contiguous blocks, one all_gather) on both ranks and says so
+    assert rec['scaling'] == 'strong' and rec['sharded_frame_assembled'] is True and 'weak_rays_per_sec' in rec
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3'], env=dict(env, WORLD_SIZE='2', RANK='0'),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr

@@ -761,14 +761,24 @@ def test_sds_step_launches_no_library_contraction(cuda, fp16):
     for must in ('conv3x3_f16x3_kernel', 'gemm5_f16x3_kernel', 'attn_f16x3_kernel', 'cv_im2col_split_kernel',
                  'resize_bilinear_fwd_kernel', 'resize_bilinear_bwd_kernel'):
         assert any(must in n for n in names), must
-    # the template flag of the single-product instantiations shows in the kernel names: <..., true> in fp16 mode only
-    single = [n for n in names if ('conv3x3_f16x3_kernel' in n or 'gemm5_f16x3_kernel' in n or 'attn_f16x3_kernel' in n)
-              and n.split('(')[0].rstrip('>').endswith('true')]
-    assert bool(single) == fp16, single
+    # the number of products per contraction step shows in the kernel names: the last template argument of the convolution
+    # / GEMM kernels (1 = fp16 mode, 2 = two products on fp16-exact weights, 3 = three), <..., true> of the attention kernel
+    def last_arg(n):
+        return n.split('(')[0].rstrip('>').split(',')[-1].strip()
+    wk = [n for n in names if 'conv3x3_f16x3_kernel' in n or 'gemm5_f16x3_kernel' in n]
+    at = [n for n in names if 'attn_f16x3_kernel' in n]
     if fp16:
-        triple = [n for n in names if ('conv3x3_f16x3_kernel' in n or 'gemm5_f16x3_kernel' in n or 'attn_f16x3_kernel' in n)
-                  and not n.split('(')[0].rstrip('>').endswith('true')]
-        assert not triple, triple
+        assert all(last_arg(n) == '1' for n in wk), wk
+        assert all(last_arg(n) == 'true' for n in at), at
+    else:
+        assert all(last_arg(n) == 'false' for n in at), at
+        # the built-in networks' weights are fp16-representable like the reference's (revision="fp16" cast up): every
+        # convolution and every weight GEMM runs TWO products; three only where an ACTIVATION is the packed operand (the VAE
+        # mid-block attention's products)
+        assert sd.networks.fp16_weights
+        assert all(last_arg(n) in ('2', '3') for n in wk), wk
+        assert all(last_arg(n) == '2' for n in wk if 'conv3x3_f16x3_kernel' in n), wk
+        assert any(last_arg(n) == '2' for n in wk if 'gemm5_f16x3_kernel' in n), wk
 
 
 def test_plain_conv3x3_on_mfma_kernel(cuda):
@@ -912,3 +922,116 @@ def test_fp16_mode_step_agrees_with_fp32_mode(cuda):
     cos = float((a @ b) / (a.norm() * b.norm()))
     print(f'fp16-mode vs fp32-mode SDS image gradient: relative L2 {rel:.3e}, cosine {cos:.6f}')
     assert rel < 8e-2 and cos > 0.997, (rel, cos)
+
+
+def _fp16_exact(t):
+    return t.half().float()
+
+
+@pytest.mark.parametrize('N_,cin,cout,H,W', [(1, 128, 128, 64, 64), (2, 320, 320, 16, 16), (2, 1280, 640, 8, 8), (1, 64, 32, 8, 32)])
+def test_two_product_convolution_equals_three_product(cuda, N_, cin, cout, H, W):
+    """prec = 2 (csrc/conv3x3.hip NP = 2: W_hi x_hi + W_hi x_lo, the weights' lo fragments neither fetched nor multiplied)
+    against prec = 0 on weights that are exact fp16 values, as every weight the reference loads is
+    (DS_NeRF/guidance/sd_utils.py:69-74): EQUAL outputs (the third product adds exact zeros), every tile shape (32 / 16 / 8
+    wide, channel-split or not), forward and transposed operator; the packer reports the image as two-product capable, and
+    says no for a weight with a non-zero lo half."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd._lib import ptr, stream, call
+    g = torch.Generator().manual_seed(cin + H)
+    w = _fp16_exact(torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(cuda)
+    x = torch.randn(N_, cin, H, W, generator=g).to(cuda)
+    bias = torch.randn(cout, generator=g).to(cuda)
+    s2 = ops.absmax_scale(x)
+    xs = ops._split_buffer(N_, cin, H * W, cuda)
+    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
+    for transpose in (False, True):
+        pk = ops.conv3x3_pack(w if not transpose else w.permute(1, 0, 2, 3).contiguous(), transpose)
+        assert pk._mvip_two_product is True
+        nbytes = int(_lib.load().mvip_conv3x3_workspace_bytes(N_, cin, cout, H, W))
+        ws = torch.empty(max(nbytes // 4, 1), device=cuda)
+        ys = []
+        for prec in (0, 2):
+            y = torch.empty(N_, cout, H, W, device=cuda)
+            call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), None, None, ptr(s2), N_, cin,
+                 cout, H, W, ptr(y), ptr(ws), prec, stream())
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    pk = ops.conv3x3_pack(w, False)
+    y = torch.empty(N_, cout, H, W, device=cuda)
+    call('mvip_conv3x3_f16x3', ptr(xs, torch.float16), ptr(pk, torch.uint8), ptr(bias), None, None, ptr(s2), N_, cin, cout, H, W,
+         ptr(y), 2, stream())
+    np.testing.assert_allclose(N(y), ref.float().cpu().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    w_full = (w + torch.randn(w.shape, generator=g).to(cuda) * 1e-6)
+    assert ops.conv3x3_pack(w_full, False)._mvip_two_product is False
+
+
+def test_two_product_gemm_paths_equal_three_product(cuda):
+    """The weight GEMMs in their two-product instantiations (gemm5 NP = 2: plain, split-K, GEGLU epilogue, operand sinks incl.
+    the transposed V-fragment launch) equal the three-product ones bit for bit on fp16-exact weights."""
+    from mvip_nerf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (N_, K, M, P) in ((2, 320, 320, 4096), (2, 1280, 1280, 256), (1, 640, 64, 1024)):
+        w = _fp16_exact(torch.randn(M, K, generator=g) * 0.04).to(cuda)
+        x = torch.randn(N_, K, P, generator=g).to(cuda)
+        b = torch.randn(M, generator=g).to(cuda)
+        pk = ops.gemm_pack_a(w, M, K, K, 1, weights=True)
+        assert pk._mvip_two_product is True
+        assert not hasattr(ops.gemm_pack_a(w, M, K, K, 1), '_mvip_two_product')       # activations packed per step never ask
+        s2 = ops.absmax_scale(x)
+        xs = ops.split_planes_strided(x, N_, K, P, K * P, P, 1, s2)
+        outs = []
+        for two in (False, True):
+            ops.TWO_PRODUCT = two
+            try:
+                assert ops._prec_w(pk) == (2 if two else 0)
+                outs.append(ops.gemm_f16x3(xs, pk, N_, K, M, P, bias=b, x_scale2=s2))
+                if M % 64 == 0:
+                    outs.append(ops.gemm_f16x3_planes(xs, pk, N_, K, M, P, 0.25, bias=b, x_scale2=s2))
+            finally:
+                ops.TWO_PRODUCT = True
+        h = len(outs) // 2
+        for a, c in zip(outs[:h], outs[h:]):
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, c.view(torch.int16) if c.dtype == torch.float16 else c)
+        ref = torch.einsum('mk,nkp->nmp', w.double(), x.double()) + b.double()[None, :, None]
+        np.testing.assert_allclose(N(outs[h]), ref.float().cpu().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    # a weight with a non-zero lo half keeps the three-product kernels
+    w_full = torch.randn(64, 64, generator=g).to(cuda)
+    pk = ops.gemm_pack_a(w_full, 64, 64, 64, 1, weights=True)
+    assert pk._mvip_two_product is False and ops._prec_w(pk) == 0
+
+
+def test_two_product_step_equals_three_product_step(cuda):
+    """VERDICT r3 task 1(a): one full-size train_step_sd with the built-in networks (fp16-representable random weights, like
+    the reference's revision="fp16" checkpoint cast up to fp32) run with two products per contraction step and with three:
+    the image gradient is EQUAL (torch.equal; the third product adds exact zeros).  And the networks built with
+    fp16_weights=False (full fp32 random values) never take the two-product kernels."""
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    from mvip_nerf_amd.guidance.sd_nets import SDNetworks
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False, use_graphs=False)
+    assert sd.networks.fp16_weights
+    for p_ in list(sd.unet.parameters())[:20] + list(sd.vae.parameters())[:20]:
+        assert torch.equal(p_.half().float(), p_)
+    mask = torch.zeros(1, 1, 378, 504, device=cuda)
+    mask[:, :, 137:241, 196:307] = 1
+    base = torch.rand(1, 3, 378, 504, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    grads = {}
+    for two in (True, False, True):
+        ops.TWO_PRODUCT = two
+        try:
+            sd.seed_generator(77)
+            pred = base.clone().requires_grad_(True)
+            (1e-4 * sd.train_step_sd(1000, mask, 'a stone bench in a park', pred, guidance_scale=7.5)).sum().backward()
+            grads.setdefault(two, []).append(pred.grad.clone())
+        finally:
+            ops.TWO_PRODUCT = True
+    assert torch.isfinite(grads[True][0]).all() and float(grads[True][0].abs().max()) > 0
+    assert torch.equal(grads[True][0], grads[True][1])              # the step itself is reproducible
+    assert torch.equal(grads[True][0], grads[False][0])             # ... and two products EQUAL three
+    del sd
+    torch.cuda.empty_cache()
+    nets = SDNetworks(cuda, torch.float32, fp16_weights=False)
+    conv = nets.vae.encoder.down_blocks[0].resnets[0].conv1
+    assert ops._conv_packed(conv, False)._mvip_two_product is False

@@ -1,5 +1,7 @@
 """render_rays as two launches per chunk (run.FUSED_RENDER, csrc/mlp_fwd16.hip FUSE = 1 / 2) vs the six-launch chain: the
-1,024-ray supervision-size render and the 378x504 frame, test-mode kwargs, same weights; launches counted by the profiler."""
+1,024-ray supervision-size render and the 378x504 frame, test-mode kwargs, same weights; launches counted by the profiler.
+Three variants, interleaved: `fused` (two launches at every size: FUSED_RENDER_MAX_RAYS lifted), `six_launch_chain`, and
+`default` (the product's choice by chunk size: two launches up to run.FUSED_RENDER_MAX_RAYS rays, the chain above)."""
 import json
 import os
 import sys
@@ -21,9 +23,13 @@ def main():
     rows_1k = rows_all[torch.linspace(0, rows_all.shape[0] - 1, 1024).long()].contiguous()
     kw = dict(lindisp=True, perturb=0., N_importance=64, network_fine=te['network_fine'], white_bkgd=True, raw_noise_std=0.)
     out = {}
-    order = (True, False, True, False) if '--swap' in sys.argv else (False, True, False, True)
-    for rnd, fused in enumerate(order):                 # interleaved: a sustained run drifts by a few per cent (clocks)
-        run.FUSED_RENDER = fused
+    order = ('fused', 'six_launch_chain', 'default') * 2
+    if '--swap' in sys.argv:
+        order = order[::-1]
+    default_max = run.FUSED_RENDER_MAX_RAYS
+    for rnd, variant in enumerate(order):               # interleaved: a sustained run drifts by a few per cent (clocks)
+        run.FUSED_RENDER = variant != 'six_launch_chain'
+        run.FUSED_RENDER_MAX_RAYS = (1 << 30) if variant == 'fused' else default_max
         rec = {}
         with torch.no_grad():
             def small():
@@ -47,11 +53,11 @@ def main():
                 rec[name + '_device_ms'] = sum(e.device_time_total for e in ev) / 1e3
         ev_top = sorted(ev, key=lambda e: -e.device_time_total)[:3]
         rec['frame_top_kernels'] = [[e.key[:60], e.count, round(e.device_time_total / 1e3, 2)] for e in ev_top]
-        out[('fused' if fused else 'six_launch_chain') + f'_round{rnd // 2}'] = rec
-    run.FUSED_RENDER = True
+        out[variant + f'_round{rnd // 3}'] = rec
+    run.FUSED_RENDER, run.FUSED_RENDER_MAX_RAYS = True, default_max
     print(json.dumps(out, indent=1))
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(out, open('gpurun_out/r3_fused_render_ab.json', 'w'), indent=1)
+    json.dump(out, open('gpurun_out/r4_fused_render_ab.json', 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 for W in ${PMC_DIAG_WORKLOADS:-train sds}; do
-  if [ $W = train ]; then PROG="tools/train_speed.py"; else PROG="tools/sds_profile.py"; fi
+  if [ $W = train ]; then PROG="tools/train_speed.py"; else PROG="tools/sds_profile_steps.py"; fi
   for P in A B; do
     if [ $P = A ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES";
     else C="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM"; fi

@@ -22,7 +22,7 @@ find gpurun_out/pmc_r3 -name '*.csv' -delete; find gpurun_out/pmc_r3 -name '*.db
 for C in FETCH_SIZE WRITE_SIZE; do
   D=gpurun_out/pmc_r3_$(echo $C | tr A-Z a-z | sed 's/_size//')
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 0 --sds-steps 0 --no-cpu-baseline --no-hashgrid > $D/line.json 2> $D/err.log
-  find $D -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_one.py {} > $D/dominant.json
+  find $D -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_summary.py {} --longest mlp_forward16_kernel > $D/dominant.json
   find $D -name '*.csv' -delete; find $D -name '*.db' -delete
   D=gpurun_out/pmc_r3_sds_$(echo $C | tr A-Z a-z | sed 's/_size//')
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 tools/sds_profile_steps.py 3 > $D/out.txt 2> $D/err.log

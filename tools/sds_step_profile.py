@@ -1,5 +1,9 @@
 """Per-kernel device time of ONE steady-state `train_step_sd` (forward + backward to the image) at SD-1.5-inpaint
-shapes, from the torch profiler: top kernels with call counts, device-busy total and the wall time of the step."""
+shapes, from the torch profiler: top kernels with call counts, device-busy total and the wall time of the step.
+  --fp16          the reference's --fp16 mode
+  --graphs        also time the hipGraph replay of the same step
+  --sequence=F    also write the step's launches IN ORDER to gpurun_out/F: [start_us, dur_us, name] per device activity
+  --three         MVIP_TWO_PRODUCT off (the three-product kernels on the same fp16-exact weights: A/B of round 4's task 1a)"""
 import json
 import os
 import sys
@@ -15,6 +19,9 @@ def main():
     if os.environ.get('MVIP_ROW_MOMENTS') == '0':          # A/B: every GroupNorm computes its moments from its input
         from mvip_nerf_amd import ops
         ops.ROW_MOMENTS = False
+    if '--three' in sys.argv:
+        from mvip_nerf_amd import ops
+        ops.TWO_PRODUCT = False
     dev = torch.device('cuda', 0)
     fp16 = '--fp16' in sys.argv            # the reference's --fp16 mode on the single-product kernels
     graphs = '--graphs' in sys.argv        # also time the captured-hipGraph replay of the same step
@@ -41,6 +48,14 @@ def main():
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
         step(1100)
         torch.cuda.synchronize()
+    seq_name = next((a.split('=', 1)[1] for a in sys.argv if a.startswith('--sequence=')), None)
+    if seq_name:
+        evs = [e for e in prof.events() if getattr(e, 'device_type', None) is not None and str(e.device_type).endswith('CUDA')]
+        evs.sort(key=lambda e: e.time_range.start)
+        t0 = evs[0].time_range.start if evs else 0
+        os.makedirs('gpurun_out', exist_ok=True)
+        json.dump([[round(e.time_range.start - t0, 2), round(e.time_range.end - e.time_range.start, 2), e.name[:140]] for e in evs],
+                  open(os.path.join('gpurun_out', seq_name), 'w'))
     ev = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
     total = sum(e.device_time_total for e in ev) / 1e3
     n = sum(e.count for e in ev if e.device_time_total > 0)        # device activities only (the averages also list the launch calls)

@@ -1,4 +1,4 @@
-"""Steady-state per-step summary of a rocprofv3 --kernel-trace of tools/sds_profile.py.
+"""Steady-state per-step summary of a rocprofv3 --kernel-trace of tools/sds_profile_steps.py.
 
 Steps are delimited by the first bilinear-resize kernel of each train_step_sd (two per step: image and
 mask), so library warm-up (MIOpen find mode) and the end-of-run idle never enter the window.
