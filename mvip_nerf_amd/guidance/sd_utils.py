@@ -136,6 +136,12 @@ class _GraphedStep:
         self.mask = torch.zeros(mask_shape, device=dev)
         self.scal = torch.zeros(4, device=dev)                  # sqrt(abar), sqrt(1-abar), 1-abar, t
         sd.networks.encode_prompt(prompt, guidance_scale > 1.0)    # cached constant, outside the capture
+        # Warm-up and capture run the body three times and DRAW each time; an eager step draws once.  The generator's state
+        # is put back afterwards, so that the first replay consumes exactly the draws an eager first step would have (measured:
+        # replays equal eager steps to atomics-level, 2e-6 relative, draw for draw -- profiles/r4_graph_vs_eager_draws.json --
+        # once the starting state is the same).
+        gen = sd.generator if sd.generator is not None else torch.cuda.default_generators[torch.device(dev).index or 0]
+        gen_state = gen.get_state()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -157,6 +163,7 @@ class _GraphedStep:
         # warm-up above) lives as long as this graph, whatever another prompt does to those caches afterwards
         from . import transformer_cm
         self.pinned = transformer_cm.prompt_entries(sd.unet) if isinstance(sd.unet, nn.Module) else []
+        gen.set_state(gen_state)
 
     def _body(self):
         sd = self.sd

@@ -60,7 +60,18 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'scene1_small.npz'), images=(img_s * 255 + .5).astype(np.uint8),
                         masks=msk_s, depths=(dep_s * 255 + .5).astype(np.uint8), poses=poses[views],
                         bds=bds, views=np.array(views), factor=16)
-    for f in ('llff_scene1_f4.npz', 'scene1_small.npz'):
+    # factor-8 fixture (283 x 504: BASELINE configs[0]'s geometry, the size the PSNR clause names): 15 training views (every
+    # 4th) + view 30 held out, the factor-4 rasters box-filtered 2x (567 -> 283 rows: the last row dropped)
+    views8 = sorted(set(range(0, 60, 4)) | {30})
+    def down2(a):
+        h, w = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
+        a = a[:h, :w]
+        return a.reshape(h // 2, 2, w // 2, 2, *a.shape[2:]).mean((1, 3))
+    img8 = np.stack([down2(images[v]) for v in views8])
+    msk8 = np.stack([(down2(masks[v]) > 0.5) for v in views8])
+    np.savez_compressed(os.path.join(OUT, 'scene1_f8.npz'), images=(img8 * 255 + .5).astype(np.uint8), masks=msk8,
+                        poses=poses[views8], bds=bds, views=np.array(views8), factor=8, held_out_view=30)
+    for f in ('llff_scene1_f4.npz', 'scene1_small.npz', 'scene1_f8.npz'):
         print(f, os.path.getsize(os.path.join(OUT, f)) / 1024, 'KB')
 
 

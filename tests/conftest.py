@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: a gpu test of minutes (real-data training); still part of -m gpu')
 
 
 @pytest.fixture(scope='session')

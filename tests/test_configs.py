@@ -267,3 +267,62 @@ def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path):
                                                                # profiles/r3_real_scene1.json)
     assert abs(p_h - p_o) < 0.05, (p_h, p_o)
     assert float(-10 * torch.log10(((hip[sel] - ora) ** 2).mean())) > 60.0        # HIP vs oracle, same weights
+
+
+FIXTURE_F8 = os.path.join(os.path.dirname(__file__), 'golden', 'scene1_f8.npz')
+
+
+@pytest.mark.slow
+def test_heldout_psnr_at_factor8_hip_vs_oracle_within_0p05_dB(cuda):
+    """The PSNR clause at a BASELINE size (VERDICT r3 task 9): factor 8 = 283 x 504, configs[0]'s geometry, REAL pixels of
+    SPIn-NeRF scene 1 (tests/golden/scene1_f8.npz: the factor-4 rasters of the reference's own loader box-filtered 2x, 15
+    training views + view 30 held out; oracle/gen_golden_llff.py).  6,000 photometric iterations of 4,096 rays (3,000 reach
+    21.6 dB on this 15-view subset, 6,000 reach 23.0: profiles/r4_real_scene1_f8.json)
+    (DS_NeRF/run.py:1000-1039's loss form without the prior), the held-out view rendered by the HIP path
+    (DS_NeRF/run.py:1222-1362 render_path) and, from the SAME trained weights, by the CPU oracle on every 5th pixel:
+    PSNR(HIP) >= 22 dB against the ground truth (DS_NeRF/run_nerf_helpers.py:17 mse2psnr), |PSNR(HIP) - PSNR(oracle)| < 0.05 dB
+    on the same pixels, HIP vs oracle > 60 dB."""
+    from mvip_nerf_amd import run, ops
+    from mvip_nerf_amd.run_nerf_helpers import img2mse
+    d = np.load(FIXTURE_F8)
+    images = torch.from_numpy(d['images'].astype(np.float32) / 255.).to(cuda)
+    poses = torch.from_numpy(d['poses'][:, :, :4]).to(cuda)
+    Nv, H, W, _ = images.shape
+    assert (H, W) == (283, 504) and int(d['factor']) == 8
+    focal = float(d['poses'][0, 2, 4]) * (W / float(d['poses'][0, 1, 4]))          # 383.65: BASELINE's focal
+    assert abs(focal - 383.65) < 0.01
+    near, far = float(d['bds'].min() * .9), float(d['bds'].max() * 1.)
+    held = int(np.nonzero(d['views'] == int(d['held_out_view']))[0][0])
+    i_train = [i for i in range(Nv) if i != held]
+    args = cfg_args(lrate=5e-4, white_bkgd=False, lindisp=False)
+    torch.manual_seed(0)
+    tr, te, _, grad_vars, opt = run.create_nerf(args, device=cuda)
+    kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
+    g = torch.Generator(device=cuda).manual_seed(0)
+    for it in range(6000):
+        v = i_train[int(torch.randint(0, len(i_train), (1,), generator=g, device=cuda))]
+        sel = torch.randint(0, H * W, (4096,), generator=g, device=cuda)
+        rows = ops.ray_rows_from_pose(poses[v], H, W, focal, near, far, sel=sel)
+        r = run.batchify_rays(rows, 1 << 15, **kw_tr)
+        tgt = images[v].reshape(-1, 3)[sel]
+        loss = img2mse(r['rgb_map'], tgt) + img2mse(r['rgb0'], tgt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    rgbs, _, _ = run.render_path(poses[held:held + 1], (H, W, focal), 1 << 15, dict(te, near=near, far=far))
+    hip = torch.from_numpy(rgbs[0]).reshape(-1, 3)
+    pc = {k: p.detach().cpu() for k, p in tr['network_fn'].named_parameters()}
+    pf = {k: p.detach().cpu() for k, p in tr['network_fine'].named_parameters()}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ro, rd = O.get_rays(H, W, focal, poses[held].cpu())
+    sel = torch.arange(0, H * W, 5)
+    rows = O.assemble_ray_batch(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], near, far)
+    with torch.no_grad():
+        ora = torch.cat([O.render_rays(rows[i:i + 4096], pc, pf, 64, 64, lindisp=False, white_bkgd=False)['rgb_map']
+                         for i in range(0, rows.shape[0], 4096)], 0)
+    gt = images[held].cpu().reshape(-1, 3)[sel]
+    psnr = lambda x: float(-10 * torch.log10(((x - gt) ** 2).mean()))
+    p_h, p_o = psnr(hip[sel]), psnr(ora)
+    assert p_h >= 22.0, (p_h, p_o)
+    assert abs(p_h - p_o) < 0.05, (p_h, p_o)
+    assert float(-10 * torch.log10(((hip[sel] - ora) ** 2).mean())) > 60.0        # HIP vs oracle, same weights

@@ -636,12 +636,14 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
             out.append(pred.grad.clone())
         return out
 
-    series(True)                                            # capture + first replays
+    first = series(True)                                    # capture (generator state restored afterwards) + first replays
     a, b, c = series(True), series(True), series(False)
-    for x, y, z in zip(a, b, c):
+    for w, x, y, z in zip(first, a, b, c):
         assert float((x - y).norm() / x.norm()) < 1e-4       # replay vs replay: atomics order only
-        assert float((x - z).norm() / z.norm()) < 2e-2       # vs eager: one low-weight draw is ordered differently
-        assert 0.5 < float(x.abs().max() / z.abs().max()) < 2.0
+        # vs eager: the SAME draws in the same order (tools/graph_vs_eager_draws.py: equal draw for draw), so atomics-level too
+        assert float((x - z).norm() / z.norm()) < 1e-4
+        # and the very first graphed call -- warm-up and capture draw as well, the generator state is put back -- likewise
+        assert float((w - z).norm() / z.norm()) < 1e-4
 
 
 def test_graphed_steps_with_two_alternating_prompts(cuda):
@@ -679,7 +681,7 @@ def test_graphed_steps_with_two_alternating_prompts(cuda):
     graphed = series(True)
     for k, (a, b) in enumerate(zip(eager, graphed)):
         assert torch.isfinite(b).all()
-        assert float((a - b).norm() / a.norm()) < 2e-2, k        # one low-weight draw is ordered differently under capture
+        assert float((a - b).norm() / a.norm()) < 1e-4, k        # same draws, same order: atomics-level
     assert float((eager[0] - eager[1]).norm() / eager[0].norm()) > 1e-3        # the prompts really differ
     for m in sd.unet.modules():
         pk = m.__dict__.get('_mvip_cm')

@@ -1,4 +1,6 @@
-"""End-to-end on REAL data (SPIn-NeRF scene 1, 30 views at 1/16 resolution from tests/golden/scene1_small.npz):
+"""End-to-end on REAL data (SPIn-NeRF scene 1: 30 views at 1/16 resolution from tests/golden/scene1_small.npz, or with
+--fixture f8 the factor-8 fixture tests/golden/scene1_f8.npz -- 283 x 504, BASELINE configs[0]'s geometry, 15 training views
+and view 30 held out):
 photometric NeRF training with the HIP renderer, held-out PSNR, and the north-star parity clause --
 PSNR against ground truth of the HIP render vs the CPU-oracle render of the SAME trained weights."""
 import argparse, json, os, sys, time, types
@@ -15,15 +17,17 @@ ap.add_argument('--train-precision', type=int, default=0)
 ap.add_argument('--tcnn', action='store_true', help='train the hash-grid model (NeRF_TCNN) instead of the 8x256 MLPs')
 ap.add_argument('--half2-atomics', action='store_true', help='hash-grid model: half-pair atomics for the table gradient')
 ap.add_argument('--oracle-view', type=int, default=1, help='render this many held-out views with the CPU oracle')
+ap.add_argument('--fixture', default='small', choices=['small', 'f8'])
+ap.add_argument('--oracle-stride', type=int, default=1, help='the oracle renders every k-th pixel of the held-out view')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
-d = np.load(os.path.join(ROOT, 'tests', 'golden', 'scene1_small.npz'))
-images = torch.from_numpy(d['images'].astype(np.float32) / 255.).to(dev)            # [30,141,252,3]
+d = np.load(os.path.join(ROOT, 'tests', 'golden', 'scene1_small.npz' if a.fixture == 'small' else 'scene1_f8.npz'))
+images = torch.from_numpy(d['images'].astype(np.float32) / 255.).to(dev)            # [30,141,252,3] / [16,283,504,3]
 poses = torch.from_numpy(d['poses'][:, :, :4]).to(dev)
 N, H, W, _ = images.shape
-focal = float(d['poses'][0, 2, 4]) * (H / float(d['poses'][0, 0, 4]))
+focal = float(d['poses'][0, 2, 4]) * (W / float(d['poses'][0, 1, 4])) if a.fixture == 'f8' else float(d['poses'][0, 2, 4]) * (H / float(d['poses'][0, 0, 4]))
 near, far = float(d['bds'].min() * .9), float(d['bds'].max() * 1.)
-i_test = [4, 14, 24]
+i_test = [4, 14, 24] if a.fixture == 'small' else [int(np.nonzero(d['views'] == int(d['held_out_view']))[0][0])]
 i_train = [i for i in range(N) if i not in i_test]
 args = types.SimpleNamespace(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=64,
                              alpha_model_path=None, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
@@ -87,18 +91,20 @@ cmp = []
 for k in range(a.oracle_view):
     v = i_test[k]
     ro, rd = O.get_rays(H, W, focal, poses[v].cpu())
-    rows = O.assemble_ray_batch(ro, rd, near, far)
+    sel = torch.arange(0, H * W, a.oracle_stride)
+    rows = O.assemble_ray_batch(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], near, far)
     with torch.no_grad():
         parts = [O.render_rays(rows[i:i + 4096], pc, pf, 64, 64, lindisp=False, white_bkgd=False)['rgb_map']
                  for i in range(0, rows.shape[0], 4096)]
-    rgb_o = torch.cat(parts, 0).reshape(H, W, 3)
-    gt = images[v].cpu()
+    rgb_o = torch.cat(parts, 0)
+    gt = images[v].cpu().reshape(-1, 3)[sel]
+    hip_sel = renders[k].cpu().reshape(-1, 3)[sel]
     p_o = float(O.mse2psnr(O.img2mse(rgb_o, gt)))
-    p_h = psnr_hip[k]
-    mse_ho = float(O.img2mse(rgb_o, renders[k].cpu()))
+    p_h = float(O.mse2psnr(O.img2mse(hip_sel, gt)))          # on the oracle's pixel subset (stride 1: the whole view)
+    mse_ho = float(O.img2mse(rgb_o, hip_sel))
     cmp.append({'view': int(d['views'][v]), 'psnr_gt_oracle': p_o, 'psnr_gt_hip': p_h, 'delta_dB': p_h - p_o,
                 'psnr_hip_vs_oracle': float(-10 * np.log10(max(mse_ho, 1e-20)))})
 res['hip_vs_oracle_same_weights'] = cmp
 print(json.dumps(res))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'real_scene_r1_prec{a.train_precision}.json'), 'w'), indent=1)
+json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'real_scene_{a.fixture}_prec{a.train_precision}.json'), 'w'), indent=1)
