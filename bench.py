@@ -439,7 +439,7 @@ def main():
                                 f'[{H * W}, 6] fp32 = {H * W * 24 / 1e6:.2f} MB per frame so every rank holds rgb / disp / acc / depth; '
                                 'value_1_same_run = whole frames on one rank (the weak leg, slowest rank)'}
         par = (f'one frame over {world} ranks: contiguous ray blocks of {-(-H * W // world)} rays, one all_gather of the maps '
-               'per frame (RCCL over xGMI)')
+               f'per frame ({"RCCL over xGMI" if backend == "nccl" else backend})')
     result.update({
         'metric': 'rays_per_sec (coarse+fine, 64+128 samples, 504x378)', 'value': value,
         'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -116,6 +116,10 @@ int mvip_mlp_forward_points(const float *packed, const float *pts, const float *
 int mvip_mlp_pack16(const float *const *params_host, const float *packed, float *packed16, void *stream);
 int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
                             float *raw, void *stream);
+/* mvip_mlp_forward_rays16 as a persistent kernel (one workgroup per CU looping over its tiles; S a power of two).  Same bits;
+ * measured equal-to-slower (profiles/r4_persistent_ab.json): an A/B alternative, never the default path. */
+int mvip_mlp_forward_rays16_persistent(const float *packed16, const float *rows, const float *z, int64_t B, int S,
+                                       float *raw, void *stream);
 int mvip_mlp_forward_points16(const float *packed16, const float *pts, const float *dirs, int64_t P,
                               float *raw, void *stream);
 

@@ -37,6 +37,7 @@ _SIGNATURES = {
     'mvip_mlp_forward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _int, _c_f]),
     'mvip_mlp_pack16': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_rays16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_mlp_forward_rays16_persistent': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
     'mvip_mlp_forward_rays_stash16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_points16': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_render_coarse_fused': (_int, [_c_f, _c_f, _i64, _c_f, _int, _c_f, _c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f,

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u, int u_is_row,
     int64_t B, int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
     float *__restrict__ z_std, int64_t *__restrict__ inds_out, float *__restrict__ cdf_out) {
+    __shared__ int rank_rows[4][80];                 // per wave: the 65-word row of rank_merge64's prefix-maximum count
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= B) return;
     const int l = lane_id();
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
         wts[i] = e < nb - 1 ? weights[ray * Nc + e + 1] : 0.f;
         uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
     }
-    sample_merge_ray<IT>(zc, wts, uu, ray, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out);
+    sample_merge_ray<IT>(zc, wts, uu, ray, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out, rank_rows[threadIdx.x >> 6]);
 }
 
 template <int IT>

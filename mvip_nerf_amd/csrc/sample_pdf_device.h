@@ -156,25 +156,67 @@ __device__ __forceinline__ void bitonic_sort(float (&v)[M]) {
     }
 }
 
-// Bitonic sort of ONE value per lane (64 values), ascending: the partner exchanges on DPP / swizzle / half-wave swap
-// (common.h::dpp_xor) instead of 21 ds_bpermute shuffles.
+// Bitonic sort of ONE value per lane (64 values), ascending.  A compare-exchange step is THREE VALU instructions: min and max
+// take the partner lane as a DPP operand (v_min_f32_dpp / v_max_f32_dpp: quad permutes for lane distance 1 and 2, a row
+// rotation for 8, two bank-masked row shifts for 4) and a v_cndmask picks by a CONSTANT 64-bit lane mask held in scalar
+// registers.  Written as inline assembly: through fminf / fmaxf the compiler canonicalises both operands of every min / max
+// (v_max_f32 x, x, x: signalling-NaN quieting, ~2 extra instructions per step) and rebuilds the lane predicate from the lane
+// id each time -- ten issue slots per step instead of four, on a kernel that is bound by VALU issue.  Distances 16 and 32
+// keep the swizzle / half-wave swap of common.h::dpp_xor.  NaNs: v_min / v_max return the other operand, as fminf / fmaxf do.
 template <int K, int J>
-__device__ __forceinline__ void bitonic_step64(float &v, int l) {
-    const float other = dpp_xor<J>(v);
-    const bool up = (l & K) == 0, lower = (l & J) == 0;
-    const float mn = fminf(v, other), mx = fmaxf(v, other);
-    v = (lower == up) ? mn : mx;
+constexpr unsigned long long bitonic_min_mask() {          // lanes that keep the MINIMUM of (own, partner l ^ J) in block size K
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((l & J) == 0) == ((l & K) == 0)) m |= 1ull << l;
+    return m;
+}
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step64(float &v) {
+    constexpr unsigned long long mask = bitonic_min_mask<K, J>();
+    float mn, mx;
+    if constexpr (J == 1)
+        asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %1, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(mn), "=&v"(mx) : "v"(v));
+    else if constexpr (J == 2)
+        asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %1, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(mn), "=&v"(mx) : "v"(v));
+    else if constexpr (J == 8)
+        asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %1, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(mn), "=&v"(mx) : "v"(v));
+    else if constexpr (J == 4) {
+        mn = v; mx = v;                                     // banks 0, 2 take lane + 4, banks 1, 3 lane - 4; a masked-off bank keeps the old value
+        asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_max_f32_dpp %1, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_min_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_max_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "+&v"(mn), "+&v"(mx) : "v"(v));
+    } else {
+        const float other = dpp_xor<J>(v);
+        asm volatile("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(v), "v"(other));
+    }
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v) : "v"(mx), "v"(mn), "s"(mask));
 }
 __device__ __forceinline__ void bitonic_sort64(float &v) {
-    const int l = lane_id();
-    bitonic_step64<2, 1>(v, l);
-    bitonic_step64<4, 2>(v, l); bitonic_step64<4, 1>(v, l);
-    bitonic_step64<8, 4>(v, l); bitonic_step64<8, 2>(v, l); bitonic_step64<8, 1>(v, l);
-    bitonic_step64<16, 8>(v, l); bitonic_step64<16, 4>(v, l); bitonic_step64<16, 2>(v, l); bitonic_step64<16, 1>(v, l);
-    bitonic_step64<32, 16>(v, l); bitonic_step64<32, 8>(v, l); bitonic_step64<32, 4>(v, l); bitonic_step64<32, 2>(v, l);
-    bitonic_step64<32, 1>(v, l);
-    bitonic_step64<64, 32>(v, l); bitonic_step64<64, 16>(v, l); bitonic_step64<64, 8>(v, l); bitonic_step64<64, 4>(v, l);
-    bitonic_step64<64, 2>(v, l); bitonic_step64<64, 1>(v, l);
+    bitonic_step64<2, 1>(v);
+    bitonic_step64<4, 2>(v); bitonic_step64<4, 1>(v);
+    bitonic_step64<8, 4>(v); bitonic_step64<8, 2>(v); bitonic_step64<8, 1>(v);
+    bitonic_step64<16, 8>(v); bitonic_step64<16, 4>(v); bitonic_step64<16, 2>(v); bitonic_step64<16, 1>(v);
+    bitonic_step64<32, 16>(v); bitonic_step64<32, 8>(v); bitonic_step64<32, 4>(v); bitonic_step64<32, 2>(v);
+    bitonic_step64<32, 1>(v);
+    bitonic_step64<64, 32>(v); bitonic_step64<64, 16>(v); bitonic_step64<64, 8>(v); bitonic_step64<64, 4>(v);
+    bitonic_step64<64, 2>(v); bitonic_step64<64, 1>(v);
+}
+
+// inclusive prefix MAXIMUM of non-negative integers over the 64 lanes (the DPP scan of common.h with max instead of add)
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false); }
+__device__ __forceinline__ int dpp_incl_max_nonneg(int v) {
+    v = max(v, dpp_i32<0x111>(0, v));
+    v = max(v, dpp_i32<0x112>(0, v));
+    v = max(v, dpp_i32<0x114>(0, v));
+    v = max(v, dpp_i32<0x118>(0, v));
+    v = max(v, dpp_i32<0x142, 0xa>(0, v));
+    v = max(v, dpp_i32<0x143, 0xc>(0, v));
+    return v;
 }
 
 // #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
@@ -204,10 +246,11 @@ __device__ __forceinline__ int count_below(const float key, const float x) {
 // the upper midpoint), and the wave falls back to the search if any lane fails the check.  Only meaningful while b is in
 // its original lane order, i.e. when it did not have to be sorted.
 __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int nb, bool b_may_be_unsorted,
-                                             float *__restrict__ out_row, int below_hint = -1) {
+                                             float *__restrict__ out_row, int below_hint = -1, int *lds_w = nullptr) {
     const int l = lane_id();
     const float a_key = l < na ? a : INFINITY;
     float b_key = l < nb ? b : INFINITY;
+    if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
     const float a_next = dpp_from_next(a_key, a_key), b_next = dpp_from_next(b_key, b_key);
     if (__any(l < 63 && a_next < a_key)) return false;
     bool b_in_lane_order = true;
@@ -216,10 +259,8 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
         bitonic_sort64(b_key);                                   // random u: sort the 64 new samples (21 stages)
         b_in_lane_order = false;
     }
-    if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
     // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
     // +inf padding lanes of the other list and land beyond the ray's own row
-    const int pa = l + min(count_below<true>(b_key, a_key), nb);
     int cb = -1;
     if (b_in_lane_order && below_hint >= 0) {
         const int r0 = below_hint + 1;                           // a_0 .. a_{r0 - 1} <= b_j
@@ -228,7 +269,24 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
         cb = r0 + (e0 <= b_key ? 1 : 0);
         if (__any(l < nb && !(e1 > b_key))) cb = -1;             // wave-uniform: the ballot covers every valid lane
     }
-    const int pb = l + min(cb >= 0 ? cb : count_below<false>(a_key, b_key), na);
+    const int cbj = min(cb >= 0 ? cb : count_below<false>(a_key, b_key), na);        // #{a <= b_j}, non-decreasing in j
+    int ca;                                                                         // #{b < a_i}
+    if (lds_w) {
+        // b_j < a_i  <=>  i >= cb_j (a sorted, cb_j = index of the first a above b_j), and cb_j does not decrease with j: so
+        // #{b < a_i} = 1 + the LAST j with cb_j <= i.  Every run of equal cb_j leaves its last j + 1 at word cb_j of a zeroed
+        // 65-word row of LDS (one writer per word), lane i reads word i, and an inclusive prefix maximum (six DPP steps)
+        // finishes the count: 3 LDS operations + ~15 VALU instructions instead of the seven-step cross-lane search (~45).
+        // One wave owns the row and LDS operations of a wave execute in order: no barrier.
+        volatile int *row = lds_w;
+        row[l] = 0;
+        if (l == 0) row[64] = 0;
+        const int cb_next = dpp_i32<0x130>(-1, cbj);            // lane l + 1's count (lane 63: -1 = "differs")
+        if (l < nb && (l == nb - 1 || cb_next != cbj)) row[cbj] = l + 1;
+        ca = dpp_incl_max_nonneg(row[l]);
+    } else {
+        ca = min(count_below<true>(b_key, a_key), nb);
+    }
+    const int pa = l + ca, pb = l + cbj;
     if (l < na) out_row[pa] = a_key;
     if (l < nb) out_row[pb] = b_key;
     return true;
@@ -242,7 +300,7 @@ template <int IT>
 __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const float (&wts)[IT], const float (&uu)[IT], int64_t ray,
                                                  int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
                                                  float *__restrict__ z_std, int64_t *__restrict__ inds_out,
-                                                 float *__restrict__ cdf_out) {
+                                                 float *__restrict__ cdf_out, int *lds_w = nullptr) {
     const int l = lane_id();
     const int nb = Nc - 1;                           // midpoints
     float bins[IT], smp[IT], cdf[IT];
@@ -284,7 +342,7 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
     if constexpr (IT == 1) {
-        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1))) return;
+        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1), lds_w)) return;
     }
     constexpr int M = 2 * IT;
     float v[M];

@@ -170,3 +170,41 @@ def test_view_sharded_sds_equals_single_process(tmp_path, cuda, world):
             assert torch.equal(parts[0]['grads'][k], p['grads'][k])              # identical after the all-reduce
         tol = 3e-3 * float(gr.abs().max()) + 1e-12
         np.testing.assert_allclose(parts[0]['grads'][k].numpy(), gr.numpy(), rtol=3e-3, atol=tol)
+
+
+# ---- the strong-scaling render: one frame over all ranks (bench.py --gpus N headline, run.render_sharded) -------------
+def _run_sharded_render(rank, world, port, out):
+    from mvip_nerf_amd import run
+    from oracle.weights import seeded_state_dict
+    import bench
+    dev = torch.device('cuda', 0)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        tr, te, _, _, _ = run.create_nerf(bench.make_args(), device=dev)
+        for net, seed in ((te['network_fn'], 71), (te['network_fine'], 72)):
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
+        H, W, focal = 37, 53, 383.65 * 53 / 504                      # 1,961 rays: ragged blocks for 2 and 3 ranks
+        with torch.no_grad():
+            maps = run.render_sharded(H, W, focal, bench.orbit_pose(3, dev), rank, world, dist, chunk=512, near=bench.NEAR,
+                                      far=bench.FAR, **te)
+            whole = run.render(H, W, focal, chunk=512, c2w=bench.orbit_pose(3, dev), near=bench.NEAR, far=bench.FAR, **te) if rank == 0 else None
+        torch.save({'maps': [m.cpu() for m in maps], 'whole': None if whole is None else [m.cpu() for m in whole[:4]]},
+                   os.path.join(out, f's{world}r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_frame_render_equals_whole_frame(tmp_path, cuda, world):
+    """run.render_sharded through the real kernels: every rank renders its contiguous block of the frame's rays, ONE
+    all_gather assembles (rgb, disp, acc, depth) on every rank -- bit for bit the maps of render() on one device (rays are
+    independent and the kernels chunk-invariant), on all ranks, for ragged block sizes."""
+    mp.spawn(_run_sharded_render, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), f's{world}r{r}.pt')) for r in range(world)]
+    whole = parts[0]['whole']
+    assert tuple(whole[0].shape) == (37, 53, 3)
+    for p in parts:
+        for got, want in zip(p['maps'], whole):
+            assert got.shape == want.shape
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32))

@@ -548,6 +548,18 @@ def test_mlp_forward_two_waves_per_simd_kernel(golden, cuda):
         r16 = ops.mlp_rays(rows, z, packed, ps, packed16=p16)
         r32 = ops.mlp_rays(rows, z, packed, ps)
     np.testing.assert_allclose(N(r16), N(r32), rtol=2e-5, atol=2e-6)
+    # the persistent form (one workgroup per CU looping over its tiles; an A/B alternative, round 4): the same bits, for ray
+    # counts that give the 256 workgroups 0, 1 and several tiles each and a ragged last tile
+    from mvip_nerf_amd._lib import ptr, stream, call
+    for B_ in (37, 700, 2049):
+        rows_b = torch.from_numpy(bench_like_rays(B_, seed=B_)).float().to(cuda)
+        for S_ in (64, 128):
+            z_b = ops.stratified_z(rows_b, S_, True)
+            ref = torch.empty(B_, S_, 4, device=cuda)
+            per = torch.full((B_, S_, 4), float('nan'), device=cuda)
+            call('mvip_mlp_forward_rays16', ptr(p16), ptr(rows_b), ptr(z_b), B_, S_, ptr(ref), stream())
+            call('mvip_mlp_forward_rays16_persistent', ptr(p16), ptr(rows_b), ptr(z_b), B_, S_, ptr(per), stream())
+            assert torch.equal(ref, per), (B_, S_)
 
 
 def test_two_wave_training_forward_stash(golden, cuda):

@@ -15,6 +15,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     for (N, cin, cout, H, W) in [(1, 128, 128, 512, 512), (1, 256, 256, 256, 256), (1, 512, 512, 128, 128), (2, 640, 640, 32, 32),
                                  (2, 320, 320, 64, 64)]:
         conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+        if os.environ.get('MVIP_CONV_EXACT_FP16_WEIGHTS', '1') == '1':     # as the reference's revision="fp16" weights: TWO products (NP = 2)
+            with torch.no_grad():
+                conv.weight.copy_(conv.weight.half().float())
         x = torch.randn(N, cin, H, W, device=dev)
         rs = torch.randn(N, cout, H, W, device=dev)
         s2 = ops.absmax_scale(x)
