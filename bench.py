@@ -729,7 +729,12 @@ def main():
                         'frac_of_sustained_f16x3_peak': round(ach / (PEAK_F16_TFLOPS / 3 * 1.67 / 2.4), 4),
                         'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
-                             'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 relative)',
+                             'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 '
+                                      'relative).  The random UNet / VAE weights are fp16-REPRESENTABLE values in fp32 containers, like the '
+                                      'reference\'s revision="fp16" checkpoint cast up (DS_NeRF/guidance/sd_utils.py:69-74): contractions with a '
+                                      'weight operand run TWO products (W_hi x_hi + W_hi x_lo; bit-identical to three, the lo half of such a '
+                                      'weight is zero), activation x activation products (attention) three',
+                             'two_product_weights': bool(getattr(sd.networks, 'fp16_weights', False)),
                              'ms_per_step_all': [round(t * 1e3, 2) for t in sds_times],
                              'mode': ('one captured hipGraph per (shape, prompt): the default of StableDiffusion for the built-in networks'
                                       + ('' if world == 1 else ' (MVIP_GRAPHS_WITH_DIST=1: replay beside a live multi-rank process group)')

@@ -336,6 +336,11 @@ int mvip_groupnorm_split_planes(const float *x, const float *gamma, const float 
 int mvip_groupnorm_split_planes_moments(const float *x, const float *gamma, const float *beta, const void *moments,
                                         float eps, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
                                         int prec, void *stream);
+/* The same, also writing mean / rstd [N, G] (the bits mvip_groupnorm_stats itself would write) for a backward that needs them
+ * (vae.encode under autograd, DS_NeRF/guidance/sd_utils.py:207): no separate finalize launch in the forward (round 4). */
+int mvip_groupnorm_split_planes_moments_out(const float *x, const float *gamma, const float *beta, const void *moments,
+                                            float eps, int64_t N, int64_t C, int64_t HW, int G, int silu, void *xs,
+                                            float *mean_out, float *rstd_out, int prec, void *stream);
 int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                        int64_t H, int64_t W, float *y, int prec, void *stream);

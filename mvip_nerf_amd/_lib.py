@@ -136,6 +136,8 @@ _SIGNATURES = {
     'mvip_absmax_scale_from_maxima': (_int, [_c_f, _i64, _c_f, _c_f]),
     'mvip_groupnorm_split_planes_moments': (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _i64, _i64, _i64, _int, _int, _c_f, _int,
                                                    _c_f]),
+    'mvip_groupnorm_split_planes_moments_out': (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _i64, _i64, _i64, _int, _int, _c_f, _c_f, _c_f,
+                                                       _int, _c_f]),
 }
 
 # every symbol include/mvip_nerf.h declares; tests check the built library exports all of them

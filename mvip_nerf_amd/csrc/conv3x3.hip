@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256)
 cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ scale2,
                    int C, int64_t HW, int cpg, uint4 *__restrict__ xs, int64_t sn, int64_t sc, int64_t sp, int prec,
-                   const double *__restrict__ part = nullptr, int chunks = 0, float eps = 0.f) {
+                   const double *__restrict__ part = nullptr, int chunks = 0, float eps = 0.f,
+                   float *__restrict__ mean_out = nullptr, float *__restrict__ rstd_out = nullptr) {
     __shared__ float pa[16], pb[16], pm[16];
     const int CK = C / 16;
     const int ck = (int)(blockIdx.y % CK);
@@ -257,6 +258,9 @@ cv_to_split_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                     if (var < 0.0) var = 0.0;
                     gmean[gi] = (float)mu;
                     grstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
+                    // the statistics also leave for a backward that needs them (the first pixel block of every channel chunk
+                    // writes its groups; chunks that share a group write the same bits): no gn_finalize launch
+                    if (mean_out && blockIdx.x == 0) { mean_out[n * G + g0 + gi] = gmean[gi]; rstd_out[n * G + g0 + gi] = grstd[gi]; }
                 }
             }
             __syncthreads();
@@ -1671,6 +1675,28 @@ extern "C" int mvip_groupnorm_split_planes_moments(const float *x, const float *
     return check_launch();
 }
 
+// mvip_groupnorm_split_planes_moments that ALSO writes mean / rstd [N, G] (bit-identical to mvip_groupnorm_stats' own): the
+// forward of a layer whose backward needs the statistics gets them from the plane writer, one launch less per GroupNorm.
+extern "C" int mvip_groupnorm_split_planes_moments_out(const float *x, const float *gamma, const float *beta,
+                                                       const void *moments, float eps, int64_t N, int64_t C, int64_t HW, int G,
+                                                       int silu, void *xs, float *mean_out, float *rstd_out, int prec,
+                                                       void *stream) {
+    if (N < 0 || C <= 0 || C % 16 != 0 || HW < 0 || G <= 0 || C % G != 0 || (prec < 0 || prec > 2)) return MVIP_EINVAL;
+    if (N == 0 || HW == 0) return MVIP_OK;
+    if (!x || !xs || !moments || !mean_out || !rstd_out || N * (C / 16) > 65535 || C / G < 4) return MVIP_EINVAL;
+    const int chunks = (int)(mvip_groupnorm_workspace_bytes(1, 1, HW) / 16);
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(N * (C / 16)));
+    if (silu)
+        hipLaunchKernelGGL((cv_to_split_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, nullptr,
+                           nullptr, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec,
+                           (const double *)moments, chunks, eps, mean_out, rstd_out);
+    else
+        hipLaunchKernelGGL((cv_to_split_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), x, gamma, beta, nullptr,
+                           nullptr, nullptr, (int)C, HW, (int)(C / G), (uint4 *)xs, C * HW, HW, (int64_t)1, prec,
+                           (const double *)moments, chunks, eps, mean_out, rstd_out);
+    return check_launch();
+}
+
 // Number of channel splits for a launch whose unsplit grid has `blocks` workgroups: fill ~2 workgroups per CU, keep at
 // least 4 channel chunks (12 stages) per workgroup so the pipeline prologue stays small.
 static inline int cv_splits(int64_t blocks, int64_t CK) {
@@ -1734,7 +1760,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     // eight-wave workgroups on 16 x 32 pixel tiles (MVIP_CONV_WIDE=1; tuning switch, default off: measured equal to the
     // four-wave tile on every VAE / UNet shape and on the whole step, 7.56 vs 7.65 ms -- tools/conv_wide_ab.py)
     static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
-    if (tw == CV_TW && wide_mode && H % 16 == 0 && prec == 0) {
+    if (tw == CV_TW && wide_mode && H % 16 == 0 && prec != 1) {
         const int64_t tiles16 = N * (W / CV_TW) * (H / 16);
         int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
         // MVIP_CONV_WIDE=2: 128 rows x 512 pixels per eight-wave workgroup (one per CU, two waves per SIMD, 128
@@ -1746,8 +1772,12 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
             if (wb > 0x7fffffffLL) return MVIP_EINVAL;
             if (mtw == 4)
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
+            else if (mtw == 2 && prec == 2)
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8, 2>), dim3((unsigned)wb), dim3(512), 0, st, a);
             else if (mtw == 2)
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
+            else if (prec == 2)
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8, 2>), dim3((unsigned)wb), dim3(512), 0, st, a);
             else
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
             return check_launch();

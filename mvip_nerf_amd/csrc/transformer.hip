@@ -13,6 +13,7 @@
 //                     time projections, x of shape [2, 1280]) -- one wavefront per output feature, weights streamed
 //                     once, exact fp32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mvip {
 namespace tok {
@@ -233,6 +234,9 @@ extern "C" int mvip_layernorm_split_planes(const float *x, const float *gamma, c
     if (N == 0) return MVIP_OK;
     if (!x || !xs || !workspace) return MVIP_EINVAL;
     hipStream_t st = as_stream(stream);
+    // (A fused statistics + apply kernel -- one workgroup per 64 tokens, all channels, two passes -- was built in round 4 and is
+    // SLOWER: 48 launches 0.70 ms against 0.21 + 0.38 ms for this pair, whose apply pass spreads over 5x more workgroups; the step
+    // 22.34 vs 22.09 ms on the same box.  Removed.)
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(LP / 64), (unsigned)(C / 64), (unsigned)N), dim3(256), 0, st, x,
                        (int)C, (int)L, (int)LP, (double *)workspace);
     hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)(LP / 256), (unsigned)(N * (C / 16))), dim3(256), 0, st, x, gamma,

@@ -726,7 +726,19 @@ class _NormActConv3x3(torch.autograd.Function):
         gb = None if norm.bias is None else norm.bias.detach().contiguous()
         xs = _split_buffer(N, C, HW, dev)
         keep_stats = ctx.needs_input_grad[0] or C // G < 4
-        if keep_stats:
+        if keep_stats and C // G >= 4 and STATS_FROM_PLANE_WRITER:
+            # the backward needs mean / rstd: the plane writer reduces the moment partials (as below) AND writes them out --
+            # the same bits gn_finalize would write, without its launch
+            rm = _row_moments_of(xc)
+            if rm is None:
+                call('mvip_groupnorm_stats', ptr(xc), N, C, HW, G, float(norm.eps), 0, None, None, ptr(ws, torch.float64), stream())
+                rm = ws
+            mean = torch.empty((N, G), device=dev, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            call('mvip_groupnorm_split_planes_moments_out', ptr(xc), ptr(gw), ptr(gb), ptr(rm, torch.float64), float(norm.eps),
+                 N, C, HW, G, int(bool(silu)), ptr(xs, torch.float16), ptr(mean), ptr(rstd), _prec(), stream())
+            ctx.save_for_backward(xc, gw, gb, mean, rstd)
+        elif keep_stats:
             mean, rstd = _gn_stats(xc, N, C, H, W, G, norm.eps, ws)
             call('mvip_groupnorm_split_planes', ptr(xc), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N, C, HW, G,
                  int(bool(silu)), ptr(xs, torch.float16), _prec(), stream())
@@ -788,6 +800,7 @@ class _NormActConv3x3(torch.autograd.Function):
 # reads the moments directly).  One entry; the strong reference keeps the address from being reused.
 _LAST_Y = [None]
 ROW_MOMENTS = True             # A/B switch: False = every GroupNorm computes its moments from its input
+STATS_FROM_PLANE_WRITER = True # A/B switch: False = mean / rstd of a forward with grad come from gn_finalize (one launch more)
 
 
 def _row_moments_of(xc):
