@@ -181,6 +181,55 @@ skinny_fwd_kernel(const float *__restrict__ Wt, int64_t w_sm, int64_t w_sn, cons
     }
 }
 
+// The same for M <= 16 output rows (the density net's 64 -> 16 layer, the colour head, the data gradient towards 16-wide
+// inputs) on v_mfma_f32_16x16x4_f32: the 32-row tile above would spend half of its matrix work on zero rows.  Lane (m, kq)
+// keeps W[m][4s + kq]; a wave step covers 64 points (lane's quad 4 (lane & 15) .. +3 of rows 4s + kq, one MFMA per component).
+template <int NS4, bool RELU>                  // NS4 = N / 4 steps (N padded to 4 NS4 with zero weights)
+__global__ void __launch_bounds__(256, 2)
+skinny_fwd16_kernel(const float *__restrict__ Wt, int64_t w_sm, int64_t w_sn, const float *__restrict__ X, int M, int N,
+                    int64_t P, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float a[NS4];
+#pragma unroll
+    for (int s = 0; s < NS4; ++s) {
+        const int k = 4 * s + kq;
+        a[s] = (n < M && k < N) ? Wt[n * w_sm + k * w_sn] : 0.f;
+    }
+    for (int64_t p0 = gw * 64; p0 < P; p0 += nw * 64) {
+        const int64_t pc = p0 + 4 * n;
+        const bool in = pc < P;
+        sg_f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = sg_f32x4{0.f, 0.f, 0.f, 0.f};
+        sg_f32x4 x[NS4];
+#pragma unroll
+        for (int s = 0; s < NS4; ++s) {
+            const int k = 4 * s + kq;
+            x[s] = (in && k < N) ? *reinterpret_cast<const sg_f32x4 *>(X + (int64_t)k * P + pc) : sg_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < NS4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s].w, acc[3], 0, 0, 0);
+        }
+        if (in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kq + r;                    // accumulator register r of lane (n, kq): row 4 kq + r, column n
+                if (row < M) {
+                    sg_f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                    *reinterpret_cast<sg_f32x4 *>(Y + (int64_t)row * P + pc) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace mvip
 
 using namespace mvip;
@@ -197,6 +246,20 @@ extern "C" int mvip_skinny_linear(const float *w, int64_t w_sm, int64_t w_sn, co
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks), block(256);
+    if (M <= 16) {                                              // 16-row tiles: 64 points per wave step
+        int64_t b16 = ((P + 63) / 64 + 3) / 4;
+        if (b16 > 2048) b16 = 2048;
+        const dim3 grid16((unsigned)b16), block16(256);
+#define SKL16(NS_) do { \
+        if (relu) hipLaunchKernelGGL((skinny_fwd16_kernel<NS_, true>), grid16, block16, 0, st, w, w_sm, w_sn, X, (int)M, (int)N, P, Y); \
+        else hipLaunchKernelGGL((skinny_fwd16_kernel<NS_, false>), grid16, block16, 0, st, w, w_sm, w_sn, X, (int)M, (int)N, P, Y); \
+    } while (0)
+        if (N > 32) SKL16(16);
+        else if (N > 16) SKL16(8);
+        else SKL16(4);
+#undef SKL16
+        return check_launch();
+    }
     const int tm = M > 32 ? 2 : 1, ns = N > 32 ? 32 : (N > 16 ? 16 : 8);
 #define SKL(TM_, NS_) do { \
         if (relu) hipLaunchKernelGGL((skinny_fwd_kernel<TM_, NS_, true>), grid, block, 0, st, w, w_sm, w_sn, X, (int)M, (int)N, P, Y); \

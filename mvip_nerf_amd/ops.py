@@ -936,35 +936,44 @@ def skinny_wgrad(dY, X):
     return slabs.sum(0)
 
 
-# Opt-in (MVIP_SKINNY_LINEAR=1): forward / data gradient of the hash-grid model's small layers on skinny_fwd_kernel instead
-# of torch matmuls.  Measured on the training iteration (tools/hashgrid_train_profile.py, same box, alternating): 15.6 ms
-# with the kernel, 15.2 ms with the library -- its 16-row MFMA tiles do half the matrix work of this kernel's 32-row tiles
-# on the 16-row layers -- so the library stays the default and the kernel a tested alternative.
-SKINNY_LINEAR = bool(int(_os.environ.get('MVIP_SKINNY_LINEAR', '0')))
+# Forward / data gradient of the hash-grid model's small layers run on skinny_fwd_kernel / skinny_fwd16_kernel (default since
+# round 4; MVIP_SKINNY_LINEAR=0 puts torch matmuls back as the A/B alternative).  Measured on the training iteration
+# (tools/hashgrid_train_profile.py, same box, alternating) in round 3 with 32-row tiles only: 15.6 ms with the kernel, 15.2 ms
+# with the library, whose 16-row MFMA tiles did half the matrix work on the 16-row layers -- those layers now have a 16-row
+# kernel of their own.
+SKINNY_LINEAR = bool(int(_os.environ.get('MVIP_SKINNY_LINEAR', '1')))
 
 
 def _skinny_ok(W, X):
     return (SKINNY_LINEAR and X.is_cuda and X.dtype == torch.float32 and W.dtype == torch.float32 and W.shape[0] <= 64 and W.shape[1] <= 64
-            and X.shape[1] % 4 == 0 and X.shape[1] > 0)
+            and X.shape[1] > 0)
+
+
+def _pad_points(X, multiple):
+    """X [C, P] with P rounded up to `multiple` by zero columns (ragged last chunks only: the kernels read 16-byte quads)."""
+    pad = (-X.shape[1]) % multiple
+    return X if pad == 0 else torch.nn.functional.pad(X, (0, pad))
 
 
 def skinny_linear(W, X, relu=False, transpose=False):
     """act(W X) (or act(W^T X) with transpose) for the hash-grid model's small layers: X [N, P] channel-major,
-    csrc/skinny_gemm.hip::skinny_fwd_kernel (exact fp32, one streaming pass)."""
-    Wc, Xc = _f32c(W), _f32c(X)
+    csrc/skinny_gemm.hip::skinny_fwd_kernel / skinny_fwd16_kernel (exact fp32, one streaming pass)."""
+    Wc = _f32c(W)
+    P0 = X.shape[1]
+    Xc = _f32c(_pad_points(X, 4))
     M, N = (Wc.shape[1], Wc.shape[0]) if transpose else (Wc.shape[0], Wc.shape[1])
     P = Xc.shape[1]
     Y = torch.empty((M, P), device=Xc.device, dtype=torch.float32)
     sm, sn = (1, Wc.shape[1]) if transpose else (Wc.shape[1], 1)
     call('mvip_skinny_linear', ptr(Wc), sm, sn, ptr(Xc), M, N, P, int(bool(relu)), ptr(Y), stream())
-    return Y
+    return Y if P == P0 else Y[:, :P0].contiguous()
 
 
 class _LinearCM(torch.autograd.Function):
-    """Y [M, P] = act(W [M, N] @ X [N, P]) (channel-major activations, act = ReLU or identity).  Forward and data gradient
-    are library matmuls (or, opt-in, csrc/skinny_gemm.hip::skinny_fwd_kernel: see SKINNY_LINEAR); the weight gradient -- a
-    [M, N] result contracted over millions of points, which the BLAS library runs on a handful of workgroups -- is
-    skinny_wgrad_kernel."""
+    """Y [M, P] = act(W [M, N] @ X [N, P]) (channel-major activations, act = ReLU or identity).  Forward and data gradient:
+    csrc/skinny_gemm.hip::skinny_fwd_kernel (16-row variant for M <= 16); the weight gradient -- a [M, N] result contracted
+    over millions of points, which a BLAS library runs on a handful of workgroups -- is skinny_wgrad_kernel.  Library
+    matmuls only for layers wider than 64 (none in NeRF_TCNN) or with MVIP_SKINNY_LINEAR=0."""
 
     @staticmethod
     def forward(ctx, W, X, relu):
@@ -986,9 +995,8 @@ class _LinearCM(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dX = skinny_linear(W, dZ, False, transpose=True) if _skinny_ok(W.t(), dZ) else W.t() @ dZ
         if ctx.needs_input_grad[0]:
-            P = X.shape[1]
-            if P % 64 == 0 and P >= 4096 and W.shape[0] <= 64 and W.shape[1] <= 64:
-                dW = skinny_wgrad(dZ, X)
+            if _skinny_ok(W, X):
+                dW = skinny_wgrad(_pad_points(dZ, 64), _pad_points(X, 64))      # zero columns add nothing
             else:
                 dW = dZ @ X.t()
         return dW, dX, None

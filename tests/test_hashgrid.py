@@ -191,7 +191,8 @@ def test_skinny_linear_kernel(cuda):
     the same products in fp64; through autograd with the fused ReLU against torch's relu(W @ X)."""
     from mvip_nerf_amd import ops
     g = torch.Generator().manual_seed(7)
-    for M, Nn, P in ((64, 32, 65536), (16, 64, 8192), (64, 64, 200000), (3, 17, 4100), (16, 64, 4), (33, 64, 131076)):
+    for M, Nn, P in ((64, 32, 65536), (16, 64, 8192), (64, 64, 200000), (3, 17, 4100), (16, 64, 4), (33, 64, 131076), (16, 32, 4102),
+                     (3, 64, 65537), (12, 20, 70000)):
         W = torch.randn(M, Nn, generator=g) / Nn ** 0.5
         X = torch.randn(Nn, P, generator=g)
         for relu in (False, True):
@@ -221,6 +222,35 @@ def test_skinny_linear_kernel(cuda):
     np.testing.assert_allclose(N(y), N(yr), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(N(gw), N(W.grad), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(N(gx), N(X.grad), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_linear_cm_runs_no_library_contraction(cuda):
+    """The hash-grid model's small layers (forward, data gradient, weight gradient) launch csrc/skinny_gemm.hip kernels only --
+    also for a ragged point count (zero-padded quads / chunks) -- and agree with torch's matmuls."""
+    from mvip_nerf_amd import ops
+    assert ops.SKINNY_LINEAR, 'own kernels are the default'
+    g = torch.Generator().manual_seed(17)
+    for M, Nn, P in ((64, 32, 16384), (16, 64, 1001), (3, 64, 4099)):
+        W = (torch.randn(M, Nn, generator=g) / Nn ** 0.5).to(cuda).requires_grad_(True)
+        X = torch.randn(Nn, P, generator=g).to(cuda).requires_grad_(True)
+        dY = torch.randn(M, P, generator=g).to(cuda)
+        ops.linear_cm(W, X, relu=True).backward(dY)                       # warm-up (allocations, module load)
+        W.grad = X.grad = None
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            y = ops.linear_cm(W, X, relu=True)
+            y.backward(dY)
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages() if e.device_time_total > 0]
+        assert any('skinny_fwd' in n for n in names) and any('skinny_wgrad' in n for n in names), names
+        assert not [n for n in names if 'Cijk' in n or 'rocblas' in n.lower() or 'gemm' in n.lower()], names
+        gw, gx = W.grad.clone(), X.grad.clone()
+        W.grad = X.grad = None
+        yr = torch.relu(W @ X)
+        yr.backward(dY)
+        np.testing.assert_allclose(N(y), N(yr), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(N(gw), N(W.grad), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(N(gx), N(X.grad), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu
