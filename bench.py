@@ -727,7 +727,11 @@ def main():
                                    'to the next, as in a real contraction, the power limit holds the part at ~23 ns per 32x32x16 MFMA '
                                    'per SIMD (tools/micro/conv_loop.hip: ~1.44 GHz at 33 cycles, sustained), i.e. ~490 TFLOP/s fp32-equivalent',
                         'frac_of_sustained_f16x3_peak': round(ach / (PEAK_F16_TFLOPS / 3 * 1.67 / 2.4), 4),
-                        'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4)}
+                        'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4),
+                        # with fp16-exact weights the weight contractions (all but attention's ~3 % of the FLOPs) need TWO fp16
+                        # products for the same bits, so the stricter denominator for this step is 2500 / 2
+                        'peak_two_product': round(PEAK_F16_TFLOPS / 2, 1),
+                        'frac_of_two_product_peak': round(ach / (PEAK_F16_TFLOPS / 2), 4)}
             result['sds'] = {'steps_per_sec': args.sds_steps * world / dt_sds, 'ms_per_step': sds_ms, 'roofline': sds_roof,
                              'dtype': 'f32 tensors; every convolution, linear layer and attention product on fp16 MFMA in split precision (f16x3, ~1e-6 '
                                       'relative).  The random UNet / VAE weights are fp16-REPRESENTABLE values in fp32 containers, like the '

@@ -237,6 +237,20 @@ int mvip_sds_grad(const float *eps_uncond, const float *eps_cond, const float *n
                   float guidance_scale, float w, int64_t n, int accumulate, float *grad,
                   void *stream);
 
+/* Posterior sample of the VAE encoder and its adjoint (the pipeline's _encode_vae_image: scaling_factor *
+ * latent_dist.sample(), reached from DS_NeRF/guidance/sd_utils.py:207): moments [N][2C][HW] = (mean | logvar),
+ * noise / out / d_out [N][C][HW], d_moments [N][2C][HW];  out = sf * (mean + exp(0.5 clamp(logvar, -30, 20)) * noise).
+ * One launch each instead of the ~7 / ~15 elementwise launches of the torch expression and its autograd backward. */
+int mvip_vae_sample(const float *moments, const float *noise, float scaling_factor, int64_t N, int64_t C,
+                    int64_t HW, float *out, void *stream);
+int mvip_vae_sample_backward(const float *moments, const float *noise, const float *d_out, float scaling_factor,
+                             int64_t N, int64_t C, int64_t HW, float *d_moments, void *stream);
+
+/* Sinusoidal timestep embedding in front of the UNet's time MLP (diffusers get_timestep_embedding with
+ * flip_sin_to_cos=True; the unet(...) call of DS_NeRF/guidance/sd_utils.py:390-403): out [N][2 half] =
+ * (cos(t_n f_k) | sin(t_n f_k)), t [N] on the device (graph-replayable), freqs [half] computed once by the caller. */
+int mvip_timestep_sincos(const float *t, const float *freqs, int64_t N, int64_t half, float *out, void *stream);
+
 /* The same two kernels with the timestep-dependent scalars read from device memory
  * (scal = {sqrt(abar), sqrt(1-abar), 1-abar}), so that ONE captured hipGraph of the SDS step
  * serves every timestep. */

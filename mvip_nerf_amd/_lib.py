@@ -68,6 +68,9 @@ _SIGNATURES = {
     'mvip_sds_grad': (_int, [_c_f, _c_f, _c_f, _flt, _flt, _i64, _int, _c_f, _c_f]),
     'mvip_sds_add_noise_dev': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_sds_grad_dev': (_int, [_c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_vae_sample': (_int, [_c_f, _c_f, _flt, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_vae_sample_backward': (_int, [_c_f, _c_f, _c_f, _flt, _i64, _i64, _i64, _c_f, _c_f]),
+    'mvip_timestep_sincos': (_int, [_c_f, _c_f, _i64, _i64, _c_f, _c_f]),
     'mvip_resize_bilinear': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_resize_bilinear_backward': (_int, [_c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_groupnorm_workspace_bytes': (_i64, [_i64, _i64, _i64]),

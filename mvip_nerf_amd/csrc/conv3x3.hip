@@ -100,11 +100,13 @@ __global__ void __launch_bounds__(256) cv_absmax_scale_kernel(const float *__res
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         const int64_t n4 = n >> 2;
-        int64_t i = tid;                               // four independent 16-byte loads per thread and trip (see cv_absmax_kernel)
-        for (; i + 3 * stride < n4; i += 4 * stride) {
-            const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
-            take(a.x); take(a.y); take(a.z); take(a.w); take(b.x); take(b.y); take(b.z); take(b.w);
-            take(c.x); take(c.y); take(c.z); take(c.w); take(d.x); take(d.y); take(d.z); take(d.w);
+        int64_t i = tid;                               // eight independent 16-byte loads per thread and trip: these launches are
+        for (; i + 7 * stride < n4; i += 8 * stride) { // latency-bound (a trip is one memory round trip), see absmax_blocks
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { take(v[u].x); take(v[u].y); take(v[u].z); take(v[u].w); }
         }
         for (; i < n4; i += stride) { const float4 v = x4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
         for (int64_t k = (n4 << 2) + tid; k < n; k += stride) take(x[k]);
@@ -140,7 +142,21 @@ __global__ void __launch_bounds__(256) cv_absmax_scale_kernel(const float *__res
 // one workgroup per 64 K elements, at most one per CU: every workgroup ends with two atomics on the same pair of words,
 // which serialise in L2 (512 workgroups: 1.54 ms over the 94 calls of an SDS step, 256: see profiles)
 static inline unsigned absmax_blocks(int64_t n) {
-    int64_t b = (n + 256 * 256 - 1) / (256 * 256);
+    // Small tensors are latency-bound (a trip of a thread's loop is one memory round trip, a workgroup's two atomics serialise
+    // in L2): 64 floats per thread on at most 64 workgroups; large ones are bandwidth-bound: 64 K floats per workgroup on at
+    // most 256.  Per launch inside a graph replay (tools/absmax_sweep.py, profiles/r4_absmax_sweep.json): 0.16 M floats 6.2 ->
+    // 3.7 us, 0.66 M 6.5 -> 4.1, 2.6 M 6.7 -> 5.9, 33 M 25.2 (unchanged).  MVIP_ABSMAX_FPT / MVIP_ABSMAX_MAXB override (tuning).
+    const char *ef = getenv("MVIP_ABSMAX_FPT"), *eb = getenv("MVIP_ABSMAX_MAXB");
+    if (ef || eb) {
+        const int64_t fpt = ef ? atoi(ef) : 256, maxb = eb ? atoi(eb) : 256;
+        const int64_t b = (n + 256 * fpt - 1) / (256 * fpt);
+        return (unsigned)(b < 1 ? 1 : (b > maxb ? maxb : b));
+    }
+    int64_t b = (n + 256 * 64 - 1) / (256 * 64);
+    if (b > 64) {
+        const int64_t big = (n + 256 * 256 - 1) / (256 * 256);
+        b = big > 64 ? big : 64;
+    }
     return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
@@ -1862,8 +1878,9 @@ extern "C" int mvip_gemm_pack_a(const float *src, int64_t M, int64_t K, int64_t 
     hipStream_t st = as_stream(stream);
     char *tail = (char *)packed + M * K * 4;
     zero_words(tail, 64, st);
-    hipLaunchKernelGGL(cv_absmax_kernel, dim3(absmax_blocks(M * K)), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 8));
-    hipLaunchKernelGGL(cv_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned *)(tail + 8), (float *)tail);
+    // maximum + scale in one launch: its two scratch words (tail + 16, + 20) are zero on entry and left zero
+    hipLaunchKernelGGL(cv_absmax_scale_kernel, dim3(absmax_blocks(M * K)), dim3(256), 0, st, src, M * K, (unsigned *)(tail + 16),
+                       (float *)tail);
     const int64_t total = (M / 32) * (K / 16) * 2 * 64;
     hipLaunchKernelGGL(gm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, (int)M, (int)K, sm,
                        sk, (const float *)tail, (uint4 *)packed, (unsigned *)(tail + 12));

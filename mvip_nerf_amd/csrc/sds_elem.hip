@@ -52,6 +52,50 @@ __global__ void sds_grad_dev_kernel(const float *__restrict__ eu, const float *_
     grad[i] = nan_to_num(g);
 }
 
+// ---- posterior sample of the VAE encoder (pipeline _encode_vae_image: scaling_factor * latent_dist.sample(),
+// DS_NeRF/guidance/sd_utils.py:207 through the inpainting pipeline) and its adjoint, one launch each instead of the seven
+// (forward) / fifteen (autograd backward: clamp mask, exp, products, the zero-filled halves of chunk's cat) elementwise
+// launches:  moments [N][2C][HW] = (mean | logvar);  lv = clamp(logvar, -30, 20);  std = exp(0.5 lv);
+//   out = sf * (mean + std * noise)            d_mean = sf g,   d_logvar = 0.5 (sf g noise) std inside the clamp, else 0
+__global__ void vae_sample_kernel(const float *__restrict__ moments, const float *__restrict__ noise, float sf, int64_t n,
+                                  int64_t chw, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / chw, r = i - b * chw;
+    const float mean = moments[b * 2 * chw + r];
+    float lv = moments[b * 2 * chw + chw + r];
+    lv = fminf(fmaxf(lv, -30.f), 20.f);
+    const float sd = expf(0.5f * lv);
+    out[i] = __fmul_rn(sf, __fadd_rn(mean, __fmul_rn(sd, noise[i])));       // torch's three roundings (no fused multiply-add)
+}
+
+__global__ void vae_sample_bwd_kernel(const float *__restrict__ moments, const float *__restrict__ noise,
+                                      const float *__restrict__ g, float sf, int64_t n, int64_t chw,
+                                      float *__restrict__ d_moments) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / chw, r = i - b * chw;
+    const float lv = moments[b * 2 * chw + chw + r];
+    const bool inside = lv >= -30.f && lv <= 20.f;
+    const float sd = expf(0.5f * fminf(fmaxf(lv, -30.f), 20.f));
+    const float gs = __fmul_rn(g[i], sf);
+    d_moments[b * 2 * chw + r] = gs;
+    d_moments[b * 2 * chw + chw + r] = inside ? __fmul_rn(__fmul_rn(__fmul_rn(gs, noise[i]), sd), 0.5f) : 0.f;
+}
+
+// ---- sinusoidal timestep embedding (diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0) in
+// front of the UNet's time MLP): out[n] = (cos(t_n f_k) | sin(t_n f_k)) for the half = dim / 2 frequencies f (computed
+// once by the caller), one launch instead of product + cos + sin + cat
+__global__ void timestep_sincos_kernel(const float *__restrict__ t, const float *__restrict__ freqs, int N, int half,
+                                       float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half) return;
+    const int n = i / half, k = i - n * half;
+    const float a = __fmul_rn(t[n], freqs[k]);
+    out[(int64_t)n * 2 * half + k] = cosf(a);
+    out[(int64_t)n * 2 * half + half + k] = sinf(a);
+}
+
 // ---- bilinear resize, align_corners = False (the F.interpolate in front of vae.encode, DS_NeRF/guidance/sd_utils.py:282-284)
 // torch's convention: scale = in / out (float), src = scale * (dst + 0.5) - 0.5 clamped at 0, i0 = (int)src,
 // i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1.
@@ -170,6 +214,38 @@ extern "C" int mvip_sds_grad_dev(const float *eps_uncond, const float *eps_cond,
     if (n == 0) return MVIP_OK;
     hipLaunchKernelGGL(sds_grad_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                        eps_uncond, eps_cond, noise, guidance_scale, scal, n, accumulate, grad);
+    return check_launch();
+}
+
+
+extern "C" int mvip_vae_sample(const float *moments, const float *noise, float scaling_factor, int64_t N, int64_t C,
+                               int64_t HW, float *out, void *stream) {
+    if (N < 0 || C <= 0 || HW < 0) return MVIP_EINVAL;
+    const int64_t n = N * C * HW;
+    if (n == 0) return MVIP_OK;
+    if (!moments || !noise || !out) return MVIP_EINVAL;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), moments, noise,
+                       scaling_factor, n, C * HW, out);
+    return check_launch();
+}
+
+extern "C" int mvip_vae_sample_backward(const float *moments, const float *noise, const float *d_out, float scaling_factor,
+                                        int64_t N, int64_t C, int64_t HW, float *d_moments, void *stream) {
+    if (N < 0 || C <= 0 || HW < 0) return MVIP_EINVAL;
+    const int64_t n = N * C * HW;
+    if (n == 0) return MVIP_OK;
+    if (!moments || !noise || !d_out || !d_moments) return MVIP_EINVAL;
+    hipLaunchKernelGGL(vae_sample_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), moments, noise,
+                       d_out, scaling_factor, n, C * HW, d_moments);
+    return check_launch();
+}
+
+extern "C" int mvip_timestep_sincos(const float *t, const float *freqs, int64_t N, int64_t half, float *out, void *stream) {
+    if (N < 0 || half <= 0 || N * half > (1 << 30)) return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!t || !freqs || !out) return MVIP_EINVAL;
+    hipLaunchKernelGGL(timestep_sincos_kernel, dim3((unsigned)((N * half + 255) / 256)), dim3(256), 0, as_stream(stream), t, freqs,
+                       (int)N, (int)half, out);
     return check_launch();
 }
 

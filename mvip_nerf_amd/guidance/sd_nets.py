@@ -280,10 +280,24 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+_FREQS = {}
+
+
 def timestep_sinusoid(t, dim):
-    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0).  The frequencies depend on `dim` only and
+    are computed once per device; on the device the product, cosine, sine and concatenation are one launch
+    (csrc/sds_elem.hip::timestep_sincos_kernel) instead of nine tiny ones per step."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    key = (half, t.device)
+    if key not in _FREQS:
+        _FREQS[key] = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    freqs = _FREQS[key]
+    if t.is_cuda and t.dim() == 1:
+        from .._lib import call, ptr, stream
+        tc = t.float().contiguous()
+        out = torch.empty((tc.shape[0], 2 * half), device=t.device, dtype=torch.float32)
+        call('mvip_timestep_sincos', ptr(tc), ptr(freqs), tc.shape[0], half, ptr(out), stream())
+        return out
     args = t[:, None].float() * freqs[None]
     return torch.cat([torch.cos(args), torch.sin(args)], -1)
 
@@ -442,10 +456,55 @@ class Decoder(nn.Module):
 
 
 class LatentDist:
+    """diffusers' DiagonalGaussianDistribution: mean / logvar / std of the encoder's moments, formed on first use (the SDS step
+    never reads them: it draws its sample through `scaled_sample`, one launch)."""
+
     def __init__(self, moments):
-        self.mean, logvar = torch.chunk(moments, 2, dim=1)
-        self.logvar = torch.clamp(logvar, -30.0, 20.0)
-        self.std = torch.exp(0.5 * self.logvar)
+        self.moments = moments
+
+    @property
+    def mean(self):
+        return torch.chunk(self.moments, 2, dim=1)[0]
+
+    @property
+    def logvar(self):
+        return torch.clamp(torch.chunk(self.moments, 2, dim=1)[1], -30.0, 20.0)
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
+
+    def scaled_sample(self, noise, scaling_factor):
+        """scaling_factor * (mean + std * noise) (the pipeline's _encode_vae_image), with autograd to the moments."""
+        m = self.moments
+        if m.is_cuda and m.dtype == torch.float32 and noise.dtype == torch.float32 and m.dim() == 4:
+            return _VaeSample.apply(m, noise, float(scaling_factor))
+        return scaling_factor * (self.mean + self.std * noise)
+
+
+class _VaeSample(torch.autograd.Function):
+    """csrc/sds_elem.hip::vae_sample_kernel / vae_sample_bwd_kernel."""
+
+    @staticmethod
+    def forward(ctx, moments, noise, sf):
+        from .._lib import call, ptr, stream
+        mc, nc = moments.contiguous(), noise.contiguous()
+        N, C2, H, W = mc.shape
+        out = torch.empty((N, C2 // 2, H, W), device=mc.device, dtype=torch.float32)
+        call('mvip_vae_sample', ptr(mc), ptr(nc), sf, N, C2 // 2, H * W, ptr(out), stream())
+        ctx.save_for_backward(mc, nc)
+        ctx.sf = sf
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .._lib import call, ptr, stream
+        mc, nc = ctx.saved_tensors
+        N, C2, H, W = mc.shape
+        gc = g.contiguous().float()
+        dm = torch.empty_like(mc)
+        call('mvip_vae_sample_backward', ptr(mc), ptr(nc), ptr(gc), ctx.sf, N, C2 // 2, H * W, ptr(dm), stream())
+        return dm, None, None
 
 
 class _EncOut:

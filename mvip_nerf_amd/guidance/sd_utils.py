@@ -260,6 +260,9 @@ class StableDiffusion(nn.Module):
     def _encode_vae_image(self, image):
         """pipeline _encode_vae_image: scaling_factor * posterior.sample()."""
         d = self.vae.encode(image.to(self.precision_t)).latent_dist
+        if hasattr(d, 'scaled_sample'):                      # the built-in networks: one launch (and one in the backward)
+            n, c2, h, w = d.moments.shape
+            return d.scaled_sample(self._randn((n, c2 // 2, h, w), d.moments.dtype), self.scaling_factor)
         return self.scaling_factor * (d.mean + d.std * self._randn(d.mean.shape, d.mean.dtype))
 
     def _timestep(self, frac):

@@ -937,7 +937,8 @@ def skinny_wgrad(dY, X):
 
 
 # Forward / data gradient of the hash-grid model's small layers run on skinny_fwd_kernel / skinny_fwd16_kernel (default since
-# round 4; MVIP_SKINNY_LINEAR=0 puts torch matmuls back as the A/B alternative).  Measured on the training iteration
+# round 4; MVIP_SKINNY_LINEAR=0 puts torch matmuls back for these two products as the A/B alternative; the weight gradient
+# is skinny_wgrad_kernel either way).  Measured on the training iteration
 # (tools/hashgrid_train_profile.py, same box, alternating) in round 3 with 32-row tiles only: 15.6 ms with the kernel, 15.2 ms
 # with the library, whose 16-row MFMA tiles did half the matrix work on the 16-row layers -- those layers now have a 16-row
 # kernel of their own.
@@ -995,7 +996,7 @@ class _LinearCM(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dX = skinny_linear(W, dZ, False, transpose=True) if _skinny_ok(W.t(), dZ) else W.t() @ dZ
         if ctx.needs_input_grad[0]:
-            if _skinny_ok(W, X):
+            if X.is_cuda and X.dtype == torch.float32 and W.shape[0] <= 64 and W.shape[1] <= 64 and X.shape[1] > 0:
                 dW = skinny_wgrad(_pad_points(dZ, 64), _pad_points(X, 64))      # zero columns add nothing
             else:
                 dW = dZ @ X.t()
@@ -1064,6 +1065,17 @@ def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, 
 # default keeps the measured scale, which is magnitude-invariant.
 FORWARD_UNIT_SCALE = False         # opt-in (34.5 vs 35.x ms per SDS step): see the comment above for what it gives up
 _UNIT = {}
+
+
+_PROB = {}
+
+
+def prob_scale(device):
+    """scale2 = {2^9, 2^-9} for softmax probabilities (values in [0, 1]: the bound IS the scale, no pass over the [L, L] matrix
+    for its maximum; a flat row's 1/L = 2^-12 still splits into normal fp16 hi + lo terms at this scale)."""
+    if device not in _PROB:
+        _PROB[device] = torch.tensor([512.0, 1.0 / 512.0, 0.0, 0.0], device=device, dtype=_F32)
+    return _PROB[device]
 
 
 def unit_scale(device):
@@ -1140,7 +1152,8 @@ class _VAEAttention(torch.autograd.Function):
             S = gemm_f16x3(ks, gemm_pack_a(q, L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]        # S[i][j] = q_i . k_j
             Pm = softmax_rows(S, C ** -0.5)
             del S
-            pts, s2 = _scaled_planes(Pm, 1, L, L, 0, 1, L, forward_activation=_prec() == 1)   # X[k=j][p=i] = P[i][j]
+            s2 = unit_scale(dev) if _prec() == 1 else prob_scale(dev)
+            pts = split_planes_strided(Pm, 1, L, L, 0, 1, L, s2)                              # X[k=j][p=i] = P[i][j]
             O[n] = gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]
             probs.append(Pm)
         os_, s2 = _scaled_planes(O, N, C, L, C * L, L, 1, forward_activation=_prec() == 1)
@@ -1163,7 +1176,8 @@ class _VAEAttention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         for n in range(N):
             q, k, v, Pm = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:], probs[n]
-            ps, s2 = _scaled_planes(Pm, 1, L, L, 0, L, 1)                                      # X[k=i][p=j] = P[i][j]
+            s2 = prob_scale(dev)
+            ps = split_planes_strided(Pm, 1, L, L, 0, L, 1, s2)                                # X[k=i][p=j] = P[i][j]
             dqkv[n, 2 * C:] = gemm_f16x3(ps, gemm_pack_a(dO[n], C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]      # dV
             vs, s2 = _scaled_planes(v, 1, C, L, 0, L, 1)
             dP = gemm_f16x3(vs, gemm_pack_a(dO[n], L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]    # dP[i][j] = dO_i . v_j

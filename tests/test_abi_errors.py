@@ -28,6 +28,10 @@ CASES = [
     # SDS operand producers and contractions (rows a14-a16)
     ('mvip_resize_bilinear', (P0, 3, 0, 8, 16, 16, P0, P0), (P0, 0, 8, 8, 16, 16, P0, P0), (P0, 3, 8, 8, 16, 16, P0, P0)),
     ('mvip_absmax_scale', (P0, -1, P0, P0, P0), None, (P0, 16, P0, P0, P0)),
+    ('mvip_vae_sample', (P0, P0, 0.18215, 1, 0, 64, P0, P0), (P0, P0, 0.18215, 0, 4, 64, P0, P0), (P0, P0, 0.18215, 1, 4, 64, P0, P0)),
+    ('mvip_vae_sample_backward', (P0, P0, P0, 0.18215, -1, 4, 64, P0, P0), (P0, P0, P0, 0.18215, 1, 4, 0, P0, P0),
+     (P0, P0, P0, 0.18215, 1, 4, 64, P0, P0)),
+    ('mvip_timestep_sincos', (P0, P0, 1, 0, P0, P0), (P0, P0, 0, 160, P0, P0), (P0, P0, 2, 160, P0, P0)),
     ('mvip_split_planes', (P0, 1, 24, 64, P0, P0, 0, P0), (P0, 0, 32, 64, P0, P0, 0, P0), (P0, 1, 32, 64, P0, P0, 0, P0)),
     ('mvip_split_planes', (P0, 1, 32, 64, P0, P0, 3, P0), None, (P0, 1, 32, 64, P0, P0, 2, P0)),     # prec is 0 (f16x3), 1 (fp16 mode) or 2 (= 0 for a producer)
     ('mvip_packed_weights_two_product', (P0, 0, None, P0), None, (P0, 1024, None, P0)),

@@ -208,3 +208,29 @@ def test_sharded_frame_render_equals_whole_frame(tmp_path, cuda, world):
         for got, want in zip(p['maps'], whole):
             assert got.shape == want.shape
             assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.slow
+def test_bench_two_ranks_on_one_device_reports_strong_scaling(cuda):
+    """`bench.py --gpus 2` end to end on the GPU box: it starts its own two ranks (both on GPU 0 over gloo,
+    MVIP_BENCH_SINGLE_DEVICE=1 -- the boxes have one GPU), renders the frame in two ray blocks joined by one all_gather, runs
+    the sharded training legs, and prints ONE line whose `value` is the strong-scaling figure with the weak one beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVIP_BENCH_SINGLE_DEVICE='1', MVIP_GRAPHS_WITH_DIST='1', MASTER_ADDR='127.0.0.1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--train-steps', '1',
+                        '--sds-steps', '1', '--no-hashgrid', '--no-cpu-baseline'], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 1
+    assert d['value'] > 0 and d['weak_rays_per_sec'] > 0 and d['value_1_same_run'] > 0
+    assert 0 < d['strong_efficiency'] < 1.5
+    assert d['multi_gpu']['rccl_world'] == 2
+    assert d['metric'].startswith('rays_per_sec') and d['unit'] == 'rays/s'

@@ -1037,3 +1037,38 @@ def test_two_product_step_equals_three_product_step(cuda):
     nets = SDNetworks(cuda, torch.float32, fp16_weights=False)
     conv = nets.vae.encoder.down_blocks[0].resnets[0].conv1
     assert ops._conv_packed(conv, False)._mvip_two_product is False
+
+
+@pytest.mark.gpu
+def test_posterior_sample_and_timestep_embedding_kernels(cuda):
+    """csrc/sds_elem.hip: the one-launch posterior sample sf * (mean + exp(0.5 clamp(logvar)) * noise) with its adjoint, and the
+    one-launch sinusoidal timestep embedding, against the torch expressions they replace (values AND gradients; logvar values
+    beyond both clamp bounds included)."""
+    from mvip_nerf_amd.guidance import sd_nets
+    g = torch.Generator().manual_seed(21)
+    m = torch.randn(2, 8, 16, 24, generator=g)
+    m[0, 5, 0, :4] = torch.tensor([-31.0, 25.0, -30.0, 20.0])               # outside / on the clamp bounds
+    noise = torch.randn(2, 4, 16, 24, generator=g)
+    gout = torch.randn(2, 4, 16, 24, generator=g)
+    md = m.to(cuda).requires_grad_(True)
+    out = sd_nets.LatentDist(md).scaled_sample(noise.to(cuda), 0.18215)
+    out.backward(gout.to(cuda))
+    mr = m.clone().requires_grad_(True)
+    mean, logvar = torch.chunk(mr, 2, dim=1)
+    ref = 0.18215 * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
+    ref.backward(gout)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(md.grad.cpu().numpy(), mr.grad.numpy(), rtol=2e-6, atol=1e-9)
+    assert float(md.grad[0, 5, 0, 0]) == 0.0 and float(md.grad[0, 5, 0, 1]) == 0.0       # clamped: no gradient to logvar
+    # the lazily formed properties are diffusers' DiagonalGaussianDistribution fields
+    d = sd_nets.LatentDist(m)
+    assert torch.equal(d.mean, m[:, :4]) and torch.equal(d.std, torch.exp(0.5 * torch.clamp(m[:, 4:], -30.0, 20.0)))
+    # timestep embedding: device kernel vs the host expression, integer and fractional timesteps
+    for t in (torch.tensor([980.0, 20.0]), torch.tensor([501.25])):
+        got = sd_nets.timestep_sinusoid(t.to(cuda), 320)
+        half = 160
+        freqs = torch.exp(-np.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs[None]
+        ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+        assert got.shape == (t.shape[0], 320)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)   # |args| <= 980: sin / cos to ~1e-7 of 1, argument rounding 6e-5 * 2^-24
