@@ -99,13 +99,13 @@ class _AddNoiseDev(torch.autograd.Function):
         return g * scal[0], None, None
 
 
-def sds_grad_dev(eps_uncond, eps_cond, noise, guidance_scale, scal):
+def sds_grad_dev(eps_uncond, eps_cond, noise, guidance_scale, scal, accumulate_into=None):
     eu = eps_uncond.contiguous().float()
     ec = None if eps_cond is None else eps_cond.contiguous().float()
     nz = noise.contiguous().float()
-    out = torch.empty_like(eu)
-    call('mvip_sds_grad_dev', ptr(eu), ptr(ec), ptr(nz), float(guidance_scale), ptr(scal), eu.numel(), 0, ptr(out),
-         stream())
+    out = accumulate_into if accumulate_into is not None else torch.empty_like(eu)
+    call('mvip_sds_grad_dev', ptr(eu), ptr(ec), ptr(nz), float(guidance_scale), ptr(scal), eu.numel(),
+         int(accumulate_into is not None), ptr(out), stream())
     return out
 
 
@@ -129,11 +129,16 @@ class _GraphedStep:
     SDS gradient, and the backward through the VAE encoder to the image -- captured once as a hipGraph.
     ~1400 kernel launches per step otherwise leave the GPU idle a third of the time (profiles/)."""
 
-    def __init__(self, sd, pred_shape, mask_shape, prompt, guidance_scale):
-        self.sd, self.prompt, self.gs = sd, prompt, guidance_scale
+    def __init__(self, sd, pred_shape, mask_shape, prompt, guidance_scale, mode='single'):
+        """mode: 'single' = train_step_sd / train_step_sd_normal; 'share' = a non-final neighbour view of
+        train_step_colla_sds (forward only: its w (eps_hat - eps) is ADDED to the running latent gradient `acc`, nothing
+        flows back to the image, DS_NeRF/guidance/sd_utils.py:575); 'last' = the final neighbour view (its share joins `acc`
+        and the sum is injected through SpecifyGradient with the CFG-duplicated mask, :597-599)."""
+        self.sd, self.prompt, self.gs, self.mode = sd, prompt, guidance_scale, mode
         dev = sd.device
-        self.pred = torch.zeros(pred_shape, device=dev, requires_grad=True)
+        self.pred = torch.zeros(pred_shape, device=dev, requires_grad=mode != 'share')
         self.mask = torch.zeros(mask_shape, device=dev)
+        self.acc = torch.zeros(1, 4, 64, 64, device=dev) if mode != 'single' else None
         self.scal = torch.zeros(4, device=dev)                  # sqrt(abar), sqrt(1-abar), 1-abar, t
         sd.networks.encode_prompt(prompt, guidance_scale > 1.0)    # cached constant, outside the capture
         # Warm-up and capture run the body three times and DRAW each time; an eager step draws once.  The generator's state
@@ -167,21 +172,30 @@ class _GraphedStep:
 
     def _body(self):
         sd = self.sd
-        init_image, mask64, masked_latents, emb, cfg = sd._prepare(self.pred, self.mask, self.prompt, self.gs)
-        image_latents = sd._encode_vae_image(init_image)
-        noise = sd._randn(image_latents.shape, image_latents.dtype)
-        latents = _AddNoiseDev.apply(image_latents, noise, self.scal)
+        with torch.set_grad_enabled(self.mode != 'share'):
+            init_image, mask64, masked_latents, emb, cfg = sd._prepare(self.pred, self.mask, self.prompt, self.gs)
+            image_latents = sd._encode_vae_image(init_image)
+            noise = sd._randn(image_latents.shape, image_latents.dtype)
+            latents = _AddNoiseDev.apply(image_latents, noise, self.scal)
         with torch.no_grad():
             x = torch.cat([latents] * 2) if cfg else latents
             x = torch.cat([x, mask64, masked_latents], dim=1)
             eps = sd.unet(x.to(sd.precision_t), self.scal[3:4], encoder_hidden_states=emb,
                           cross_attention_kwargs=None, return_dict=False)[0]
             e_u, e_c = eps.chunk(2) if cfg else (eps, None)
-            grad = sds_grad_dev(e_u, e_c, noise, self.gs, self.scal)
-        (d_pred,) = torch.autograd.grad(latents, self.pred, grad_outputs=grad * mask64[0, :, :, :])
+            grad = sds_grad_dev(e_u, e_c, noise, self.gs, self.scal, accumulate_into=self.acc)
+            if self.mode == 'share':
+                return None
+            if self.mode == 'single':
+                inject = grad * mask64[0, :, :, :]
+            else:       # SpecifyGradient is handed the CFG-duplicated [2, 1, 64, 64] mask whole: autograd sums the two copies
+                inject = (grad * mask64).sum(0, keepdim=True)
+        (d_pred,) = torch.autograd.grad(latents, self.pred, grad_outputs=inject)
         return d_pred
 
-    def run(self, pred, mask, t):
+    def run(self, pred, mask, t, acc=None):
+        """Replays the step for this image / mask / timestep.  'single': d step / d pred.  'share': the updated running latent
+        gradient.  'last': (d step / d pred, updated running latent gradient)."""
         abar = self.sd._alphas_host[t]
         # scalars travel as kernel arguments of four fill launches: an asynchronous copy from a temporary host
         # tensor can execute after that tensor's memory has been reused (seen as sporadic garbage timesteps)
@@ -189,8 +203,14 @@ class _GraphedStep:
             self.scal[k].fill_(v)
         self.pred.data.copy_(pred.detach())
         self.mask.copy_(mask)
+        if self.acc is not None:
+            self.acc.copy_(acc.reshape(1, 4, 64, 64))
         self.graph.replay()
-        return self.d_pred.clone()
+        if self.mode == 'single':
+            return self.d_pred.clone()
+        if self.mode == 'share':
+            return self.acc.clone()
+        return self.d_pred.clone(), self.acc.clone()
 
 
 def seed_everything(seed):
@@ -309,11 +329,14 @@ class StableDiffusion(nn.Module):
             grad = sds_grad(e_u, e_c, noise, guidance_scale, 1.0 - abar, accumulate_into)
         return latents, grad
 
-    def _graphed(self, t, mask, prompt, pred, guidance_scale):
-        key = (tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale), id(self.generator))
+    def _graph_for(self, mode, mask, prompt, pred, guidance_scale):
+        key = (mode, tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale), id(self.generator))
         if key not in self._graphs:
-            self._graphs[key] = _GraphedStep(self, pred.shape, mask.shape, prompt, guidance_scale)
-        d_pred = self._graphs[key].run(pred, mask, t)
+            self._graphs[key] = _GraphedStep(self, pred.shape, mask.shape, prompt, guidance_scale, mode)
+        return self._graphs[key]
+
+    def _graphed(self, t, mask, prompt, pred, guidance_scale):
+        d_pred = self._graph_for('single', mask, prompt, pred, guidance_scale).run(pred, mask, t)
         return _InjectGrad.apply(pred, d_pred)
 
     # -- the three step methods ---------------------------------------------------------------------
@@ -348,10 +371,24 @@ class StableDiffusion(nn.Module):
         grad = torch.zeros(1, 4, 64, 64, device=self.device)
         loss = None
         for k in range(NN):
-            prep = self._prepare(pred_rgb_nn[k].unsqueeze(0), mask_nn[k].unsqueeze(0), prompt, guidance_scale)
+            pred_k, mask_k = pred_rgb_nn[k].unsqueeze(0), mask_nn[k].unsqueeze(0)
             t = self._timestep(k / 10000)
-            latents, grad = self._noise_and_predict(*prep, t, guidance_scale, accumulate_into=grad)
-            loss = SpecifyGradient.apply(latents, grad.clone(), prep[1])
+            last = k == NN - 1
+            if self.use_graphs:
+                g = self._graph_for('last' if last else 'share', mask_k, prompt, pred_k, guidance_scale)
+                if last:
+                    d_pred, grad = g.run(pred_k, mask_k, t, grad)
+                    loss = _InjectGrad.apply(pred_k, d_pred)
+                else:
+                    grad = g.run(pred_k, mask_k, t, grad)
+                continue
+            # `loss` of a non-final view is overwritten before anything reads it, so no gradient ever flows through that view:
+            # it runs without an autograd graph (same draws, same values; no saved activations)
+            with torch.set_grad_enabled(last and torch.is_grad_enabled()):
+                prep = self._prepare(pred_k, mask_k, prompt, guidance_scale)
+                latents, grad = self._noise_and_predict(*prep, t, guidance_scale, accumulate_into=grad)
+            if last:
+                loss = SpecifyGradient.apply(latents, grad.clone(), prep[1])
         return loss
 
     # `train_step` exists by name only in the reference's unused guidance/sd.py (:162, :988)
@@ -382,6 +419,9 @@ class StableDiffusion(nn.Module):
         gradient (DS_NeRF/guidance/sd_utils.py:575), forward only; t comes from the VIEW index as in the reference."""
         if seed is not None:
             self.seed_generator(seed)
+        if self.use_graphs:
+            g = self._graph_for('share', mask_k, prompt, pred_k, guidance_scale)
+            return g.run(pred_k, mask_k, self._timestep(k / 10000), torch.zeros(1, 4, 64, 64, device=self.device))
         with torch.no_grad():
             prep = self._prepare(pred_k.detach(), mask_k, prompt, guidance_scale)
             _, grad = self._noise_and_predict(*prep, self._timestep(k / 10000), guidance_scale)
@@ -393,6 +433,10 @@ class StableDiffusion(nn.Module):
         the reference does (sd_utils.py:597-599); returns weight * d term / d pred_k."""
         if seed is not None:
             self.seed_generator(seed)
+        if self.use_graphs:
+            g = self._graph_for('last', mask_k, prompt, pred_k, guidance_scale)
+            d_pred, _ = g.run(pred_k, mask_k, self._timestep(k / 10000), share_sum.detach().float())
+            return weight * d_pred
         x = pred_k.detach().clone().requires_grad_(True)
         with torch.enable_grad():
             prep = self._prepare(x, mask_k, prompt, guidance_scale)

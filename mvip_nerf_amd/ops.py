@@ -1043,9 +1043,14 @@ def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
 GEMM_CFG = 0       # 0: tile chosen by shape; 1..4 force a workgroup tile (A/B timing switch, see include/mvip_nerf.h)
 
 
-def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None):
-    """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P]."""
-    y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
+def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None, out=None):
+    """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P].
+    out: a contiguous fp32 tensor of N * M * P elements to write instead of a new one (e.g. a slice of a larger result)."""
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == N * M * P
+        y = out
+    else:
+        y = torch.empty((N, M, P), device=xs.device, dtype=torch.float32)
     if GEMM_CFG:
         call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
              ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), _prec_w(packed), stream())
@@ -1154,7 +1159,7 @@ class _VAEAttention(torch.autograd.Function):
             del S
             s2 = unit_scale(dev) if _prec() == 1 else prob_scale(dev)
             pts = split_planes_strided(Pm, 1, L, L, 0, 1, L, s2)                              # X[k=j][p=i] = P[i][j]
-            O[n] = gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]
+            gemm_f16x3(pts, gemm_pack_a(v, C, L, L, 1), 1, L, C, L, x_scale2=s2, out=O[n])
             probs.append(Pm)
         os_, s2 = _scaled_planes(O, N, C, L, C * L, L, 1, forward_activation=_prec() == 1)
         out = gemm_f16x3(os_, wts['o'], N, C, C, L, bias=wts['bo'], residual=xc.reshape(N, C, L), x_scale2=s2)
@@ -1178,23 +1183,26 @@ class _VAEAttention(torch.autograd.Function):
             q, k, v, Pm = qkv[n, :C], qkv[n, C:2 * C], qkv[n, 2 * C:], probs[n]
             s2 = prob_scale(dev)
             ps = split_planes_strided(Pm, 1, L, L, 0, L, 1, s2)                                # X[k=i][p=j] = P[i][j]
-            dqkv[n, 2 * C:] = gemm_f16x3(ps, gemm_pack_a(dO[n], C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]      # dV
+            gemm_f16x3(ps, gemm_pack_a(dO[n], C, L, L, 1), 1, L, C, L, x_scale2=s2, out=dqkv[n, 2 * C:])        # dV
             vs, s2 = _scaled_planes(v, 1, C, L, 0, L, 1)
             dP = gemm_f16x3(vs, gemm_pack_a(dO[n], L, C, 1, L), 1, C, L, L, x_scale2=s2)[0]    # dP[i][j] = dO_i . v_j
             dS = softmax_rows_backward(Pm, dP, C ** -0.5)
             del dP
             s2 = absmax_scale(dS)
             dst = split_planes_strided(dS, 1, L, L, 0, 1, L, s2)                               # X[k=j][p=i] = dS[i][j]
-            dqkv[n, :C] = gemm_f16x3(dst, gemm_pack_a(k, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]             # dQ
+            gemm_f16x3(dst, gemm_pack_a(k, C, L, L, 1), 1, L, C, L, x_scale2=s2, out=dqkv[n, :C])               # dQ
             dsn = split_planes_strided(dS, 1, L, L, 0, L, 1, s2)                               # X[k=i][p=j] = dS[i][j]
-            dqkv[n, C:2 * C] = gemm_f16x3(dsn, gemm_pack_a(q, C, L, L, 1), 1, L, C, L, x_scale2=s2)[0]        # dK
+            gemm_f16x3(dsn, gemm_pack_a(q, C, L, L, 1), 1, L, C, L, x_scale2=s2, out=dqkv[n, C:2 * C])          # dK
         dqs, s2 = _scaled_planes(dqkv, N, 3 * C, L, 3 * C * L, L, 1)
         dh = gemm_f16x3(dqs, wts['qkv_t'], N, 3 * C, C, L, x_scale2=s2)                         # Wqkv^T dqkv
         dx = torch.empty_like(xc)
         ws = _gn_workspace(N, C, L, dev)
-        call('mvip_groupnorm_backward', ptr(xc), ptr(dh.reshape(N, C, H, W)), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N,
-             C, L, norm.num_groups, 0, 0, ptr(dx), ptr(ws, torch.float64), stream())
-        return dx + d.reshape(N, C, H, W), None
+        # + the gradient arriving over the block's residual connection, and the maxima of the sum for the next backward's scale
+        maxima = torch.empty(int(_lib.load().mvip_groupnorm_backward_maxima(N, C, L)), device=dev, dtype=torch.float32)
+        call('mvip_groupnorm_backward_fused', ptr(xc), ptr(dh.reshape(N, C, H, W)), ptr(gw), ptr(gb), ptr(mean), ptr(rstd), N,
+             C, L, norm.num_groups, 0, 0, ptr(d), ptr(dx), ptr(maxima), ptr(ws, torch.float64), stream())
+        _LAST_DX[0] = (dx, dx._version, maxima)
+        return dx, None
 
 
 def vae_attention(x, mod):

@@ -646,6 +646,45 @@ def test_graphed_full_size_step_is_replay_stable(cuda):
         assert float((w - z).norm() / z.norm()) < 1e-4
 
 
+def test_graphed_colla_step_equals_eager(cuda):
+    """train_step_colla_sds as hipGraph replays (non-final views: forward-only 'share' graphs adding to the running latent
+    gradient; final view: the 'last' graph that also carries the backward to the image, with the CFG-duplicated mask summed as
+    SpecifyGradient's autograd does) against the eager method, same draws: the gradient of the stacked neighbour views is zero for
+    every view but the last and equal there; also the sharded entry points colla_view_share / colla_last_view_image_grad."""
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False, use_graphs=True)
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    NN, H, W = 3, 96, 128
+    preds = torch.rand(NN, 3, H, W, device=cuda, generator=gen)
+    masks = torch.zeros(NN, 1, H, W, device=cuda)
+    masks[:, :, 30:70, 40:100] = 1
+    out = {}
+    for graphs in (True, False, True):
+        sd.use_graphs = graphs
+        torch.cuda.manual_seed(123)
+        x = preds.clone().requires_grad_(True)
+        loss = sd.train_step_colla_sds(0, masks, 'a stone bench in a park', x, guidance_scale=7.5)
+        (1e-4 * loss).sum().backward()
+        out.setdefault(graphs, []).append(x.grad.clone())
+    ge, g1, g2 = out[False][0], out[True][0], out[True][1]
+    assert float(ge[:NN - 1].abs().max()) == 0.0 and float(g1[:NN - 1].abs().max()) == 0.0     # only the last view receives gradient
+    assert float(ge[NN - 1].abs().max()) > 0
+    assert float((g1 - ge).norm() / ge.norm()) < 1e-4 and float((g2 - ge).norm() / ge.norm()) < 1e-4
+    assert sorted(k[0] for k in sd._graphs) == ['last', 'share']                               # one graph per role, reused over the views
+    # the per-term entry points of the view-sharded path, graphs vs eager
+    res = {}
+    for graphs in (True, False):
+        sd.use_graphs = graphs
+        shares = [sd.colla_view_share(k, masks[k:k + 1], 'a stone bench in a park', preds[k:k + 1], 7.5, seed=1000 + k) for k in range(NN - 1)]
+        d = sd.colla_last_view_image_grad(NN - 1, masks[NN - 1:], 'a stone bench in a park', preds[NN - 1:], 7.5, sum(shares), weight=1e-4,
+                                          seed=1000 + NN - 1)
+        res[graphs] = (torch.stack(shares), d)
+    sd.generator = None
+    assert float((res[True][0] - res[False][0]).norm() / res[False][0].norm()) < 1e-4
+    assert float((res[True][1] - res[False][1]).norm() / res[False][1].norm()) < 1e-4
+
+
 def test_graphed_steps_with_two_alternating_prompts(cuda):
     """configs[2]/[3] alternate the RGB prompt and `text_normal` inside one iteration.  Each prompt's cross-attention
     key / value planes are cached per transformer (guidance/transformer_cm.py::_prompt_kv) and a captured hipGraph
@@ -1067,8 +1106,12 @@ def test_posterior_sample_and_timestep_embedding_kernels(cuda):
     for t in (torch.tensor([980.0, 20.0]), torch.tensor([501.25])):
         got = sd_nets.timestep_sinusoid(t.to(cuda), 320)
         half = 160
-        freqs = torch.exp(-np.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-        args = t[:, None].float() * freqs[None]
+        # the expression it replaces, evaluated where the reference evaluates it (on the device: a host exp() differs from
+        # the device's by an ulp in some frequencies, i.e. by 6e-5 in an argument of 980)
+        freqs = torch.exp(-np.log(10000.0) * torch.arange(half, dtype=torch.float32, device=cuda) / half)
+        args = t.to(cuda)[:, None].float() * freqs[None]
         ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
         assert got.shape == (t.shape[0], 320)
-        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)   # |args| <= 980: sin / cos to ~1e-7 of 1, argument rounding 6e-5 * 2^-24
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=5e-7)
+        ref64 = torch.cat([torch.cos(args.double()), torch.sin(args.double())], -1)          # and against the exact functions
+        np.testing.assert_allclose(got.cpu().numpy(), ref64.cpu().numpy(), rtol=0, atol=5e-7)
