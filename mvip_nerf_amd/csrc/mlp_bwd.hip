@@ -256,7 +256,7 @@ __global__ void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *
 // per MFMA against 1.7 + 0.1 in the forward kernel); the per-block source addresses of a stage are hoisted into
 // scalar base pointers (a stage advances every block by the same 4 KB), which removes the 64-bit multiply chain that
 // issue_stage re-ran for each of the 12 blocks of every stage.
-template <int NTW, int KT, int PREC = 0, bool BSPLIT = false, int EXTRA = 0, int SP = 32>
+template <int NTW, int KT, int PREC = 0, bool BSPLIT = false, int EXTRA = 0, int SP = 32, int STAGE_BLOCKS = W_STAGE_BLOCKS>
 __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restrict__ act, int64_t act_n_pt,
                                            int64_t act_pt0, const float *__restrict__ gst, int64_t n_pt,
                                            int64_t pt0, int64_t pt1, float *lds, int wave, int lane,
@@ -395,7 +395,6 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 #pragma unroll
         for (int ks = 0; ks < SP / 16; ++ks) {           // 16 points per k-step; lane (i,hh) takes points 16ks+8hh..+7
             const int cw = 4 * ks + 2 * hh;
-            h16x8 Ah[NTW], Al[NTW], Bh[KT], Bl[KT];
             auto split8 = [&](const f32x4 &p0, const f32x4 &p1, float sc, h16x8 &hi, h16x8 &lo) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -405,6 +404,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                     lo[q] = (_Float16)(v - (float)hv);
                 }
             };
+            h16x8 Ah[NTW], Al[NTW], Bh[KT], Bl[KT];
 #pragma unroll
             for (int a = 0; a < NTW; ++a) {
                 const float *t = stg + (a_first + a) * BLK;
@@ -462,7 +462,8 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
 
     // double-buffered stages with COMPILE-TIME buffer addresses (so LDS-DMA writes into one buffer
     // provably do not alias the ds_reads of the other and no wait is inserted between them)
-    float *buf0 = lds, *buf1 = lds + W_STAGE_BLOCKS * BLK;
+    static_assert(nblk <= STAGE_BLOCKS, "stage buffer");
+    float *buf0 = lds, *buf1 = lds + STAGE_BLOCKS * BLK;
     // The loop body is a whole PAIR of stages with its only exit at the bottom, and an odd last stage runs after it:
     // with an exit between the two stages the accumulators reached the flush from two places and the register
     // allocator kept two copies of all eight tiles, moving 128 registers from one to the other every stage.
@@ -497,7 +498,7 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
                     atomicAdd(dst + (int64_t)(8 * (q >> 2) + (q & 3)) * G.ldw, acc[a][b][q] * inv_gscale);
             }
         }
-        if (G.db && (!BSPLIT || a == wave)) {                 // BSPLIT: every wave holds all four sums, each flushes one
+        if (G.db && (!BSPLIT || (a & 3) == wave)) {           // BSPLIT: every wave holds all NTW sums, wave w flushes tiles w, w + 4
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32, 64);
             if (hh == 0) atomicAdd(G.db + n0 + i, tot);
         }
@@ -540,16 +541,27 @@ __global__ void mlp_wgrad_table_kernel(GemmTable tab, Gemm *__restrict__ out) {
 // 128 accumulator registers.
 // SP = 16 (half stages, 56 KB of LDS, <= 128 + 128 registers): TWO workgroups per CU, so the barrier / LDS-latency bubble
 // at every stage boundary of one workgroup runs under the other's MFMAs.
-template <int PREC, int SP>
+// WHOLE (the split-precision kernel with 32-point stages, one workgroup per CU): the eight 256 x 256 products are NOT cut in two
+// row halves -- one workgroup stages 8 gradient + 8 activation blocks (64 KB) per 32 points and every wave holds 8 x 2
+// accumulator tiles (256 registers).  Two halves stage the same 8 activation blocks twice (96 KB of LDS-DMA per product and
+// stage instead of 64; the kernel requests 29 KB per point at ~5 TB/s over the chip, MI355X_MICROARCH.md "ldsdma-fill": 6.4 TB/s at
+// best) and convert them twice: 10 instead of 12 operand-tile conversions per 48 MFMAs.  43.6-44.0 -> 41.2-41.3 ms per configs[2]
+// iteration (profiles/r4_wgrad_experiments.json, which also holds what did NOT help: a three-slot stage ring, fewer
+// flushes, 512-thread workgroups with two waves per SIMD).  grid.y = 12: ids 0..7 the whole products (table entries 2 id),
+// 8..11 the entries 16..19.  MVIP_WGRAD_WHOLE=0 (host) launches the two-halves form.
+constexpr int W_WHOLE_BLOCKS = 17;                         // 8 G + 8 act + the sigma row's d^T block
+template <int PREC, int SP, bool WHOLE = false>
 __global__ __launch_bounds__(256, SP == 16 ? 2 : 1) void mlp_wgrad_kernel(const Gemm *__restrict__ tab,
                                                           const float *__restrict__ act, int64_t act_n_pt,
                                                           int64_t act_pt0, const float *__restrict__ gst,
                                                           int64_t n_pt, int stages_per_slab,
                                                           const unsigned *__restrict__ absmax_bits) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * W_STAGE_BLOCKS * (SP == 32 ? TILE_FLOATS : HALF_FLOATS)];
+    static_assert(!WHOLE || (PREC == 1 && SP == 32), "whole products: the split-precision kernel");
+    constexpr int SB = WHOLE ? W_WHOLE_BLOCKS : W_STAGE_BLOCKS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * SB * (SP == 32 ? TILE_FLOATS : HALF_FLOATS)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int id = blockIdx.y;
+    const int id = WHOLE ? (blockIdx.y < 8 ? 2 * blockIdx.y : blockIdx.y + 8) : blockIdx.y;
     const int64_t pt0 = (int64_t)blockIdx.x * stages_per_slab;
     int64_t pt1 = pt0 + stages_per_slab;
     if (pt1 > n_pt) pt1 = n_pt;
@@ -563,6 +575,16 @@ __global__ __launch_bounds__(256, SP == 16 ? 2 : 1) void mlp_wgrad_kernel(const 
         if (e < -110) e = -110;
         gs = __int_as_float((127 + 6 - e) << 23);
         igs = __int_as_float((127 + e - 6) << 23);
+    }
+    if constexpr (WHOLE) {
+        if (id < 16) {                                // both row halves: 8 gradient tiles from g_tile0, rows from n_off = 0
+            if (G.extra == 1) wgrad_body<8, 2, 1, true, 1, SP, SB>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+            else wgrad_body<8, 2, 1, true, 0, SP, SB>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        }
+        else if (id < 18) wgrad_body<2, 2, PREC, false, 0, SP, SB>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        else if (id == 18) wgrad_body<1, 5, PREC, false, 2, SP, SB>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        else wgrad_body<1, 4, PREC, false, 0, SP, SB>(G, act, act_n_pt, act_pt0, gst, n_pt, pt0, pt1, lds, wave, lane, gs, igs);
+        return;
     }
     if (id < 16) {                                    // 256 x 256 products; product 14 also carries the sigma row
         if (G.extra == 1) {
@@ -694,9 +716,14 @@ static int backward_impl(const float *packed, const float *a, const float *b, in
         // 1 % slower that way, so they keep 32-point stages.  MVIP_WGRAD_HALF=0/1 forces one shape (tuning / A-B switch).
         static const int half_env = [] { const char *e = getenv("MVIP_WGRAD_HALF"); return e ? atoi(e) : -1; }();
         const int half_stages = half_env >= 0 ? half_env : (precision == 1 ? 0 : 1);
+        // split precision: whole 256 x 256 products per workgroup (see mlp_wgrad_kernel); MVIP_WGRAD_WHOLE=0 = two row halves (A/B)
+        static const int whole_env = [] { const char *e = getenv("MVIP_WGRAD_WHOLE"); return e ? atoi(e) : 1; }();
         if (precision == 1) {
             if (half_stages) hipLaunchKernelGGL((mlp_wgrad_kernel<1, 16>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
-            else hipLaunchKernelGGL((mlp_wgrad_kernel<1, 32>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+            else if (whole_env) {
+                const dim3 grid2w((unsigned)((n_pt + sps - 1) / sps), 12);
+                hipLaunchKernelGGL((mlp_wgrad_kernel<1, 32, true>), grid2w, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
+            } else hipLaunchKernelGGL((mlp_wgrad_kernel<1, 32>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
         } else {
             if (half_stages) hipLaunchKernelGGL((mlp_wgrad_kernel<0, 16>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
             else hipLaunchKernelGGL((mlp_wgrad_kernel<0, 32>), grid2, block, 0, s, tab_dev, act, act_n_pt, act_pt0, gst, n_pt, sps, absmax);
