@@ -164,3 +164,27 @@ def test_clip_text_tower_matches_transformers(golden):
     with torch.no_grad():
         out = m(torch.from_numpy(g['ids']))
     np.testing.assert_allclose(out.numpy(), g['last_hidden_state'], rtol=0, atol=2e-5 * float(np.abs(g['last_hidden_state']).max()))
+
+
+def test_latent_distribution_and_timestep_embedding_host_paths():
+    """guidance/sd_nets.py on the host (no device, no library): LatentDist forms diffusers' mean / logvar / std lazily and its
+    scaled_sample is the pipeline's expression with autograd to the moments; timestep_sinusoid is diffusers'
+    get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    import math
+    from mvip_nerf_amd.guidance import sd_nets
+    g = torch.Generator().manual_seed(4)
+    m = torch.randn(1, 8, 6, 5, generator=g).requires_grad_(True)
+    noise = torch.randn(1, 4, 6, 5, generator=g)
+    d = sd_nets.LatentDist(m)
+    assert torch.equal(d.mean, m[:, :4]) and torch.equal(d.logvar, torch.clamp(m[:, 4:], -30.0, 20.0))
+    assert torch.equal(d.std, torch.exp(0.5 * d.logvar))
+    out = d.scaled_sample(noise, 0.18215)
+    assert torch.equal(out, 0.18215 * (m[:, :4] + torch.exp(0.5 * torch.clamp(m[:, 4:], -30.0, 20.0)) * noise))
+    out.sum().backward()
+    assert m.grad is not None and float(m.grad[:, :4].min()) == pytest.approx(0.18215)
+    t = torch.tensor([980.0, 3.0])
+    emb = sd_nets.timestep_sinusoid(t, 320)
+    k = torch.arange(160, dtype=torch.float32)
+    args = t[:, None] * torch.exp(-math.log(10000.0) * k / 160)[None]
+    assert emb.shape == (2, 320)
+    assert torch.allclose(emb[:, :160], torch.cos(args), atol=1e-6) and torch.allclose(emb[:, 160:], torch.sin(args), atol=1e-6)
