@@ -247,12 +247,14 @@ class StableDiffusion(nn.Module):
         # for the built-in networks on the device; injected networks (tests replaying recorded draws through _randn,
         # library modules that may synchronise) keep the eager path unless asked.
         if use_graphs is None:
-            use_graphs = builtin and torch.device(device).type == 'cuda'
+            import os
+            use_graphs = builtin and torch.device(device).type == 'cuda' and os.environ.get('MVIP_SDS_GRAPHS', '1') != '0'
+            # (MVIP_SDS_GRAPHS=0: launch-by-launch steps, e.g. under rocprofv3 --pmc, whose per-dispatch counter collection next
+            # to replayed graphs of the multi-view step did not finish in 49 minutes on this pool)
             # next to a live multi-rank process group the default stays eager: a capture beside RCCL's own threads and
             # streams has not been exercised on multi-GPU hardware (the build boxes have one GPU).  use_graphs=True or
             # MVIP_GRAPHS_WITH_DIST=1 turn the replay on there too (thread-local capture; the step itself contains no
             # collective -- bench.py reports which mode ran, profiles/r4_bench_2rank_single_device.json has the 2-rank run)
-            import os
             import torch.distributed as dist
             if (use_graphs and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
                     and os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') != '1'):

@@ -6,7 +6,9 @@
 #                                                                            -> r4_pmc_sds_traffic.json
 #  (5) one SDS step per kernel + hipGraph replay, fp32 networks (two products) and --fp16 mode -> r4_sds_step_f32.json, r4_sds_step_fp16.json
 #  (6) isolated HBM-bound stage kernels                                      -> r4_micro_hbm_kernels.jsonl
-# PMC runs are their own processes with --kernel-trace only (never combined with --stats / sys-trace).
+# PMC runs are their own processes with --kernel-trace only (never combined with --stats / sys-trace), with the SDS steps launched
+# kernel by kernel (MVIP_SDS_GRAPHS=0) and under their own timeouts: per-dispatch counter collection next to replayed hipGraphs of the
+# multi-view step did not finish in 49 minutes.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -21,17 +23,17 @@ for r in rows[1:41]:
     r[0]=r[0][:110]; w.writerow(r)
 "
 find gpurun_out/prof_r4 -name '*kernel_trace.csv' -delete; find gpurun_out/prof_r4 -name '*.db' -delete
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_r4 -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 1 --sds-steps 1 --no-cpu-baseline --no-hashgrid > gpurun_out/pmc_r4/line.json 2> gpurun_out/pmc_r4/err.log
+MVIP_SDS_GRAPHS=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_r4 -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 1 --sds-steps 1 --no-cpu-baseline --no-hashgrid > gpurun_out/pmc_r4/line.json 2> gpurun_out/pmc_r4/err.log
 find gpurun_out/pmc_r4 -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_summary.py {} gpurun_out/r4_pmc_mfma_util.json > gpurun_out/pmc_r4/summary_top.txt
 find gpurun_out/pmc_r4 -name '*.csv' -delete; find gpurun_out/pmc_r4 -name '*.db' -delete
 for C in FETCH_SIZE WRITE_SIZE; do
   c=$(echo $C | tr A-Z a-z | sed 's/_size//')
   D=gpurun_out/pmc_r4_$c; mkdir -p $D
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 0 --sds-steps 0 --no-cpu-baseline --no-hashgrid > $D/line.json 2> $D/err.log
+  MVIP_SDS_GRAPHS=0 timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 0 --sds-steps 0 --no-cpu-baseline --no-hashgrid > $D/line.json 2> $D/err.log
   find $D -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_summary.py {} --longest mlp_forward16_kernel > $D/dominant.json
   find $D -name '*.csv' -delete; find $D -name '*.db' -delete
   D=gpurun_out/pmc_r4_sds_$c; mkdir -p $D
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 tools/sds_profile_steps.py 5 > $D/out.txt 2> $D/err.log
+  timeout 420 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 tools/sds_profile_steps.py 5 > $D/out.txt 2> $D/err.log
   find $D -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} $D/cc.csv
   find $D -name '*.db' -delete
 done
