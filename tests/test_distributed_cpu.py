@@ -115,7 +115,7 @@ def _blocks_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_block_sharded_frame_is_assembled_on_every_rank(tmp_path, world):
     """Strong-scaling render (bench.py --gpus N headline, run.render_sharded): contiguous ray blocks, one all_gather of
     (rgb, disp, acc, depth); every rank ends with the whole maps, equal to the unsharded result."""
