@@ -166,7 +166,7 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
     tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
     traffic, src = None, None
-    for name in ('r4_pmc_mlp_forward.json', 'r3_pmc_mlp_forward.json', 'r2_pmc_mlp_forward.json'):     # separate --pmc passes of this launch, newest first
+    for name in ('r5_pmc_mlp_forward.json', 'r4_pmc_mlp_forward.json', 'r3_pmc_mlp_forward.json', 'r2_pmc_mlp_forward.json'):     # separate --pmc passes of this launch, newest first
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
@@ -292,6 +292,41 @@ class Reporter:
             self.fail(f'{type(e).__name__}: {e}')
         self.done.set()
         self.print_line(ok=True)
+
+
+def add_scaling_prediction(result, world):
+    """multi_gpu.predicted: the per-leg time model of mvip_nerf_amd/scaling_model.py evaluated on ONE-GPU
+    legs -- this run's own at N = 1 (predictions for N = 2, 4, 8), the newest committed one-GPU line at N > 1 (prediction for
+    this N, with measured / predicted beside it): the first real multi-GPU run confirms or refutes the model."""
+    from mvip_nerf_amd.scaling_model import predict
+    mg = result.setdefault('multi_gpu', {})
+    get = lambda d, *ks: (None if d is None else (d.get(ks[0]) if len(ks) == 1 else get(d.get(ks[0]), *ks[1:]))) if isinstance(d, dict) else None
+    if world == 1:
+        src, line = 'this run', result
+    else:
+        src, line = None, None
+        for name in ('r5_bench_line.json', 'r4_bench_line.json'):
+            path = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(path):
+                src, line = f'profiles/{name}', json.load(open(path))
+                break
+        if line is None:
+            return
+    measured = {'frame_ms': get(line, 'ms_per_step'), 'train_ms': get(line, 'train', 'ms_per_step'),
+                'sds_ms': get(line, 'sds', 'ms_per_step'), 'config2_ms': get(line, 'config2_rgb_normal_sds', 'ms_per_step'),
+                'config3_ms': get(line, 'config3_rgb_normal_colla_sds', 'ms_per_step')}
+    if measured['frame_ms'] is None:
+        return
+    pred = predict(measured, ns=(2, 4, 8) if world == 1 else (world,))
+    pred['one_gpu_legs_from'] = src
+    if world > 1:
+        row = pred['N'].get(world, {})
+        got = {'ms_per_step': result.get('ms_per_step'), 'value': result.get('value'), 'strong_efficiency': result.get('strong_efficiency'),
+               'train_ms': mg.get('train_ms'), 'train_with_sds_ms': mg.get('train_with_sds_ms'),
+               'config2_ms': mg.get('config2_ms'), 'config3_ms': mg.get('config3_ms')}
+        pred['measured'] = got
+        pred['measured_over_predicted'] = {k: round(got[k] / row[k], 3) for k in row if got.get(k) and row.get(k)}
+    mg['predicted'] = pred
 
 
 def dry_run(world, rank, args):
@@ -432,12 +467,31 @@ def main():
         dt_weak = timed(step)                        # every rank its own frames, no collective: N x by construction
         dt = timed(step_strong)                      # the headline at N > 1: fixed work, one frame over all ranks
         value, scaling = H * W * args.steps / dt, 'strong'
-        v1 = H * W * args.steps / dt_weak            # one rank's whole-frame rate in this same run (slowest rank)
+        # The one-GPU baseline of this same run, measured with the OTHER ranks idle (they wait at the barrier): rank 0 renders
+        # whole frames alone, so neither a shared device nor contention for host / fabric halves it.
+        for k in range(args.warmup):
+            if rank == 0:
+                step(k)
+        barrier()
+        t0 = time.perf_counter()
+        if rank == 0:
+            for k in range(args.steps):
+                step(args.warmup + k)
+        barrier()
+        dt_solo = time.perf_counter() - t0
+        t = torch.tensor([dt_solo], device=device, dtype=torch.float64)
+        dist.broadcast(t, 0)
+        dt_solo = float(t.item())
+        v1 = H * W * args.steps / dt_solo
+        shared_device = os.environ.get('MVIP_BENCH_SINGLE_DEVICE') == '1'
         extra = {'weak_rays_per_sec': rays_per_step * args.steps / dt_weak, 'weak_ms_per_step': dt_weak / args.steps * 1e3,
-                 'value_1_same_run': v1, 'strong_efficiency': value / (world * v1),
+                 'value_1_same_run': v1,
+                 # ranks that time-share ONE device scale nothing: no efficiency is claimed for such a run
+                 'strong_efficiency': None if shared_device else value / (world * v1),
+                 'ranks_share_one_device': shared_device,
                  'strong_what': 'each frame cut into N contiguous ray blocks (run.render_sharded), ONE all_gather of '
                                 f'[{H * W}, 6] fp32 = {H * W * 24 / 1e6:.2f} MB per frame so every rank holds rgb / disp / acc / depth; '
-                                'value_1_same_run = whole frames on one rank (the weak leg, slowest rank)'}
+                                'value_1_same_run = whole frames on rank 0 ALONE (the other ranks idle at a barrier)'}
         par = (f'one frame over {world} ranks: contiguous ray blocks of {-(-H * W // world)} rays, one all_gather of the maps '
                f'per frame ({"RCCL over xGMI" if backend == "nccl" else backend})')
     result.update({
@@ -708,26 +762,43 @@ def main():
             sds_ms = dt_sds / args.sds_steps * 1e3
             ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            for name in ('r4_pmc_sds_traffic.json', 'r3_pmc_sds_traffic.json'):                 # newest first
+            for name in ('r5_pmc_sds_traffic.json', 'r4_pmc_sds_traffic.json', 'r3_pmc_sds_traffic.json'):      # newest first
                 pmc_sds = os.path.join(ROOT, 'profiles', name)
                 if os.path.exists(pmc_sds):
                     traffic = json.load(open(pmc_sds)).get('hbm_bytes_per_step')
                     traffic_src = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over eager steps, per kernel)'
                     break
+            # The ceiling of the work the step ISSUES: a contraction with an fp16-exact weight operand runs two fp16 products per
+            # algorithmic multiply-add (ops.TWO_PRODUCT), activation x activation products (attention) three, so the
+            # fp32-equivalent peak is 2500 x FLOPs / (2 x weight FLOPs + 3 x attention FLOPs); three everywhere otherwise.
+            from mvip_nerf_amd import ops as _ops
+            two_prod = bool(getattr(sd.networks, 'fp16_weights', False)) and bool(_ops.TWO_PRODUCT)
+            fl_w = fl_a = 0
+            for net, mult in (('unet', 1), ('vae_encoder', 3)):
+                fl_w += mult * (fl['breakdown'][net]['conv'] + fl['breakdown'][net]['linear'])
+                fl_a += mult * fl['breakdown'][net]['attention']
+            products_per_flop = ((2 if two_prod else 3) * fl_w + 3 * fl_a) / max(fl_w + fl_a, 1)
+            peak_issued = PEAK_F16_TFLOPS / products_per_flop
             sds_roof = {'bound': 'mfma', 'flops_per_step': fl['per_step'], 'composition': fl['composition'],
                         'algorithmic_hbm_bytes': fl['bytes_per_step'], 'traffic': traffic, 'traffic_unit': 'HBM bytes per step',
                         'traffic_source': traffic_src,
                         'unet_forward_flops': fl['unet_forward'], 'vae_encoder_forward_flops': fl['vae_encoder_forward'],
                         'achieved': round(ach, 1), 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the step / median step time)',
-                        'peak': round(PEAK_F16_TFLOPS / 3, 1),
-                        'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / 3 products: the split-precision kernels (3x3 convolutions, GEMMs, '
+                        'peak': round(peak_issued, 1),
+                        'products_per_algorithmic_flop': round(products_per_flop, 4),
+                        'peak_is': 'fp16 dense MFMA 2500 TFLOP/s / the fp16 products ISSUED per algorithmic multiply-add, weighted over the '
+                                   'step: two for contractions whose weight operand is an exact fp16 value (every convolution and linear '
+                                   'layer when two_product_weights is true), three for attention and for everything when it is false.  '
+                                   'The split-precision kernels (3x3 convolutions, GEMMs, '
                                    'attention) carry every contraction of the step.  Under dense fp16 MFMA load the shader clock of '
                                    'this part settles at ~1.67 GHz (tools/micro/mfma_clock.hip, profiles/r2_micro_mfma_clock_and_lds.json), '
                                    'i.e. a sustained peak of ~580 TFLOP/s fp32-equivalent; with operands that change from one MFMA '
                                    'to the next, as in a real contraction, the power limit holds the part at ~23 ns per 32x32x16 MFMA '
                                    'per SIMD (tools/micro/conv_loop.hip: ~1.44 GHz at 33 cycles, sustained), i.e. ~490 TFLOP/s fp32-equivalent',
                         'frac_of_sustained_f16x3_peak': round(ach / (PEAK_F16_TFLOPS / 3 * 1.67 / 2.4), 4),
-                        'frac': round(ach / (PEAK_F16_TFLOPS / 3), 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4),
+                        'frac': round(ach / peak_issued, 4), 'frac_of_exact_fp32_mfma_peak': round(ach / PEAK_F32_TFLOPS, 4),
+                        'peak_three_product': round(PEAK_F16_TFLOPS / 3, 1),
+                        'frac_of_three_product_peak': round(ach / (PEAK_F16_TFLOPS / 3), 4),
                         # with fp16-exact weights the weight contractions (all but attention's ~3 % of the FLOPs) need TWO fp16
                         # products for the same bits, so the stricter denominator for this step is 2500 / 2
                         'peak_two_product': round(PEAK_F16_TFLOPS / 2, 1),
@@ -759,7 +830,11 @@ def main():
                                         'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
                                                 '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}
 
-    rep.guarded(extra_legs)
+    def legs_and_prediction():
+        extra_legs()
+        add_scaling_prediction(result, world)
+
+    rep.guarded(legs_and_prediction)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

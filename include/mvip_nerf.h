@@ -31,9 +31,11 @@ extern "C" {
 #define MVIP_ELAUNCH  -2   /* hipLaunch / runtime error (see mvip_last_hip_error) */
 #define MVIP_EUNSUP   -3   /* shape outside what the kernels are built for */
 
-#define MVIP_ABI_VERSION 3      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points;
+#define MVIP_ABI_VERSION 4      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points;
                                    3: prec = 2 (two products for fp16-exact weights), mvip_packed_weights_two_product,
-                                      mvip_build_is_experiment */
+                                      mvip_build_is_experiment;
+                                   4: mvip_mlp_*_f16x3_w16 (two-waves-per-SIMD split-precision forward) added,
+                                      mvip_mlp_forward_rays16_persistent removed */
 
 int         mvip_abi_version(void);
 int         mvip_build_is_experiment(void); /* 1: compiled with a -DMVIP_EXPERIMENT_* macro (timing build, WRONG results) */
@@ -95,6 +97,17 @@ int mvip_mlp_forward_rays_f16x3(const float *image, const float *rows, const flo
 int mvip_mlp_forward_points_f16x3(const float *image, const float *pts, const float *dirs, int64_t P,
                                   float *raw, void *stream);
 
+/* Round 5: the split-precision forward with TWO waves per SIMD (csrc/mlp_fwd16_f16x3.hip: 16 points per wave on
+ * v_mfma_f32_16x16x32_f16, one weight ring per 8-wave workgroup) -- the kernel behind NeRF.forward under no_grad at
+ * inference_precision = 1 (run_network, DS_NeRF/run.py:1108-1124; DS_NeRF/run_nerf_helpers.py:104-127).  Its own image
+ * (mvip_mlp_packed_floats() floats: fp16 hi / lo A fragments in 16x16x32 order + section B of the fp32 image); values equal
+ * mvip_mlp_forward_*_f16x3's up to fp32 summation order.  Forward only. */
+int mvip_mlp_pack_f16x3_w16(const float *const *params_host, const float *packed_f32, float *image, void *stream);
+int mvip_mlp_forward_rays_f16x3_w16(const float *image, const float *rows, const float *z, int64_t B, int S,
+                                    float *raw, void *stream);
+int mvip_mlp_forward_points_f16x3_w16(const float *image, const float *pts, const float *dirs, int64_t P,
+                                      float *raw, void *stream);
+
 /* Forward from geometry: rows [B,11], z [B,S] -> raw [B,S,4]; points are o + d*z, view dirs
  * are rows[:,8:11] (run.py:1783, :1787).
  * precision 0: exact fp32 MFMA, `packed` from mvip_mlp_pack().
@@ -116,10 +129,6 @@ int mvip_mlp_forward_points(const float *packed, const float *pts, const float *
 int mvip_mlp_pack16(const float *const *params_host, const float *packed, float *packed16, void *stream);
 int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
                             float *raw, void *stream);
-/* mvip_mlp_forward_rays16 as a persistent kernel (one workgroup per CU looping over its tiles; S a power of two).  Same bits;
- * measured equal-to-slower (profiles/r4_persistent_ab.json): an A/B alternative, never the default path. */
-int mvip_mlp_forward_rays16_persistent(const float *packed16, const float *rows, const float *z, int64_t B, int S,
-                                       float *raw, void *stream);
 int mvip_mlp_forward_points16(const float *packed16, const float *pts, const float *dirs, int64_t P,
                               float *raw, void *stream);
 

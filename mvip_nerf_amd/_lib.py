@@ -33,11 +33,13 @@ _SIGNATURES = {
     'mvip_mlp_pack_f16x3': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_rays_f16x3': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
     'mvip_mlp_forward_points_f16x3': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
+    'mvip_mlp_pack_f16x3_w16': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),
+    'mvip_mlp_forward_rays_f16x3_w16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
+    'mvip_mlp_forward_points_f16x3_w16': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_mlp_forward_rays': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _int, _c_f]),
     'mvip_mlp_forward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _int, _c_f]),
     'mvip_mlp_pack16': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_rays16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
-    'mvip_mlp_forward_rays16_persistent': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
     'mvip_mlp_forward_rays_stash16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_points16': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
     'mvip_render_coarse_fused': (_int, [_c_f, _c_f, _i64, _c_f, _int, _c_f, _c_f, _c_f, _int, _int, _int, _c_f, _c_f, _c_f, _c_f,
@@ -147,7 +149,7 @@ _SIGNATURES = {
 DECLARED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MvipError(RuntimeError):

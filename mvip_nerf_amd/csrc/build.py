@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(PKG, 'lib_experiment' if EXPERIMENT else 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libmvipnerf.so')
 
-SOURCES = ['api.hip', 'rays.hip', 'composite.hip', 'sample_pdf.hip', 'mlp_pack.hip', 'mlp_fwd.hip', 'mlp_fwd16.hip', 'mlp_fwd_f16x3.hip',
+SOURCES = ['api.hip', 'rays.hip', 'composite.hip', 'sample_pdf.hip', 'mlp_pack.hip', 'mlp_fwd.hip', 'mlp_fwd16.hip', 'mlp_fwd_f16x3.hip', 'mlp_fwd16_f16x3.hip',
            'mlp_bwd.hip', 'mlp_bwd16.hip', 'mlp_bwd_f16x3.hip', 'normal_fit.hip', 'sds_elem.hip', 'group_norm.hip', 'conv3x3.hip', 'attention.hip', 'transformer.hip', 'hashgrid.hip', 'hashgrid_fused.hip', 'skinny_gemm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function'] + EXTRA_FLAGS

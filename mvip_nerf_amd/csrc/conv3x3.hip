@@ -1779,16 +1779,13 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     if (tw == CV_TW && wide_mode && H % 16 == 0 && prec != 1) {
         const int64_t tiles16 = N * (W / CV_TW) * (H / 16);
         int mtw = (Cout % 64 == 0 && tiles16 * (Cout / 64) >= 256) ? 2 : (tiles16 * (Cout / 32) >= 256 ? 1 : 0);
-        // MVIP_CONV_WIDE=2: 128 rows x 512 pixels per eight-wave workgroup (one per CU, two waves per SIMD, 128
-        // accumulator registers per wave): 12 fragment reads per 24 MFMAs instead of 16
-        if (wide_mode == 2 && Cout % 128 == 0 && tiles16 * (Cout / 128) >= 200) mtw = 4;
+        // (MVIP_CONV_WIDE=2 -- 128 rows x 512 pixels per eight-wave workgroup, 12 fragment reads per 24 MFMAs instead of 16 --
+        //  was measured no faster in round 3 and its <4, 32, 8, 3> instantiation spilled 164 registers: removed in round 5.)
         if (mtw) {
             a.tilesY = (int)(H / 16); a.MB = (int)(Cout / (32 * mtw));
             const int64_t wb = tiles16 * a.MB;
             if (wb > 0x7fffffffLL) return MVIP_EINVAL;
-            if (mtw == 4)
-                hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);
-            else if (mtw == 2 && prec == 2)
+            if (mtw == 2 && prec == 2)
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8, 2>), dim3((unsigned)wb), dim3(512), 0, st, a);
             else if (mtw == 2)
                 hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, CV_TW, 8>), dim3((unsigned)wb), dim3(512), 0, st, a);

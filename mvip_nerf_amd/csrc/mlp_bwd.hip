@@ -283,18 +283,25 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         const int r = 16 * (wave & 1) + (lane >> 2), c = lane & 3;
         lane_off = r * 32 + ((c ^ ((r >> 2) & 3)) << 2);
     }
-    const float *blk_base[nblk];                                   // wave-uniform: stage pt of block b = base + pt * 4 KB
-#pragma unroll
-    for (int b = 0; b < nblk; ++b) {
+    // wave-uniform source of block b of a stage: stage pt of block b = base + pt * 4 KB
+    auto base_of = [&](int b) -> const float * {
         int tile;
         bool from_g = false;
         if (b < NT) { tile = g_tile0 + b; from_g = true; }
         else if (b < NT + KTT) { const int k = b - NT; tile = k < ac0 ? a0 + k : a1 + (k - ac0); }
         else if (extra == 2 && b < NT + KTT + 4) tile = AT_V + (b - NT - KTT);
         else { tile = GT_D; from_g = true; }
-        blk_base[b] = from_g ? gst + (int64_t)tile * n_pt * TILE_FLOATS
-                             : act + ((int64_t)tile * act_n_pt + act_pt0) * TILE_FLOATS;
-    }
+        return from_g ? gst + (int64_t)tile * n_pt * TILE_FLOATS
+                      : act + ((int64_t)tile * act_n_pt + act_pt0) * TILE_FLOATS;
+    };
+    // SP = 32: every wave stages a piece of EVERY block.  SP = 16: waves 0, 1 stage the even blocks, waves 2, 3 the odd ones --
+    // each wave keeps only the bases of ITS blocks, at compile-time positions (an array of all bases indexed by 2 k + (wave >> 1)
+    // is a dynamically indexed private array: it went to scratch, 96 B per lane, and every stage re-loaded it from there).
+    constexpr int NB = SP == 32 ? nblk : (nblk + 1) / 2;
+    const int odd = SP == 32 ? 0 : (wave >> 1);
+    const float *blk_base[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) blk_base[k] = base_of(SP == 32 ? k : 2 * k + odd);
     // `st` counts stages of SP points from the start of the tile
     auto issue_stage = [&](int64_t st, float *dst) {
         // scalar base + 32-bit per-lane byte offset (a backward tile spans < 2^32 bytes per stash row): the form the
@@ -308,16 +315,11 @@ __device__ __forceinline__ void wgrad_body(const Gemm &G, const float *__restric
         } else {
             const unsigned voff = (unsigned)((((unsigned)st >> 1) * (unsigned)TILE_FLOATS + ((unsigned)st & 1u) * 16u +
                                               (unsigned)lane_off) * 4u);
-            float *d = dst + (wave & 1) * 256;
-            if (wave >> 1) {
+            float *d = dst + (wave & 1) * 256 + odd * HALF_FLOATS;
 #pragma unroll
-                for (int b = 1; b < nblk; b += 2)
-                    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff), d + b * HALF_FLOATS);
-            } else {
-#pragma unroll
-                for (int b = 0; b < nblk; b += 2)
-                    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[b]) + voff), d + b * HALF_FLOATS);
-            }
+            for (int k = 0; k < NB; ++k)
+                if (2 * k + odd < nblk)
+                    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(blk_base[k]) + voff), d + 2 * k * HALF_FLOATS);
         }
     };
 

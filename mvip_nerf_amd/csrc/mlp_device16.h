@@ -18,6 +18,21 @@ __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(ic<I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
 }
 
+// channel c of the sinusoidal encoding of (x, y, z) with C real channels (Embedder.embed order)
+template <int C>
+__device__ __forceinline__ float enc_channel(float x, float y, float z, int c) {
+    const int m = c >= 3 ? c - 3 : 0;
+    const int oct = m / 6, rem = m - 6 * oct;
+    const int d = rem >= 3 ? rem - 3 : rem;
+    const int dsel = c < 3 ? c : d;
+    const float xv = dsel == 0 ? x : (dsel == 1 ? y : z);
+    const float arg = xv * __int_as_float((127 + oct) << 23);
+    float val = rem < 3 ? sinf(arg) : cosf(arg);
+    if (c < 3) val = xv;
+    if (c >= C) val = 0.f;
+    return val;
+}
+
 constexpr int NSLOT16 = 4;
 constexpr int RING16_FLOATS = NSLOT16 * CHUNK_FLOATS;            // 64 KB
 constexpr int LDS16_FLOATS = RING16_FLOATS + SEC_B_FLOATS;       // + 13 KB of small vectors

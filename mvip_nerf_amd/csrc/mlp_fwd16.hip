@@ -30,21 +30,6 @@ using namespace mlp;
 
 namespace f16p {
 
-// channel c of the sinusoidal encoding of (x, y, z) with C real channels (Embedder.embed order)
-template <int C>
-__device__ __forceinline__ float enc_channel(float x, float y, float z, int c) {
-    const int m = c >= 3 ? c - 3 : 0;
-    const int oct = m / 6, rem = m - 6 * oct;
-    const int d = rem >= 3 ? rem - 3 : rem;
-    const int dsel = c < 3 ? c : d;
-    const float xv = dsel == 0 ? x : (dsel == 1 ? y : z);
-    const float arg = xv * __int_as_float((127 + oct) << 23);
-    float val = rem < 3 ? sinf(arg) : cosf(arg);
-    if (c < 3) val = xv;
-    if (c >= C) val = 0.f;
-    return val;
-}
-
 // FUSE (rays form only; DS_NeRF/run.py:1703-1847 render_rays as TWO launches per chunk instead of six):
 //   1  the COARSE pass: 64 samples per ray, a workgroup = two rays.  The depths are computed here (stratified_point, no z
 //      tensor), and after the network the first wave of each ray composites its 64 samples (raw2outputs) from the
@@ -244,140 +229,6 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     }
 }
 
-// ---- the same forward as a PERSISTENT kernel (rays form, no stash, no fused tail) ---------------------------------------
-// One workgroup per CU loops over its 128-point tiles.  What the loop removes is the bubble between two workgroups of the
-// kernel above: all eight waves of a workgroup leave together (they meet at a barrier every 16 KB of weights), so the next
-// workgroup's waves start together too -- and wait, matrix pipes idle, for section B and their first two weight chunks to come
-// up from L2, ~1-2 % of a tile's 250 us.  Here
-//   * the weight stream never stops: a ring of FIVE slots (145 chunks per tile = 29 x 5, so a chunk's slot stays a compile-time
-//     function of its index from tile to tile) and chunk indices that wrap -- the next tile's chunks 0 and 1 are staged while
-//     this tile's view layer runs, and its first operand block is read by the view layer's last block;
-//   * section B (biases, sigma / rgb rows) is loaded once per workgroup;
-//   * the next tile's ray rows and depths are fetched at the top of the current tile and consumed a tile later.
-// 93 KB of LDS, one workgroup per CU (the register file admits no second one anyway: 2 waves per SIMD x 4 SIMDs = 8 waves).
-// Same instructions per point in the same order as mlp_forward16_kernel<true>: bit-identical results.
-// MEASURED (round 4, tools/persistent_ab.py, profiles/r4_persistent_ab.json): 200.1-200.5 ms against 199.6-199.9 ms for one
-// workgroup per tile on the bench's fine-pass launch -- no gain: the hardware already lets the next workgroup's waves flow in
-// while the last ones finish (see the LDS-footprint note in mlp_forward16_kernel), and inside a loop the compiler needs opaque
-// per-tile base pointers to keep 145 DMA addresses from being hoisted (23 registers still spill).  Kept as a tested
-// alternative behind mvip_mlp_forward_rays16_persistent / MVIP_MLP_PERSISTENT=1; the default stays one workgroup per tile.
-constexpr int NSLOT16P = 5;
-static_assert(TOTAL_CHUNKS % NSLOT16P == 0, "the ring phase must repeat from tile to tile");
-constexpr int LDS16P_FLOATS = NSLOT16P * CHUNK_FLOATS + SEC_B_FLOATS;
-
-__global__ void __launch_bounds__(512, 2)
-mlp_forward16_persistent_kernel(const float *__restrict__ packed, const float *__restrict__ rows, const float *__restrict__ z,
-                                int64_t P, int S, float *__restrict__ raw) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS16P_FLOATS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const int64_t n_tiles = (P + WG_POINTS - 1) / WG_POINTS;
-
-    Stream16T<NSLOT16P, true> st{packed, lds, wave, lane, TOTAL_CHUNKS, (lds_cfloat *)lds};
-    constexpr int RINGP = NSLOT16P * CHUNK_FLOATS;
-    for (int b = wave; b < SEC_B_FLOATS / BLOCK_FLOATS; b += 8)
-        glds<0>(packed + SEC_A_FLOATS + b * BLOCK_FLOATS + lane * 4, lds + RINGP + b * BLOCK_FLOATS);
-    st.issue_chunk(0, 0);
-    st.issue_chunk(1, 1);
-    lds_cfloat *sb_const = (lds_cfloat *)(lds + RINGP);
-    __syncthreads();
-    // inputs of the first tile (every later tile's arrive one tile ahead)
-    auto point_of = [&](int64_t tile) { int64_t p = tile * WG_POINTS + wave * 16 + n; return p < P ? p : P - 1; };
-    float o0, o1, o2, d0, d1, d2, v0, v1, v2, zz;
-    auto fetch = [&](int64_t tile) {
-        const int64_t p = point_of(tile);
-        const float *row = rows + (p >> S) * 11;          // S = log2(samples per ray) here: the launcher takes this kernel for powers of two
-        o0 = row[0]; o1 = row[1]; o2 = row[2]; d0 = row[3]; d1 = row[4]; d2 = row[5];
-        v0 = row[8]; v1 = row[9]; v2 = row[10];
-        zz = z[p];
-    };
-    int64_t tile = blockIdx.x;
-    fetch(tile);
-    f32x4 a = st.read_block<0>();
-    for (; tile < n_tiles; tile += gridDim.x) {
-        // Opaque per-tile copies of what the tile's ~300 address computations start from.  Inside a loop the compiler otherwise
-        // hoists every one of them out as "loop invariant" (145 DMA source pointers, the section-B addresses beyond the 64 KB reach
-        // of an LDS immediate, ...) -- hundreds of registers, all spilled.
-        asm volatile("" : "+v"(st.lane));
-        asm volatile("" : "+s"(st.packed));
-        asm volatile("" : "+v"(st.lds_read));
-        lds_cfloat *sb = sb_const;
-        asm volatile("" : "+v"(sb));
-        const int64_t p = tile * WG_POINTS + wave * 16 + n;
-        const bool live = p < P;
-        const float px = o0 + d0 * zz, py = o1 + d1 * zz, pz = o2 + d2 * zz;
-        const float vx = v0, vy = v1, vz = v2;
-        f32x4 emb[4], edir[2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) emb[t][i] = enc_channel<63>(px, py, pz, 16 * t + 4 * g + i);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) edir[t][i] = enc_channel<27>(vx, vy, vz, 16 * t + 4 * g + i);
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);   // lands while this tile's network runs
-
-        f32x4 h[16], o[16];
-        layer16<OFF_L0, 16, NTI_L0, false>(st, a, sb + SB_BIAS, [&](auto ti) { return emb[ti.value]; },
-            [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
-#pragma unroll
-        for (int t = 0; t < 16; ++t) h[t] = o[t];
-        static_for<4>([&](auto li) {
-            constexpr int l = 1 + decltype(li)::value;
-            layer16<OFF_L1 + (l - 1) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
-                [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
-#pragma unroll
-            for (int t = 0; t < 16; ++t) h[t] = o[t];
-        });
-        layer16<OFF_L5, 16, NTI_L5, false>(st, a, sb + SB_BIAS + 5 * 256,
-            [&](auto ti) { if constexpr (ti.value < 4) return emb[ti.value]; else return h[ti.value - 4]; },
-            [&](auto to, const f32x4 &acc) { o[to.value] = act16<true>(acc); });
-#pragma unroll
-        for (int t = 0; t < 16; ++t) h[t] = o[t];
-        float sigma = 0.f;
-        static_for<2>([&](auto li) {
-            constexpr int l = 6 + decltype(li)::value;
-            layer16<OFF_L6 + (l - 6) * LH_BLOCKS, 16, NTI_LH, false>(st, a, sb + SB_BIAS + l * 256, [&](auto ti) { return h[ti.value]; },
-                [&](auto to, const f32x4 &acc) {
-                    o[to.value] = act16<true>(acc);
-                    if constexpr (l == 7) {
-                        const f32x4 w = ld4(sb + SB_WALPHA + 16 * to.value + 4 * g);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sigma = fmaf(w[i], o[to.value][i], sigma);
-                    }
-                });
-#pragma unroll
-            for (int t = 0; t < 16; ++t) h[t] = o[t];
-        });
-        sigma += __shfl_xor(sigma, 16, 64);
-        sigma += __shfl_xor(sigma, 32, 64);
-        sigma += sb[SB_BALPHA];
-        layer16<OFF_FEAT, 16, NTI_LH, false>(st, a, sb + SB_BFEAT, [&](auto ti) { return h[ti.value]; },
-            [&](auto to, const f32x4 &acc) { o[to.value] = act16<false>(acc); });
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        layer16<OFF_VIEWS, 8, NTI_LV, true>(st, a, sb + SB_BVIEWS,
-            [&](auto ti) { if constexpr (ti.value < 16) return o[ti.value]; else return edir[ti.value - 16]; },
-            [&](auto to, const f32x4 &acc) {
-                const f32x4 v = act16<true>(acc);
-                const f32x4 w0 = ld4(sb + SB_WRGB + 16 * to.value + 4 * g);
-                const f32x4 w1 = ld4(sb + SB_WRGB + 128 + 16 * to.value + 4 * g);
-                const f32x4 w2 = ld4(sb + SB_WRGB + 256 + 16 * to.value + 4 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    r0 = fmaf(w0[i], v[i], r0);
-                    r1 = fmaf(w1[i], v[i], r1);
-                    r2 = fmaf(w2[i], v[i], r2);
-                }
-            });
-        r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
-        r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
-        const float4 out4 = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
-        if (live && g == 0) reinterpret_cast<float4 *>(raw)[p] = out4;
-    }
-}
-
 // ---- packing ---------------------------------------------------------------------------------------------------
 struct ParamPtrsC16 { const float *p[P_COUNT]; };
 
@@ -430,23 +281,6 @@ extern "C" int mvip_mlp_pack16(const float *const *params_host, const float *pac
     return check_launch();
 }
 
-// The same forward as ONE workgroup per CU looping over its 128-point tiles (mlp_forward16_persistent_kernel): S must be a
-// power of two (ray = point >> log2 S).  Bit-identical to mvip_mlp_forward_rays16; an A/B alternative, not the default.
-extern "C" int mvip_mlp_forward_rays16_persistent(const float *packed16, const float *rows, const float *z, int64_t B, int S,
-                                                  float *raw, void *stream) {
-    if (B < 0 || S <= 0 || (S & (S - 1)) != 0) return MVIP_EINVAL;
-    if (B == 0) return MVIP_OK;
-    if (!packed16 || !rows || !z || !raw) return MVIP_EINVAL;
-    const int64_t P = B * S;
-    const int64_t tiles = (P + WG_POINTS - 1) / WG_POINTS;
-    static const int n_cu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-    int log2s = 0;
-    while ((1 << log2s) < S) ++log2s;
-    hipLaunchKernelGGL(mlp_forward16_persistent_kernel, dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(512), 0, as_stream(stream),
-                       packed16, rows, z, P, log2s, raw);
-    return check_launch();
-}
-
 extern "C" int mvip_mlp_forward_rays16(const float *packed16, const float *rows, const float *z, int64_t B, int S,
                                        float *raw, void *stream) {
     if (B < 0 || S <= 0) return MVIP_EINVAL;
@@ -454,11 +288,6 @@ extern "C" int mvip_mlp_forward_rays16(const float *packed16, const float *rows,
     if (!packed16 || !rows || !z || !raw) return MVIP_EINVAL;
     const int64_t P = B * S;
     const int64_t tiles = (P + WG_POINTS - 1) / WG_POINTS;
-    // MVIP_MLP_PERSISTENT=1 (A/B switch, default off): launches of several tiles per CU take the persistent form below.  Measured
-    // EQUAL-to-slower (profiles/r4_persistent_ab.json: fine-pass launch 200.1-200.5 vs 199.6-199.9 ms, same bits): the gap between
-    // two workgroups of this kernel is not where its last 8 % are.
-    static const int persistent = [] { const char *e = getenv("MVIP_MLP_PERSISTENT"); return e ? atoi(e) : 0; }();
-    if (persistent && (S & (S - 1)) == 0 && tiles >= 1024) return mvip_mlp_forward_rays16_persistent(packed16, rows, z, B, S, raw, stream);
     hipLaunchKernelGGL((mlp_forward16_kernel<true>), dim3((unsigned)tiles), dim3(512), 0,
                        as_stream(stream), packed16, rows, z, P, S, raw);
     return check_launch();

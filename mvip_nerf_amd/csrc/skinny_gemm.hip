@@ -125,8 +125,11 @@ skinny_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ B, in
 // consecutive points of one output row: float4 stores, 512 B contiguous per half-wave.  The weights (<= 16 KB) are the
 // same for every wave: lane (m, kh) keeps W[32t + m][2s + kh] of all steps in registers (N/2 per row tile).
 // Exact fp32 (v_mfma_f32_32x32x2_f32, k-ordered accumulation).  RELU fuses the activation that follows the hidden layers.
+// Registers: NS weight values + 4 NS of X in flight + 64 TM accumulators.  Two waves per SIMD (256 registers each) hold that up to
+// TM = 1, NS = 16; the 64-input layers (NS = 32: 224 registers + addresses) and the two-tile form get the whole file -- with
+// the two-wave bound <1, 32> spilled 132 registers to scratch inside its point loop (round 4 build; tests/test_kernel_scratch.py).
 template <int TM, int NS, bool RELU>          // TM row tiles of 32, NS = N / 2 steps (N padded to 2 NS with zero weights)
-__global__ void __launch_bounds__(256, TM == 2 ? 1 : 2)
+__global__ void __launch_bounds__(256, (TM == 2 || NS == 32) ? 1 : 2)
 skinny_fwd_kernel(const float *__restrict__ Wt, int64_t w_sm, int64_t w_sn, const float *__restrict__ X, int M, int N,
                   int64_t P, float *__restrict__ Y) {
     const int lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5;

@@ -5,7 +5,9 @@ The hot path shards by RAY: every per-step ray set is split rank r -> indices r:
 renders and back-propagates its shard, and the only data-path collectives per step are
   * one all_gather of the rendered masked colours (<= 139 KB at 378x504) so every rank can run the
     image-space SDS term on the assembled frame, and
-  * one all_reduce(sum) of the flat 1,191,688-float gradient bucket of both MLPs (4.77 MB).
+  * one all_reduce(sum) of the flat 1,191,688-float gradient bucket of both MLPs (4.77 MB) -- since round 5 as TWO
+    asynchronous halves (`OverlappedGradBuckets`): the coarse network's half is on the wire while the backward of the
+    fine network's largest render (the masked set, created first and therefore back-propagated last) still runs.
 """
 import torch
 
@@ -66,12 +68,24 @@ def all_gather_blocks(local, n_total, rank, world, dist):
     if pad.shape[0] < per:
         pad = torch.cat([pad, pad.new_zeros((per - pad.shape[0],) + tuple(pad.shape[1:]))], 0)
     out = pad.new_empty((world * per,) + tuple(pad.shape[1:]))
-    try:
+    # The form of the collective is chosen UP FRONT from facts every rank shares (the backend's name and the API's presence), never
+    # by catching an error: a rank that failed inside one collective and then entered another would desynchronise its peers,
+    # and the original error would be lost.  Errors of the collective itself propagate.
+    if _flat_gather_ok(dist):
         dist.all_gather_into_tensor(out, pad)
-    except (RuntimeError, NotImplementedError, AttributeError):       # a backend without the flat form
-        parts = list(out.view((world, per) + tuple(pad.shape[1:])).unbind(0))
-        dist.all_gather(parts, pad)
+    else:
+        dist.all_gather(list(out.view((world, per) + tuple(pad.shape[1:])).unbind(0)), pad)
     return out[:n_total]
+
+
+def _flat_gather_ok(dist):
+    """all_gather_into_tensor exists and the backend is RCCL ("nccl" on ROCm); gloo and anything else take the list form."""
+    if not hasattr(dist, 'all_gather_into_tensor'):
+        return False
+    try:
+        return str(dist.get_backend()).lower() == 'nccl'
+    except (AttributeError, RuntimeError, ValueError):          # a stand-in `dist` of the tests, or no default group
+        return False
 
 
 class FlatGradBucket:
@@ -102,3 +116,102 @@ class FlatGradBucket:
         dist.all_reduce(self.flat)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+
+class OverlappedGradBuckets(FlatGradBucket):
+    """The same flat bucket cut into GROUPS of consecutive parameters (the trainer passes [coarse network, fine network]),
+    each all-reduced ASYNCHRONOUSLY as soon as every gradient of the group is final, i.e. while the rest of
+    loss.backward() still runs; `finish()` waits for the handles before the optimizer reads the gradients.
+
+    "Final" is told by torch's post-accumulate-grad hooks: the engine sums all uses of a leaf before its AccumulateGrad node
+    runs, so the hook fires once per parameter per backward.  The second-stage iteration's graph makes that useful: the
+    coarse network only receives a gradient through `rgb0` of the colour batch (DS_NeRF/run.py:1023; every other render
+    reaches it through detached depths, run.py:1812), whose nodes were created AFTER the masked render's and are therefore
+    back-propagated BEFORE it -- the coarse half is complete while the fine network's largest backward has not started.
+
+    Every rank issues the collectives in GROUP ORDER whatever its graph looks like (a rank whose colour shard is empty
+    never completes the coarse group in a hook): a group is launched from a hook only when all earlier groups have been
+    launched, everything else is launched by `finish()` in order.  Replaces the reference's nn.DataParallel gradient
+    reduction (DS_NeRF/run.py:1491, :1527).  Values are those of FlatGradBucket.all_reduce (a sum over ranks of the same
+    addends; tests/test_distributed_cpu.py compares the two bit for bit under gloo)."""
+
+    def __init__(self, params, group_sizes=None):
+        super().__init__(params)
+        n = len(self.params)
+        sizes = [n] if not group_sizes else list(group_sizes)
+        assert sum(sizes) == n and all(k > 0 for k in sizes), 'group_sizes must partition the parameter list'
+        self.group_of, self.bounds = [], []                  # parameter index -> group; group -> [lo, hi) in the flat bucket
+        o = k = 0
+        for g, cnt in enumerate(sizes):
+            lo = o
+            for _ in range(cnt):
+                self.group_of.append(g)
+                o += self.params[k].numel()
+                k += 1
+            self.bounds.append((lo, o))
+        self.group_sizes = sizes
+        self.dist = None
+        self._armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda q, i=i: self._ready(i)) for i, p in enumerate(self.params)]
+        self._reset()
+
+    def _reset(self):
+        self._pending = list(self.group_sizes)
+        self._seen = [False] * len(self.params)
+        self._launched = 0                                   # groups 0 .. _launched-1 are on the wire (or done)
+        self._handles = []
+        self.launched_in_backward = 0                        # diagnostics (tests, bench): groups whose reduce overlapped
+
+    def begin(self, dist, world):
+        """Call before loss.backward(); with world == 1 nothing is hooked up."""
+        self._reset()
+        self.dist, self._armed = dist, world > 1
+
+    def _launch(self, g, asynchronous=True):
+        lo, hi = self.bounds[g]
+        k0 = sum(self.group_sizes[:g])
+        for i in range(k0, k0 + self.group_sizes[g]):
+            p, v = self.params[i], self.views[i]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+        # device tensors over a transport other than RCCL (the several-ranks-on-one-GPU debug mode over gloo, where an
+        # asynchronous device-tensor collective faulted -- see sds_shard.evaluate) are reduced in place, blocking
+        if self.flat.is_cuda and str(self.dist.get_backend()).lower() != 'nccl':
+            torch.cuda.synchronize(self.flat.device)
+            asynchronous = False
+        self._handles.append(self.dist.all_reduce(self.flat[lo:hi], async_op=True) if asynchronous
+                             else self.dist.all_reduce(self.flat[lo:hi]))
+        self._launched = g + 1
+
+    def _ready(self, i):
+        if not self._armed or self._seen[i]:
+            return
+        self._seen[i] = True
+        g = self.group_of[i]
+        self._pending[g] -= 1
+        # launch every complete group that is next in order (a later group may have completed first: it waits its turn)
+        while self._launched < len(self.group_sizes) and self._pending[self._launched] == 0:
+            self._launch(self._launched)
+            self.launched_in_backward += 1
+
+    def finish(self):
+        """After loss.backward(): launch what the hooks could not (in order), wait, hand the reduced views back as .grad."""
+        if not self._armed:
+            return
+        self._armed = False
+        while self._launched < len(self.group_sizes):
+            self._launch(self._launched)
+        for h in self._handles:
+            if h is not None:
+                h.wait()
+        self._handles = []
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce(self, dist, world):
+        """FlatGradBucket's blocking form (kept for callers that do not bracket their backward with begin / finish)."""
+        if self._armed:
+            return self.finish()
+        return super().all_reduce(dist, world)

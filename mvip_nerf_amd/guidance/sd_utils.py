@@ -145,7 +145,11 @@ class _GraphedStep:
         # is put back afterwards, so that the first replay consumes exactly the draws an eager first step would have (measured:
         # replays equal eager steps to atomics-level, 2e-6 relative, draw for draw -- profiles/r4_graph_vs_eager_draws.json --
         # once the starting state is the same).
-        gen = sd.generator if sd.generator is not None else torch.cuda.default_generators[torch.device(dev).index or 0]
+        # the default generator of the device the draws are made on: a bare 'cuda' means the CURRENT device, not device 0
+        dev_index = torch.device(dev).index
+        if dev_index is None:
+            dev_index = torch.cuda.current_device()
+        gen = sd.generator if sd.generator is not None else torch.cuda.default_generators[dev_index]
         gen_state = gen.get_state()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()

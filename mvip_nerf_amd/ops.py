@@ -137,6 +137,14 @@ def mlp_pack_f16x3(params, packed_f32):
     return img
 
 
+def mlp_pack_f16x3_w16(params, packed_f32):
+    """Image for the two-waves-per-SIMD split-precision forward (csrc/mlp_fwd16_f16x3.hip); same size as the fp32 image."""
+    ps = [_f32c(p.detach()) for p in params]
+    img = torch.empty(packed_floats(), device=ps[0].device, dtype=_F32)
+    call('mvip_mlp_pack_f16x3_w16', _lib.ptr_array(ps), ptr(packed_f32), ptr(img), stream())
+    return img
+
+
 def mlp_unpack_grads(grad_packed, like):
     grads = [torch.empty(shp, device=grad_packed.device, dtype=_F32) for shp in PARAM_SHAPES]
     call('mvip_mlp_unpack_grads', ptr(grad_packed), _lib.ptr_array(grads), 0, stream())
@@ -300,13 +308,14 @@ class _MLPPoints(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, train16=None):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, train16=None, f16x3_w16=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
     routes the gradients back to them; with no grad needed the Function is skipped.
     `packed_f16x3` selects the split-precision kernel (precision = 1) for no-grad calls,
     `train_f16x3` (the same kind of image) for calls that will be back-propagated, `packed16` the exact-fp32
     two-waves-per-SIMD inference kernel (no-grad calls at precision 0), `train16` the same image for the stash-writing
-    training forward at precision 0."""
+    training forward at precision 0, `f16x3_w16` (ops.mlp_pack_f16x3_w16) the two-waves-per-SIMD split-precision kernel
+    for no-grad calls (takes precedence over `packed_f16x3`)."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
@@ -314,7 +323,9 @@ def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packe
         return _MLPRays.apply(rows, z, packed, 0, train16, *params)
     B, S = z.shape
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
-    if packed_f16x3 is not None:
+    if f16x3_w16 is not None:
+        call('mvip_mlp_forward_rays_f16x3_w16', ptr(f16x3_w16), ptr(rows), ptr(z), B, S, ptr(raw), stream())
+    elif packed_f16x3 is not None:
         call('mvip_mlp_forward_rays', ptr(packed_f16x3), ptr(rows), ptr(z), B, S, ptr(raw), 1, stream())
     elif packed16 is not None:
         call('mvip_mlp_forward_rays16', ptr(packed16), ptr(rows), ptr(z), B, S, ptr(raw), stream())
@@ -323,14 +334,16 @@ def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packe
     return raw
 
 
-def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None):
+def mlp_points(pts, dirs, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, f16x3_w16=None):
     pts, dirs = _f32c(pts), _f32c(dirs)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
             return _MLPPoints.apply(pts, dirs, train_f16x3, 1, *params)
         return _MLPPoints.apply(pts, dirs, packed, 0, *params)
     raw = torch.empty((pts.shape[0], 4), device=pts.device, dtype=_F32)
-    if packed_f16x3 is not None:
+    if f16x3_w16 is not None:
+        call('mvip_mlp_forward_points_f16x3_w16', ptr(f16x3_w16), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), stream())
+    elif packed_f16x3 is not None:
         call('mvip_mlp_forward_points', ptr(packed_f16x3), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), 1, stream())
     elif packed16 is not None:
         call('mvip_mlp_forward_points16', ptr(packed16), ptr(pts), ptr(dirs), pts.shape[0], ptr(raw), stream())

@@ -93,7 +93,8 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     return ret_list + [ret_dict]
 
 
-def render_sharded(H, W, focal, c2w, rank, world, dist, chunk=1024 * 32, near=0., far=1., row_fn=None, **kwargs):
+def render_sharded(H, W, focal, c2w, rank, world, dist, chunk=1024 * 32, ndc=True, near=0., far=1., use_viewdirs=False,
+                   c2w_staticcam=None, depths=None, row_fn=None, **kwargs):
     """ONE frame over all ranks (strong scaling; extension, no reference counterpart -- the reference's only multi-GPU
     mechanism is nn.DataParallel around the MLPs, DS_NeRF/run.py:1491, :1527): rank r renders the contiguous block
     dist_utils.block_bounds(H*W, r, world) of the frame's rays through batchify_rays (DS_NeRF/run.py:1127-1140, the loop
@@ -101,7 +102,10 @@ def render_sharded(H, W, focal, c2w, rank, world, dist, chunk=1024 * 32, near=0.
     Returns [rgb_map [H,W,3], disp_map [H,W], acc_map [H,W], depth_map [H,W]] -- render()'s first four outputs; the
     per-sample extras stay sharded (nobody reads them across ranks).  Rays of different blocks are independent, so the
     values equal render()'s (bit for bit when the chunk boundaries coincide; the kernels are chunk-invariant anyway,
-    tests/test_configs_large.py).  `row_fn(lo, hi)` overrides the ray-row source (CPU tests of the collective)."""
+    tests/test_configs_large.py).  ndc / near / far / use_viewdirs / c2w_staticcam / depths mean what they mean in
+    render() (same defaults): the view-direction, non-NDC, scalar-bounds case builds its block of ray rows in one launch,
+    every other case assembles the frame's rows as render() does (DS_NeRF/run.py:1182-1207) and takes the block.
+    `row_fn(lo, hi)` overrides the ray-row source (CPU tests of the collective)."""
     from .dist_utils import block_bounds, all_gather_blocks
     n = H * W
     lo, hi = block_bounds(n, rank, world)
@@ -109,9 +113,18 @@ def render_sharded(H, W, focal, c2w, rank, world, dist, chunk=1024 * 32, near=0.
         rows = row_fn(lo, hi)
     else:
         c2w = torch.as_tensor(c2w)
-        sel = torch.arange(lo, hi, device=c2w.device, dtype=torch.int64)
-        rows = ops.ray_rows_from_pose(c2w, H, W, focal, near, far, sel=sel)
-    kwargs = {k: v for k, v in kwargs.items() if k not in ('use_viewdirs', 'ndc')}
+        scalar_bounds = not torch.is_tensor(near) and not torch.is_tensor(far)
+        if use_viewdirs and not ndc and depths is None and c2w_staticcam is None and scalar_bounds:      # render()'s `fast`
+            sel = torch.arange(lo, hi, device=c2w.device, dtype=torch.int64)
+            rows = ops.ray_rows_from_pose(c2w, H, W, focal, near, far, sel=sel)
+        else:
+            rays_o, rays_d = ops.get_rays(H, W, focal, c2w)
+            if torch.is_tensor(near):
+                near = near.reshape(-1, 1)
+            if torch.is_tensor(far):
+                far = far.reshape(-1, 1)
+            rows = _assemble_rows_general(H, W, focal, rays_o, rays_d, ndc, near, far, use_viewdirs, c2w_staticcam,
+                                          depths)[lo:hi].contiguous()
     if rows.shape[0] > 0:
         ret = batchify_rays(rows, chunk, **kwargs)
         local = torch.cat([ret['rgb_map'], ret['disp_map'][:, None], ret['acc_map'][:, None], ret['depth_map'][:, None]], -1)

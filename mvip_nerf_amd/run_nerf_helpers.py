@@ -73,6 +73,9 @@ class NeRF(nn.Module):
         self._packed16_key = None
         self._packed_w16 = None
         self._packed_w16_key = None
+        self._packed_hw16 = None
+        self._packed_hw16_key = None
+        self.two_wave_f16x3 = True        # no-grad split-precision forwards use csrc/mlp_fwd16_f16x3.hip (two waves per SIMD)
         self.two_wave_inference = True    # no-grad fp32 forwards use csrc/mlp_fwd16.hip (two waves per SIMD)
         self.two_wave_training = True     # ... and so does the stash-writing fp32 training forward from ray rows
         # 0: exact fp32 MFMA.  1: split-precision fp16 MFMA ("f16x3", ~1e-6 relative, fp32 accumulate).
@@ -93,6 +96,7 @@ class NeRF(nn.Module):
         self._packed = self._packed_key = None
         self._packed16 = self._packed16_key = None
         self._packed_w16 = self._packed_w16_key = None
+        self._packed_hw16 = self._packed_hw16_key = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -138,6 +142,14 @@ class NeRF(nn.Module):
             self._packed_w16_key = self._packed_key
         return self._packed_w16
 
+    def packed_f16x3_w16(self):
+        """Image of the two-waves-per-SIMD split-precision inference kernel (csrc/mlp_fwd16_f16x3.hip)."""
+        packed = self.packed()
+        if self._packed_hw16 is None or self._packed_hw16_key != self._packed_key:
+            self._packed_hw16 = ops.mlp_pack_f16x3_w16(self.param_list(), packed)
+            self._packed_hw16_key = self._packed_key
+        return self._packed_hw16
+
     def _infer16(self):
         no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
         return self.packed_w16() if (self.two_wave_inference and no_grad and self.inference_precision == 0) else None
@@ -149,16 +161,20 @@ class NeRF(nn.Module):
     def _fast_image(self):
         return self.packed_f16x3() if self.inference_precision == 1 else None
 
+    def _fast_image_w16(self):
+        no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        return self.packed_f16x3_w16() if (self.inference_precision == 1 and self.two_wave_f16x3 and no_grad) else None
+
     def _train_image(self):
         return self.packed_f16x3() if self.train_precision == 1 else None
 
     def query_points(self, pts, dirs):
         return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
-                              self._infer16())
+                              self._infer16(), self._fast_image_w16())
 
     def query_rays(self, rows, z):
         return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
-                            self._infer16(), self._train16())
+                            self._infer16(), self._train16(), self._fast_image_w16())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

@@ -31,12 +31,13 @@ after which every rank applies the identical Adam update.  Shard losses are weig
 reduced gradient is the single-process one for any shard sizes.
 """
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import ops, run, sds_shard
-from .dist_utils import shard, all_gather_ragged, FlatGradBucket
+from .dist_utils import shard, all_gather_ragged, FlatGradBucket, OverlappedGradBuckets
 from .run_nerf_helpers import img2mse
 
 
@@ -86,7 +87,14 @@ class SecondStageTrainer:
         self.guidance = guidance                       # Pretrain_Model-like object with cal_loss(), or None
         self.rng = np.random.RandomState(1234)         # same draw on every rank (view choice must agree)
         self.N_rand = args.N_rand
-        self.bucket = FlatGradBucket(self.grad_vars)
+        # one flat bucket, reduced as two asynchronous halves [coarse network | fine network] (dist_utils.OverlappedGradBuckets);
+        # MVIP_OVERLAP_ALLREDUCE=0 restores the single blocking all_reduce after the backward (A/B switch, same values)
+        n_coarse = len(list(self.kw_train['network_fn'].parameters())) if self.kw_train.get('network_fn') is not None else 0
+        if (world > 1 and os.environ.get('MVIP_OVERLAP_ALLREDUCE', '1') != '0' and 0 < n_coarse < len(self.grad_vars)
+                and hasattr(torch.nn.Parameter, 'register_post_accumulate_grad_hook')):
+            self.bucket = OverlappedGradBuckets(self.grad_vars, [n_coarse, len(self.grad_vars) - n_coarse])
+        else:
+            self.bucket = FlatGradBucket(self.grad_vars)
         # SDS terms owned by different ranks (sds_shard); None = whenever there is more than one rank
         self.view_shard = (world > 1) if view_shard is None else bool(view_shard)
         if world > 1:                                  # identical initial weights on every rank
@@ -161,7 +169,7 @@ class SecondStageTrainer:
         return torch.stack(rgbs, 0).permute(0, 3, 1, 2), masks.float().unsqueeze(1), n
 
     def _allreduce_grads(self):
-        self.bucket.all_reduce(self.dist, self.world)      # ONE 4.77 MB bucket over RCCL/xGMI
+        self.bucket.all_reduce(self.dist, self.world)      # the 4.77 MB bucket over RCCL/xGMI (waits for the async halves)
 
     # -- the SDS terms, owned by different ranks ----------------------------------------------------------------
     def _sds_view_sharded(self, i, combin_rgb, mask, normal_map, rgbs4, mask4):
@@ -278,6 +286,8 @@ class SecondStageTrainer:
             # iteration to have the reference's cost structure: a plain colour loss stands in
             wm = sel.numel() / max(masked_idx.numel(), 1)
             loss = loss + args.sds_loss_weight * img2mse(rgb_masked, sc.images[img_i].reshape(-1, 3)[sel]) * wm
+        if isinstance(self.bucket, OverlappedGradBuckets):
+            self.bucket.begin(self.dist, self.world)       # the coarse half is reduced while the masked render's backward runs
         loss.backward()
         self._allreduce_grads()
         self.optimizer.step()

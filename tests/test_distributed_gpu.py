@@ -231,6 +231,7 @@ def test_bench_two_ranks_on_one_device_reports_strong_scaling(cuda):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 1
     assert d['value'] > 0 and d['weak_rays_per_sec'] > 0 and d['value_1_same_run'] > 0
-    assert 0 < d['strong_efficiency'] < 1.5
+    # both ranks time-share ONE device here: the line must say so and claim no scaling efficiency for it
+    assert d['ranks_share_one_device'] is True and d['strong_efficiency'] is None
     assert d['multi_gpu']['rccl_world'] == 2
     assert d['metric'].startswith('rays_per_sec') and d['unit'] == 'rays/s'

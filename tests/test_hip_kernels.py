@@ -458,6 +458,44 @@ def test_mlp_forward_f16x3_accuracy(golden, cuda):
     np.testing.assert_allclose(r16, g['out'], rtol=5e-5, atol=5e-6)
 
 
+def test_mlp_forward_f16x3_two_wave_accuracy(golden, cuda):
+    """The two-waves-per-SIMD split-precision forward (csrc/mlp_fwd16_f16x3.hip: 16 points per wave on
+    v_mfma_f32_16x16x32_f16, round 5) against the fp64 evaluation of the same network (NeRF.forward,
+    DS_NeRF/run_nerf_helpers.py:104-127): the same bound as the 32-point split-precision kernel, and the reference's golden
+    output; points API and rays API (both ring geometries), ray counts that leave partly filled workgroups and tiles."""
+    import os
+    from mvip_nerf_amd import ops
+    from mvip_nerf_amd._lib import ptr, stream, call
+    g = golden('mlp_fwd_bwd')
+    ps = params_dev(g['seed'], cuda)
+    packed = ops.mlp_pack(ps)
+    p16, pw = ops.mlp_pack_f16x3(ps, packed), ops.mlp_pack_f16x3_w16(ps, packed)
+    pts, dirs = T(g['pts'], cuda), T(g['dirs'], cuda)
+    with torch.no_grad():
+        r32 = N(ops.mlp_points(pts, dirs, packed, ps))
+        r16 = N(ops.mlp_points(pts, dirs, packed, ps, packed_f16x3=p16))
+        rw = N(ops.mlp_points(pts, dirs, packed, ps, f16x3_w16=pw))
+    sd64 = {k: torch.from_numpy(v).double() for k, v in params_np(g['seed']).items()}
+    ref = O.mlp_forward(sd64, torch.from_numpy(g['emb']).double()).numpy()
+    scale = np.abs(ref).max()
+    ew, e16 = np.abs(rw - ref).max(), np.abs(r16 - ref).max()
+    assert ew < 8e-6 * scale, (ew, e16, np.abs(r32 - ref).max(), scale)
+    np.testing.assert_allclose(rw, g['out'], rtol=5e-5, atol=5e-6)
+    # rays API against the exact-fp32 two-wave kernel: ragged ray counts (a lone ray, a partly filled last workgroup, several
+    # workgroups per CU), 64 and 128 samples; every output written (the buffer starts as NaN)
+    p16f = ops.mlp_pack16(ps, packed)
+    for B_ in (1, 37, 700, 2049):
+        rows_b = torch.from_numpy(bench_like_rays(B_, seed=B_)).float().to(cuda)
+        for S_ in (64, 128):
+            z_b = ops.stratified_z(rows_b, S_, True)
+            ref32 = torch.empty(B_, S_, 4, device=cuda)
+            got = torch.full((B_, S_, 4), float('nan'), device=cuda)
+            call('mvip_mlp_forward_rays16', ptr(p16f), ptr(rows_b), ptr(z_b), B_, S_, ptr(ref32), stream())
+            call('mvip_mlp_forward_rays_f16x3_w16', ptr(pw), ptr(rows_b), ptr(z_b), B_, S_, ptr(got), stream())
+            assert torch.isfinite(got).all(), (B_, S_)
+            np.testing.assert_allclose(N(got), N(ref32), rtol=5e-5, atol=1e-5 * float(ref32.abs().max()), err_msg=f'{B_} {S_}')
+
+
 def test_render_f16x3_matches_fp32_render(cuda):
     from mvip_nerf_amd import run
     import types as _t
@@ -548,18 +586,6 @@ def test_mlp_forward_two_waves_per_simd_kernel(golden, cuda):
         r16 = ops.mlp_rays(rows, z, packed, ps, packed16=p16)
         r32 = ops.mlp_rays(rows, z, packed, ps)
     np.testing.assert_allclose(N(r16), N(r32), rtol=2e-5, atol=2e-6)
-    # the persistent form (one workgroup per CU looping over its tiles; an A/B alternative, round 4): the same bits, for ray
-    # counts that give the 256 workgroups 0, 1 and several tiles each and a ragged last tile
-    from mvip_nerf_amd._lib import ptr, stream, call
-    for B_ in (37, 700, 2049):
-        rows_b = torch.from_numpy(bench_like_rays(B_, seed=B_)).float().to(cuda)
-        for S_ in (64, 128):
-            z_b = ops.stratified_z(rows_b, S_, True)
-            ref = torch.empty(B_, S_, 4, device=cuda)
-            per = torch.full((B_, S_, 4), float('nan'), device=cuda)
-            call('mvip_mlp_forward_rays16', ptr(p16), ptr(rows_b), ptr(z_b), B_, S_, ptr(ref), stream())
-            call('mvip_mlp_forward_rays16_persistent', ptr(p16), ptr(rows_b), ptr(z_b), B_, S_, ptr(per), stream())
-            assert torch.equal(ref, per), (B_, S_)
 
 
 def test_two_wave_training_forward_stash(golden, cuda):

@@ -97,9 +97,11 @@ def test_pose_processing_on_fixture_poses(golden):
     assert g['render_poses'].shape == (120, 3, 5)
 
 
-def test_bench_launcher_spawns_ranks_itself():
+@pytest.mark.parametrize('n', [2, 8])
+def test_bench_launcher_spawns_ranks_itself(n):
     """`bench.py --gpus N` with no WORLD_SIZE starts N ranks before touching a GPU and relays ONE JSON line with
-    n_gpus = N (launcher-only dry run over gloo); under an external launcher a mismatching --gpus fails loudly."""
+    n_gpus = N (launcher-only dry run over gloo; N = 8 is the full node the driver's scaling run uses); under an
+    external launcher a mismatching --gpus fails loudly."""
     import json
     import os
     import subprocess
@@ -107,15 +109,17 @@ def test_bench_launcher_spawns_ranks_itself():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env['MVIP_BENCH_DRYRUN'] = '1'
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
-                         env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == n
     rec = json.loads(lines[0])
     # the N > 1 headline is the STRONG-scaling form: the dry run passed a frame of ray rows through run.render_sharded
     # (contiguous blocks, one all_gather) on both ranks and says so
     assert rec['scaling'] == 'strong' and rec['sharded_frame_assembled'] is True and 'weak_rays_per_sec' in rec
+    if n != 2:
+        return
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3'], env=dict(env, WORLD_SIZE='2', RANK='0'),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr
@@ -188,3 +192,39 @@ def test_latent_distribution_and_timestep_embedding_host_paths():
     args = t[:, None] * torch.exp(-math.log(10000.0) * k / 160)[None]
     assert emb.shape == (2, 320)
     assert torch.allclose(emb[:, :160], torch.cos(args), atol=1e-6) and torch.allclose(emb[:, 160:], torch.sin(args), atol=1e-6)
+
+
+def test_scaling_model_predictions():
+    """mvip_nerf_amd/scaling_model.py (VERDICT r4 task 4a): the per-leg time model bench.py emits as multi_gpu.predicted.
+    Checked here: the collective formulas, the replay of sds_shard's ownership (configs[3]: 7 terms; at 8 ranks the critical
+    path is one forward-only term + the term that waits for the latent sum), monotonic legs, and the hook in bench.py."""
+    import json
+    import bench
+    from mvip_nerf_amd import scaling_model as sm
+    c = dict(sm.DEFAULTS)
+    bw = c['link_GBps'] * 1e9 * c['link_efficiency']
+    assert sm.collective_ms('all_reduce', 8e6, 1) == 0.0
+    assert abs(sm.collective_ms('all_reduce', 8e6, 8) - ((c['alpha_us'] + 14 * c['hop_us']) * 1e-3 + 2 * 7 / 8 * 8e6 / bw * 1e3)) < 1e-9
+    assert abs(sm.collective_ms('all_gather', 8e6, 4) - ((c['alpha_us'] + 3 * c['hop_us']) * 1e-3 + 3 / 4 * 8e6 / bw * 1e3)) < 1e-9
+    terms = sm.config_terms(3)
+    assert len(terms) == 7 and sum(1 for p, _ in terms if p == 1) == 4
+    t_full, t_fwd = 20.0, 15.0
+    one = sm.sds_critical_path_ms(terms, 1, t_full, t_fwd, 0)
+    assert abs(one - (4 * t_fwd + 3 * t_full)) < 1e-9                       # one GPU: back to back
+    eight = sm.sds_critical_path_ms(terms, 8, t_full, t_fwd, 0)
+    assert t_fwd + t_full < eight < t_fwd + t_full + 0.2                     # forward-only term, 64 KB all_reduce, the waiting term
+    two = sm.sds_critical_path_ms(terms, 2, t_full, t_fwd, 0)
+    assert abs(two - (2 * t_fwd + 2 * t_full)) < 0.2                         # rank 0: two latent terms, rgb, the last view
+    m = {'frame_ms': 300.0, 'train_ms': 54.0, 'sds_ms': 21.0, 'config2_ms': 160.0, 'config3_ms': 440.0}
+    p = sm.predict(m, fwd_share=0.775)
+    for key in ('ms_per_step', 'train_ms', 'train_with_sds_ms', 'config2_ms', 'config3_ms'):
+        vals = [p['N'][n][key] for n in (2, 4, 8)]
+        assert vals[0] > vals[1] > vals[2] > 0, (key, vals)
+    assert 0.97 < p['N'][8]['strong_efficiency'] < 1.0 and p['N'][8]['value'] > 7.5 * 378 * 504 / 0.3
+    # the prior's terms do not shard below one term per rank: configs[1] cannot scale past ~3x, configs[3] past ~10x
+    assert p['scaling_ceiling']['train_with_sds_ms']['max_speedup'] < 3.5 < p['scaling_ceiling']['config3_ms']['max_speedup']
+    line = {'ms_per_step': 300.0, 'train': {'ms_per_step': 54.0}, 'sds': {'ms_per_step': 21.0},
+            'config2_rgb_normal_sds': {'ms_per_step': 160.0}, 'config3_rgb_normal_colla_sds': {'ms_per_step': 440.0}}
+    bench.add_scaling_prediction(line, 1)
+    assert sorted(line['multi_gpu']['predicted']['N']) == [2, 4, 8]
+    json.dumps(line)

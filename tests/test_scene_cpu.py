@@ -69,7 +69,7 @@ def _toy_terms(w, x, n_latent=3):
     frames = [torch.tanh(x[k] @ w).reshape(1, 3, 4, 5) for k in range(3)]
     g = torch.Generator().manual_seed(0)
     K = [torch.randn(1, 3, 4, 5, generator=g) for _ in range(3)]
-    Lt = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(3)]
+    Lt = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(max(3, n_latent))]
 
     def image_term(k, share):
         f = frames[k].detach().clone().requires_grad_(True)
@@ -133,3 +133,24 @@ def test_view_sharded_terms_single_neighbour_view(tmp_path):
     for r in range(2):
         got = torch.load(os.path.join(str(tmp_path), f'w2r{r}.pt'))
         np.testing.assert_allclose(got['grad'].numpy(), ref['grad'].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_seven_terms_over_eight_ranks(tmp_path):
+    """configs[3] on a full node: 7 SDS terms (RGB, normal, the collaborative term's last view + 4 latent shares) over 8
+    ranks (VERDICT r4 task 4c).  Ownership is round-robin, so rank 7 owns NOTHING: it contributes zeros to the latent
+    all_reduce, receives the three image-gradient broadcasts, and ends with the same surrogate gradient as everybody
+    else; every term is evaluated exactly once across the node."""
+    from mvip_nerf_amd import sds_shard
+    world = 8
+    _shard_worker(0, 1, 0, str(tmp_path), 4)
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path), 4), nprocs=world, join=True)
+    ref = torch.load(os.path.join(str(tmp_path), 'w1r0.pt'))
+    assert len(ref['calls']) == 7
+    owned = []
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f'w{world}r{r}.pt'))
+        np.testing.assert_allclose(got['grad'].numpy(), ref['grad'].numpy(), rtol=1e-5, atol=1e-6)
+        assert len(got['calls']) == (1 if r < 7 else 0), (r, got['calls'])      # one term per rank, the eighth rank idle
+        owned += got['calls']
+    assert sorted(owned) == sorted(ref['calls'])
+    assert [sds_shard.owner_of(k, world) for k in range(7)] == list(range(7))
