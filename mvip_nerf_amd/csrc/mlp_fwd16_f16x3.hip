@@ -99,6 +99,13 @@ struct StreamH {
 // fp32 activation quad -> the hi / lo halves at elements 4 HALF .. 4 HALF + 3 of the fragment pair
 template <int HALF>
 __device__ __forceinline__ void split_into(const f32x4 &v, h16x8 &hi, h16x8 &lo) {
+#ifdef MVIP_EXPERIMENT_F16W16_NO_SPLIT                                          // timing experiment only: bits moved, nothing converted
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 &H = reinterpret_cast<u32x4 &>(hi), &L = reinterpret_cast<u32x4 &>(lo);
+    H[2 * HALF] = __builtin_bit_cast(unsigned, v[0]); H[2 * HALF + 1] = __builtin_bit_cast(unsigned, v[1]);
+    L[2 * HALF] = __builtin_bit_cast(unsigned, v[2]); L[2 * HALF + 1] = __builtin_bit_cast(unsigned, v[3]);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const _Float16 hv = (_Float16)v[i];
@@ -107,14 +114,82 @@ __device__ __forceinline__ void split_into(const f32x4 &v, h16x8 &hi, h16x8 &lo)
     }
 }
 
+// NaN-preserving ReLU of one value (one integer max; see mlp_device.h)
+__device__ __forceinline__ float relu1(float v) {
+    const int bits = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, bits > 0 ? bits : 0);
+}
+
+// The epilogue of an output tile in STAGES of two vector instructions.  The SIMD has ONE vector issue port: a 16x16x32 MFMA holds
+// it for 8 of its 16 cycles, so a gap between two MFMAs hides ~8 cycles of other vector work (MI355X_MICROARCH.md, row
+// "vector-instruction ISSUE cost") -- and the unstaged epilogue, a burst of ~20 conversions per tile wherever the compiler
+// put it, cost this kernel 16 % (tools/micro/f16w16_variants.hip: 60.1 ms with, 50.5 ms without the conversions).  Staged,
+// layer_h places one stage per MFMA gap of the NEXT tile.
+//   S0, S1  v = relu(acc)            S2  hi = f16(v)            S3, S4  r = v - f32(hi)  (one v_fma_mix_f32 each: the
+//   conversion back is the instruction's own operand widening)            S5  lo = f16(r)
+// The stages are INLINE ASSEMBLY: as plain expressions the compiler's instruction selection gathers all of them in front of the
+// first use of the finished fragment (one burst again, whatever sched_barrier says about the order of the MFMAs around it),
+// turns the residual into a packed v_pk_add_f32 (an anti-lever beside MFMAs, same table) and converts hi back with two
+// instructions; volatile asm statements keep their order relative to the operand reads and waits of the k-step.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int HALF, bool RELU, int S>
+__device__ __forceinline__ void split_stage(const f32x4 &acc, f32x4 &v, f32x4 &r, h16x8 &hi, h16x8 &lo) {
+    if constexpr (S == 0 || S == 1) {
+        constexpr int i0 = 2 * S;
+        float t0, t1;
+        if constexpr (RELU)
+            asm volatile("v_max_i32 %0, 0, %2\n\tv_max_i32 %1, 0, %3" : "=&v"(t0), "=&v"(t1) : "v"(acc[i0]), "v"(acc[i0 + 1]));
+        else
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(t0), "=&v"(t1) : "v"(acc[i0]), "v"(acc[i0 + 1]));
+        v[i0] = t0; v[i0 + 1] = t1;
+    }
+    if constexpr (S == 2) {
+        unsigned h0, h1;
+        asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5" : "=&v"(h0), "=&v"(h1)
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        u32x4 H = __builtin_bit_cast(u32x4, hi);
+        H[2 * HALF] = h0; H[2 * HALF + 1] = h1;
+        hi = __builtin_bit_cast(h16x8, H);
+    }
+    if constexpr (S == 3 || S == 4) {                    // r = v - f32(hi): the f16 operand is widened by the instruction itself
+        constexpr int i0 = 2 * (S - 3);
+        const unsigned hp = __builtin_bit_cast(u32x4, hi)[2 * HALF + (S - 3)];
+        float t0, t1;
+        asm volatile("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(t0), "=&v"(t1) : "v"(hp), "v"(v[i0]), "v"(v[i0 + 1]));
+        r[i0] = t0; r[i0 + 1] = t1;
+    }
+    if constexpr (S == 5) {
+        unsigned l0, l1;
+        asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5" : "=&v"(l0), "=&v"(l1)
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+        u32x4 L = __builtin_bit_cast(u32x4, lo);
+        L[2 * HALF] = l0; L[2 * HALF + 1] = l1;
+        lo = __builtin_bit_cast(h16x8, L);
+    }
+}
+// acc += a0 * b0; acc += a1 * b1 (fused, in this order), pinned in place
+__device__ __forceinline__ void fmac2(float &acc, float a0, float b0, float a1, float b1) {
+    asm volatile("v_fmac_f32 %0, %1, %2\n\tv_fmac_f32 %0, %3, %4" : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+__device__ __forceinline__ void relu2(float &o0, float &o1, float i0, float i1) {
+    asm volatile("v_max_i32 %0, 0, %2\n\tv_max_i32 %1, 0, %3" : "=&v"(o0), "=&v"(o1) : "v"(i0), "v"(i1));
+}
+
 // One layer: NTO output tiles of 16 units x KS k-steps of 32 input units; BASE = absolute index of the layer's first block.
-// bsrc(ks) -> (hi, lo) B fragments of k-step ks; epi(to, acc) consumes a finished tile (the bias is already in it: it enters as
-// the C operand of the tile's first MFMA).  a0 / a1 carry the A fragments of the current and the next k-step across tiles and
-// layers, `bias` the bias quad of the NEXT tile to start (read one tile ahead; NEXT_BIAS = section-B offset of the bias vector
-// of the layer after this one, whose first quad this layer's last tile fetches, or -1).
-template <int BASE, int NTO, int KS, bool LAST, int BIAS, int NEXT_BIAS, class St, class BSrc, class Epi>
+// bsrc(ks) -> (hi, lo) B fragments of k-step ks.  epi(to, stage, acc) runs stage `stage` (0 .. NS - 1) of the epilogue of the
+// finished tile `to` (the bias is already in acc: it enters as the C operand of the tile's first MFMA); the stages of tile
+// to - 1 are placed one per MFMA gap of tile `to`, from its second k-step on: stage s < LATE in gap s, stage s >= LATE in gap
+// 6 + (s - LATE) (the stages that consume section-B values their stage 0 asked for by asynchronous read: two k-step waits
+// later those have landed).  a0 / a1 carry the A fragments of the current and the next k-step across tiles and layers, `bias`
+// the bias quad of the NEXT tile to start (read one tile ahead; NEXT_BIAS = section-B offset of the bias vector of the layer
+// after this one, whose first quad this layer's last tile fetches, or -1).
+template <int BASE, int NTO, int KS, bool LAST, int BIAS, int NEXT_BIAS, int NS, int LATE, class St, class BSrc, class Epi>
 __device__ __forceinline__ void layer_h(const St &st, APairH &a0, APairH &a1, f32x4 &bias, BSrc bsrc, Epi epi) {
     constexpr int CHB = St::chb;
+    constexpr int GAPS = 3 * (KS - 1);                                          // MFMA gaps of a tile after its first k-step
+    constexpr int PER = LATE < NS ? 1 : (NS + GAPS - 1) / GAPS;                 // stages per gap (2 in layer 0: two k-steps per tile)
+    static_assert(LATE >= NS || (LATE <= 6 && 6 + (NS - LATE) <= GAPS), "late stages need k-steps 3 ...");
     f32x4 accs[2];
     static_for<NTO>([&](auto to_) {
         constexpr int TO = decltype(to_)::value;
@@ -123,9 +198,19 @@ __device__ __forceinline__ void layer_h(const St &st, APairH &a0, APairH &a1, f3
             constexpr int K = decltype(ks_)::value;
             constexpr int bi = BASE + 2 * (TO * KS + K);                       // the Ah block of this k-step
             constexpr int left = LAST ? (NTO * KS - (TO * KS + K) - 1) : 1000; // k-steps after this one in the whole stream
+            auto gap = [&](auto m_) {                                           // the epilogue stages that belong into gap (K, m)
+                if constexpr (TO > 0 && K >= 1) {
+                    constexpr int q = 3 * (K - 1) + decltype(m_)::value;
+                    static_for<PER>([&](auto r_) {
+                        constexpr int e = q * PER + decltype(r_)::value;        // early numbering: stage e in gap e / PER
+                        if constexpr (e < LATE && e < NS) epi(ic<TO - 1>{}, ic<e>{}, accs[(TO - 1) & 1]);
+                    });
+                    if constexpr (q >= 6 && LATE + (q - 6) < NS) epi(ic<TO - 1>{}, ic<LATE + (q - 6)>{}, accs[(TO - 1) & 1]);
+                }
+            };
             if constexpr (bi % CHB == 0) st.template issue_chunk<bi / CHB + 2>();
             // a0 must have landed; the two reads issued one k-step ago (a1) may still be in flight.  LDS operations complete
-            // in order, so "at most two outstanding" also covers the bias quad issued before them.
+            // in order, so "at most two outstanding" also covers the bias quad (and an epilogue's section-B quads) issued before them.
             if constexpr (left >= 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0.h), "+v"(a0.l), "+v"(bias));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0.h), "+v"(a0.l), "+v"(bias));
             if constexpr (K == 0) acc = bias;
@@ -138,16 +223,31 @@ __device__ __forceinline__ void layer_h(const St &st, APairH &a0, APairH &a1, f3
                 else if constexpr (NEXT_BIAS >= 0) bias = st.template read_sb_async<NEXT_BIAS>();
             }
             if constexpr (left >= 2) a2 = APairH{st.template read_async<bi + 4>(), st.template read_async<bi + 5>()};
+            gap(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
             acc = mfma32(a0.h, b.lo, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            gap(ic<1>{});
+            __builtin_amdgcn_sched_barrier(0);
             acc = mfma32(a0.l, b.hi, acc);
-            if constexpr (K == KS - 1) asm volatile("" : "+v"(acc));            // keep the tile's chain inside the tile
+            __builtin_amdgcn_sched_barrier(0);
+            gap(ic<2>{});
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef MVIP_EXPERIMENT_F16W16_NO_BARRIER                                       // timing experiment only: results are wrong without it
             if constexpr ((bi + 2) % CHB == 0) __syncthreads();                 // chunk consumed; the one after next has landed
+#endif
             a0 = a1; a1 = a2;
-            if constexpr (TO > 0 && K == 1) epi(ic<TO - 1>{}, accs[(TO - 1) & 1]);
         });
     });
-    epi(ic<NTO - 1>{}, accs[(NTO - 1) & 1]);
+    // the last tile's epilogue has no next tile of this layer to hide under (once per layer); what its early stages asked
+    // section B for must have landed before the late ones run
+    // (inline assembly reads the accumulators: the compiler's hazard pass does not pace it behind the last MFMA)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accs[(NTO - 1) & 1]));
+    static_for<NS>([&](auto s_) {
+        if constexpr (decltype(s_)::value == LATE)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0.h), "+v"(a0.l), "+v"(a1.h), "+v"(a1.l), "+v"(bias));
+        epi(ic<NTO - 1>{}, s_, accs[(NTO - 1) & 1]);
+    });
 }
 
 template <bool FROM_RAYS, int CHB, int NSL>
@@ -188,8 +288,12 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         f32x4 q0, q1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#ifdef MVIP_EXPERIMENT_F16W16_NO_ENCODING                                       // timing experiment only (no sin / cos)
+            q0[i] = px * (float)(i + 1); q1[i] = py * (float)(i + 1);
+#else
             q0[i] = f16p::enc_channel<63>(px, py, pz, 32 * s + 4 * g + i);
             q1[i] = f16p::enc_channel<63>(px, py, pz, 32 * s + 16 + 4 * g + i);
+#endif
         }
         split_into<0>(q0, emb_h[s], emb_l[s]);
         split_into<1>(q1, emb_h[s], emb_l[s]);
@@ -202,46 +306,52 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
     APairH a1{st.template read_async<2>(), st.template read_async<3>()};
 
     h16x8 h_h[8], h_l[8], o_h[8], o_l[8];
+    f32x4 ev, er;                                       // epilogue state between stages: relu'd tile, residual
     // layer 0: 63(+1) -> 256
-    layer_h<OFF_L0, 16, KS_L0, false, SB_BIAS, SB_BIAS + 256>(st, a0, a1, bias,
+    layer_h<OFF_L0, 16, KS_L0, false, SB_BIAS, SB_BIAS + 256, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{emb_h[ks.value], emb_l[ks.value]}; },
-        [&](auto to, const f32x4 &acc) { split_into<to.value & 1>(act16<true>(acc), o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     // layers 1..4
     static_for<4>([&](auto li) {
         constexpr int l = 1 + decltype(li)::value;
-        layer_h<OFF_L1 + (l - 1) * LH_BLOCKS, 16, KS_LH, false, SB_BIAS + l * 256, SB_BIAS + (l + 1) * 256>(st, a0, a1, bias,
+        layer_h<OFF_L1 + (l - 1) * LH_BLOCKS, 16, KS_LH, false, SB_BIAS + l * 256, SB_BIAS + (l + 1) * 256, 6, 6>(st, a0, a1, bias,
             [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-            [&](auto to, const f32x4 &acc) { split_into<to.value & 1>(act16<true>(acc), o_h[to.value >> 1], o_l[to.value >> 1]); });
+            [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
 #pragma unroll
         for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     });
     // layer 5: cat[encoded point (64), h4 (256)] -> 256
-    layer_h<OFF_L5, 16, KS_L5, false, SB_BIAS + 5 * 256, SB_BIAS + 6 * 256>(st, a0, a1, bias,
+    layer_h<OFF_L5, 16, KS_L5, false, SB_BIAS + 5 * 256, SB_BIAS + 6 * 256, 6, 6>(st, a0, a1, bias,
         [&](auto ks) {
             if constexpr (ks.value < 2) return BPairH{emb_h[ks.value], emb_l[ks.value]};
             else return BPairH{h_h[ks.value - 2], h_l[ks.value - 2]};
         },
-        [&](auto to, const f32x4 &acc) { split_into<to.value & 1>(act16<true>(acc), o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     // layer 6
-    layer_h<OFF_L6, 16, KS_LH, false, SB_BIAS + 6 * 256, SB_BIAS + 7 * 256>(st, a0, a1, bias,
+    layer_h<OFF_L6, 16, KS_LH, false, SB_BIAS + 6 * 256, SB_BIAS + 7 * 256, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-        [&](auto to, const f32x4 &acc) { split_into<to.value & 1>(act16<true>(acc), o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
-    // layer 7; sigma = alpha_linear(h7) accumulated in fp32 from the fp32 activations, tile by tile
+    // layer 7; sigma = alpha_linear(h7) accumulated in fp32 from the fp32 activations, tile by tile: stage 0 also asks for the
+    // tile's quad of the sigma row, stages 6 and 7 (two k-steps later) consume it
     float sigma = 0.f;
-    layer_h<OFF_L6 + LH_BLOCKS, 16, KS_LH, false, SB_BIAS + 7 * 256, SB_BFEAT>(st, a0, a1, bias,
+    f32x4 wq;
+    layer_h<OFF_L6 + LH_BLOCKS, 16, KS_LH, false, SB_BIAS + 7 * 256, SB_BFEAT, 8, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-        [&](auto to, const f32x4 &acc) {
-            const f32x4 v = act16<true>(acc);
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(sb + SB_WALPHA + 16 * to.value + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sigma = fmaf(w[i], v[i], sigma);
-            split_into<to.value & 1>(v, o_h[to.value >> 1], o_l[to.value >> 1]);
+        [&](auto to, auto sg, const f32x4 &acc) {
+            constexpr int S_ = decltype(sg)::value;
+            if constexpr (S_ == 0) wq = st.template read_sb_async<SB_WALPHA + 16 * decltype(to)::value>();
+            if constexpr (S_ < 6) split_stage<to.value & 1, true, S_>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (S_ == 6) {
+                asm volatile("" : "+v"(wq));                       // ordered behind the k-step wait that covers the read
+                fmac2(sigma, wq[0], ev[0], wq[1], ev[1]);
+            }
+            if constexpr (S_ == 7) fmac2(sigma, wq[2], ev[2], wq[3], ev[3]);
         });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
@@ -249,9 +359,9 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
     sigma += __shfl_xor(sigma, 32, 64);
     sigma += sb[SB_BALPHA];
     // feature = feature_linear(h7), no activation
-    layer_h<OFF_FEAT, 16, KS_LH, false, SB_BFEAT, SB_BVIEWS>(st, a0, a1, bias,
+    layer_h<OFF_FEAT, 16, KS_LH, false, SB_BFEAT, SB_BVIEWS, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-        [&](auto to, const f32x4 &acc) { split_into<to.value & 1>(act16<false>(acc), o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, false, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
     // view branch: cat[feature (256), encoded direction (27 + 5)] -> 128, relu; rgb = rgb_linear(v) in the epilogue.
     // The direction encoding is formed only now (8 fewer live registers through the trunk).
     h16x8 ed_h, ed_l;
@@ -259,29 +369,43 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         f32x4 q0, q1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#ifdef MVIP_EXPERIMENT_F16W16_NO_ENCODING
+            q0[i] = vx * (float)(i + 1); q1[i] = vy * (float)(i + 1);
+#else
             q0[i] = f16p::enc_channel<27>(vx, vy, vz, 4 * g + i);
             q1[i] = f16p::enc_channel<27>(vx, vy, vz, 16 + 4 * g + i);
+#endif
         }
         split_into<0>(q0, ed_h, ed_l);
         split_into<1>(q1, ed_h, ed_l);
     }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    layer_h<OFF_VIEWS, 8, KS_LV, true, SB_BVIEWS, -1>(st, a0, a1, bias,
+    f32x4 w0, w1, w2;
+    layer_h<OFF_VIEWS, 8, KS_LV, true, SB_BVIEWS, -1, 8, 2>(st, a0, a1, bias,
         [&](auto ks) {
             if constexpr (ks.value < 8) return BPairH{o_h[ks.value], o_l[ks.value]};
             else return BPairH{ed_h, ed_l};
         },
-        [&](auto to, const f32x4 &acc) {
-            const f32x4 v = act16<true>(acc);
-            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 16 * to.value + 4 * g);
-            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 128 + 16 * to.value + 4 * g);
-            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(sb + SB_WRGB + 256 + 16 * to.value + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r0 = fmaf(w0[i], v[i], r0);
-                r1 = fmaf(w1[i], v[i], r1);
-                r2 = fmaf(w2[i], v[i], r2);
+        [&](auto to, auto sg, const f32x4 &acc) {
+            constexpr int S_ = decltype(sg)::value, TO_ = decltype(to)::value;
+            if constexpr (S_ == 0) {                                // the three rgb rows' quads of this tile, and relu
+                w0 = st.template read_sb_async<SB_WRGB + 16 * TO_>();
+                w1 = st.template read_sb_async<SB_WRGB + 128 + 16 * TO_>();
+                w2 = st.template read_sb_async<SB_WRGB + 256 + 16 * TO_>();
+                float t0, t1;
+                relu2(t0, t1, acc[0], acc[1]);
+                ev[0] = t0; ev[1] = t1;
             }
+            if constexpr (S_ == 1) { float t0, t1; relu2(t0, t1, acc[2], acc[3]); ev[2] = t0; ev[3] = t1; }
+            if constexpr (S_ == 2) {
+                asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+                fmac2(r0, w0[0], ev[0], w0[1], ev[1]);
+            }
+            if constexpr (S_ == 3) fmac2(r0, w0[2], ev[2], w0[3], ev[3]);
+            if constexpr (S_ == 4) fmac2(r1, w1[0], ev[0], w1[1], ev[1]);
+            if constexpr (S_ == 5) fmac2(r1, w1[2], ev[2], w1[3], ev[3]);
+            if constexpr (S_ == 6) fmac2(r2, w2[0], ev[0], w2[1], ev[1]);
+            if constexpr (S_ == 7) fmac2(r2, w2[2], ev[2], w2[3], ev[3]);
         });
     r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
     r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
@@ -332,8 +456,11 @@ static int launch_w16(const float *img, const float *a, const float *b, int64_t 
     static const int ring = [] { const char *e = getenv("MVIP_F16W16_RING"); return e ? atoi(e) : 0; }();
     const dim3 grid((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), block(512);
     hipStream_t s = as_stream(stream);
+#ifndef MVIP_EXPERIMENT_F16W16_ONE_RING
     if (ring == 1) hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, 32, 3>), grid, block, 0, s, img, a, b, P, S, raw);
-    else hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, 16, 4>), grid, block, 0, s, img, a, b, P, S, raw);
+    else
+#endif
+    hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, 16, 4>), grid, block, 0, s, img, a, b, P, S, raw);
     return check_launch();
 }
 
