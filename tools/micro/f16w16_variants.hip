@@ -20,6 +20,9 @@ int main(int argc, char **argv) {
     for (int64_t b = 0; b < mlp::TOTAL_BLOCKS; ++b)
         for (int e = 0; e < 512; ++e) hh[b * 512 + e] = (_Float16)(rnd() * ((b & 1) ? 2.4e-5f : 0.1f));
     for (int i = mlp::SEC_A_FLOATS; i < mlp::PACKED_FLOATS; ++i) h[i] = rnd() * 0.1f;
+    // argv[2] = "zero": an all-zero weight image (same instructions, minimal operand toggling): how much of the launch time is the
+    // POWER the data costs rather than the schedule
+    if (argc > 2 && argv[2][0] == 'z') for (auto &v : h) v = 0.f;
     std::vector<float> rows(B * 11), z(B * S);
     for (int64_t r = 0; r < B; ++r) {
         for (int c = 0; c < 11; ++c) rows[r * 11 + c] = rnd();
