@@ -6,8 +6,9 @@ The reference obtains these from `diffusers` / `transformers` with the
 `runwayml/stable-diffusion-inpainting@fp16` weights (DS_NeRF/guidance/sd_utils.py:69-74).  Neither the
 library source nor the weights exist offline, so: the module/parameter names follow diffusers'
 state-dict layout (a real checkpoint can be loaded with `load_state_dict` once available), the
-weights are randomly initialised, and the network bodies are "parity unpinned" (DESIGN.md).  They
-exist so the SDS step can be executed and timed at its true shapes and FLOPs.
+weights are randomly initialised unless a checkpoint DIRECTORY is given (`SDNetworks.load_checkpoint`,
+guidance/sd_checkpoint.py: strict manifest of names and shapes), and the network bodies are "parity
+unpinned" (DESIGN.md).  They exist so the SDS step can be executed and timed at its true shapes and FLOPs.
 """
 import math
 
@@ -621,6 +622,20 @@ class SDNetworks:
         self.alphas_cumprod = scaled_linear_alphas_cumprod()
         self.device, self.dtype = device, dtype
         self._cache = {}
+
+    def load_checkpoint(self, root):
+        """Replace the random weights by those of the diffusers-layout checkpoint directory `root` (strict key / shape check
+        against guidance/sd_checkpoint_manifest.json; `fp16_weights` = every UNet / VAE tensor an exact fp16 value; the CLIP BPE
+        tokenizer when its files are there) -- what the reference's from_pretrained does (DS_NeRF/guidance/sd_utils.py:69-74).
+        In --fp16 mode the values are rounded to fp16 like the reference's half modules."""
+        from . import sd_checkpoint
+        report = sd_checkpoint.load_into(self, root)
+        if self.dtype == torch.float16 and torch.device(self.device).type == 'cuda':
+            for m in (self.vae, self.unet, self.text_encoder):
+                for p in m.parameters():
+                    p.data = p.data.half().float()
+            self.fp16_weights = True
+        return report
 
     @torch.no_grad()
     def encode_prompt(self, prompt, cfg):

@@ -227,8 +227,8 @@ class StableDiffusion(nn.Module):
                  reference_rng=True, use_graphs=None):
         """Signature of DS_NeRF/guidance/sd_utils.py:46 plus two keyword extensions: `networks`
         (an object with .vae, .unet, .encode_prompt(prompt, cfg), .alphas_cumprod; default = the
-        SD-1.5-inpaint-shaped modules of sd_nets with random weights, since no checkpoint exists
-        offline) and `reference_rng`."""
+        SD-1.5-inpaint-shaped modules of sd_nets -- filled from the diffusers-layout checkpoint directory `hf_key`
+        when one is given (guidance/sd_checkpoint.py), with random weights otherwise) and `reference_rng`."""
         super().__init__()
         self.device = device
         self.sd_version = sd_version
@@ -237,6 +237,11 @@ class StableDiffusion(nn.Module):
         if networks is None:
             from .sd_nets import SDNetworks
             networks = SDNetworks(device, self.precision_t)
+            if hf_key is not None:
+                # the reference resolves hf_key / sd_version to a hub name and downloads it (sd_utils.py:52-74); offline, hf_key is
+                # a local diffusers-layout DIRECTORY: loaded strictly (wrong key set or shape -> CheckpointError), fp16-exactness
+                # of the weights decides the two-product contractions, CLIP BPE tokenizer when its files are present
+                networks.load_checkpoint(hf_key)
         self.networks = networks
         self.vae, self.unet = networks.vae, networks.unet
         self.num_train_timesteps = 1000
