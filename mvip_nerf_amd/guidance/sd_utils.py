@@ -183,6 +183,9 @@ class _GraphedStep:
             latents = _AddNoiseDev.apply(image_latents, noise, self.scal)
         with torch.no_grad():
             x = torch.cat([latents] * 2) if cfg else latents
+            join, sd._join = sd._join, None
+            if join is not None:                                 # the masked-image encode (second stream, see _prepare) ends here
+                torch.cuda.current_stream(latents.device).wait_stream(join)
             x = torch.cat([x, mask64, masked_latents], dim=1)
             eps = sd.unet(x.to(sd.precision_t), self.scal[3:4], encoder_hidden_states=emb,
                           cross_attention_kwargs=None, return_dict=False)[0]
@@ -313,14 +316,43 @@ class StableDiffusion(nn.Module):
         # Its only consumer is the UNet input inside torch.no_grad() below (DS_NeRF/guidance/sd_utils.py:375-380: the
         # gradient is applied to `latents` alone), so no gradient ever flows back through this encode: run it without a
         # graph -- same values, no saved activations, and the GroupNorm statistics need not be kept (one launch less each).
-        with torch.no_grad():
-            masked_image_latents = self._encode_vae_image(masked_image)              # randn draw 1
+        # ... and on a SECOND STREAM (round 5): the two VAE encodes of a step are independent until the UNet's input is
+        # assembled, each is ~170 launches, many of them too small to fill the chip -- side by side their kernel boundaries
+        # and tails overlap.  Fork here, join in _noise_and_predict right before the concatenation; inside a captured step
+        # the fork / join become graph edges.  The random draws keep their order (they are ordered by the host calls).
+        # MVIP_SDS_TWO_STREAMS=0: one stream (A/B switch, same values).
+        side = self._side_stream() if masked_image.is_cuda else None
+        if side is not None:
+            cur = torch.cuda.current_stream(masked_image.device)
+            side.wait_stream(cur)
+            masked_image.record_stream(side)
+            with torch.cuda.stream(side), torch.no_grad():
+                masked_image_latents = self._encode_vae_image(masked_image)          # randn draw 1
+                if cfg:
+                    masked_image_latents = torch.cat([masked_image_latents] * 2)
+            masked_image_latents.record_stream(cur)
+            self._join = side
+        else:
+            with torch.no_grad():
+                masked_image_latents = self._encode_vae_image(masked_image)          # randn draw 1
+            if cfg:
+                masked_image_latents = torch.cat([masked_image_latents] * 2)
         if cfg:
             mask64 = torch.cat([mask64] * 2)
-            masked_image_latents = torch.cat([masked_image_latents] * 2)
         if self.reference_rng:
             self._randn((1, 4, latent_size // 8, latent_size // 8))                  # draw 2: the unused encode
         return init_image, mask64, masked_image_latents, prompt_embeds, cfg
+
+    _join = None
+
+    def _side_stream(self):
+        """The stream of the masked-image encode (one per StableDiffusion object), or None when switched off."""
+        import os
+        if os.environ.get('MVIP_SDS_TWO_STREAMS', '1') == '0':
+            return None
+        if self.__dict__.get('_side') is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _noise_and_predict(self, init_image, mask64, masked_image_latents, prompt_embeds, cfg, t, guidance_scale,
                            accumulate_into=None):
@@ -330,6 +362,9 @@ class StableDiffusion(nn.Module):
         latents = _AddNoise.apply(image_latents, noise, abar ** 0.5, (1.0 - abar) ** 0.5)
         with torch.no_grad():
             x = torch.cat([latents] * 2) if cfg else latents
+            join, self._join = self._join, None
+            if join is not None:                                                     # the masked-image encode (second stream) ends here
+                torch.cuda.current_stream(latents.device).wait_stream(join)
             x = torch.cat([x, mask64, masked_image_latents], dim=1)
             noise_pred = self.unet(x.to(self.precision_t), t, encoder_hidden_states=prompt_embeds,
                                    cross_attention_kwargs=None, return_dict=False)[0]
