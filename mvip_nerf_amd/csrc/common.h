@@ -92,6 +92,16 @@ __device__ __forceinline__ T dpp_incl_scan_add(T v, Dpp) {
     v += Dpp::template f<0x143, 0xc>((T)0, v);
     return v;
 }
+// inclusive prefix PRODUCT over the 64 lanes, same six steps (a lane without a source multiplies by 1)
+__device__ __forceinline__ float dpp_incl_prod(float v) {
+    v *= dpp_f32<0x111>(1.f, v);
+    v *= dpp_f32<0x112>(1.f, v);
+    v *= dpp_f32<0x114>(1.f, v);
+    v *= dpp_f32<0x118>(1.f, v);
+    v *= dpp_f32<0x142, 0xa>(1.f, v);
+    v *= dpp_f32<0x143, 0xc>(1.f, v);
+    return v;
+}
 struct DppF32 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ float f(float o, float v) { return dpp_f32<C, R, B>(o, v); } };
 struct DppF64 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ double f(double o, double v) { return dpp_f64<C, R, B>(o, v); } };
 __device__ __forceinline__ float dpp_incl_sum(float v) { return dpp_incl_scan_add<float>(v, DppF32{}); }

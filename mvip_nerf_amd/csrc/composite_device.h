@@ -1,6 +1,9 @@
 // Device side of raw2outputs (DS_NeRF/run_nerf_helpers.py:350-404), shared by csrc/composite.hip (stand-alone launches,
 // forward and backward) and the fused render kernels of csrc/mlp_fwd16.hip: one 64-lane wavefront per ray, ITEMS
-// consecutive samples per lane, the transmittance cumprod / suffix sums as wave-level scans on shuffles.
+// consecutive samples per lane, the transmittance cumprod and the five ray sums as wave-level scans on DPP (round 5: a
+// cross-lane step is an operand modifier of an ordinary VALU instruction, ~8 cycles, where the ds_bpermute shuffles of the
+// earlier version were an LDS-crossbar round trip each, 37 of them per ray -- the fused render kernel's tail runs this on ONE
+// wave while the workgroup's other seven have left, so its latency is exposed in full).
 #pragma once
 #include "common.h"
 
@@ -12,6 +15,49 @@ struct RayState {
     float c[ITEMS][3];
     bool valid[ITEMS];
 };
+
+// ---- the per-sample terms of raw2outputs, as functions: the stand-alone kernels evaluate them lane by lane inside ray_forward,
+// the fused render kernel (mlp_fwd16.hip) evaluates them on ALL waves of the workgroup before its compositing tail -- the same
+// calls on the same values, hence the same bits.
+__device__ __forceinline__ float comp_dist(float z, float znext, bool last, float dnorm) {
+    const float d = last ? 1e10f : (znext - z);
+    return d * dnorm;
+}
+__device__ __forceinline__ float comp_neg_exponent(float pre, float d) {         // -relu(sigma + noise) * dist
+    const float sg = pre > 0.f ? pre : 0.f;
+    return -sg * d;
+}
+__device__ __forceinline__ float comp_sigmoid_from_exp(float e) { return 1.f / (1.f + e); }     // e = expf(-x)
+
+// Second half of the forward: st.valid / z / e / c are filled (per sample: e = exp(-relu(sigma) dist), c = sigmoid(rgb));
+// alpha, t, the transmittance T, the weights and the five ray sums follow.
+template <int ITEMS>
+__device__ __forceinline__ void ray_finish(RayState<ITEMS> &st, float sums[5]) {
+    float lane_prod = 1.f;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const float a = 1.f - st.e[i];                          // raw2alpha
+        st.alpha[i] = a;
+        st.t[i] = (1.f - a) + 1e-10f;
+        st.T[i] = lane_prod;                                    // exclusive product inside the lane
+        lane_prod *= st.t[i];
+    }
+    const float incl = dpp_incl_prod(lane_prod);
+    const float excl = dpp_from_prev(incl, 1.f);                // product over the lanes before this one (lane 0: 1)
+    float a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        st.T[i] *= excl;
+        st.w[i] = st.valid[i] ? st.alpha[i] * st.T[i] : 0.f;
+        a_sum += st.w[i];
+        d_sum += st.w[i] * st.z[i];
+        c0 += st.w[i] * st.c[i][0];
+        c1 += st.w[i] * st.c[i][1];
+        c2 += st.w[i] * st.c[i][2];
+    }
+    sums[0] = dpp_wave_sum(a_sum); sums[1] = dpp_wave_sum(d_sum);
+    sums[2] = dpp_wave_sum(c0); sums[3] = dpp_wave_sum(c1); sums[4] = dpp_wave_sum(c2);
+}
 
 // Recomputes everything the forward defines for one ray.  Returns (acc, depth, rgb sums).
 // z == nullptr: the caller has already put the ray's depths into st.z (a fused kernel that computed them itself).
@@ -29,8 +75,7 @@ __device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const
         if (z) st.z[i] = st.valid[i] ? z[s] : 0.f;
         else if (!st.valid[i]) st.z[i] = 0.f;
     }
-    zfirst_next = __shfl_down(st.z[0], 1, 64);
-    float lane_prod = 1.f;
+    zfirst_next = dpp_from_next(st.z[0], st.z[0]);          // lane l + 1's first depth (lane 63: its own, never used: s = S - 1)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int s = l * ITEMS + i;
@@ -42,36 +87,33 @@ __device__ __forceinline__ void ray_forward(const float *__restrict__ raw, const
             else if (noise) nz = noise[s];
         }
         const float znext = (i + 1 < ITEMS) ? st.z[(i + 1) % ITEMS] : zfirst_next;
-        float d = (s == S - 1) ? 1e10f : (znext - st.z[i]);
-        d = d * dnorm;
+        const float d = comp_dist(st.z[i], znext, s == S - 1, dnorm);
         const float pre = r.w + nz;
-        const float sg = pre > 0.f ? pre : 0.f;                 // relu
-        const float ee = st.valid[i] ? expf(-sg * d) : 1.f;
-        const float a = 1.f - ee;                               // raw2alpha
-        st.dist[i] = d; st.sig[i] = pre; st.e[i] = ee; st.alpha[i] = a;
-        st.t[i] = (1.f - a) + 1e-10f;
-        st.c[i][0] = 1.f / (1.f + expf(-r.x));                  // sigmoid
-        st.c[i][1] = 1.f / (1.f + expf(-r.y));
-        st.c[i][2] = 1.f / (1.f + expf(-r.z));
-        st.T[i] = lane_prod;                                    // exclusive product inside the lane
-        lane_prod *= st.t[i];
+        st.dist[i] = d; st.sig[i] = pre;
+        st.e[i] = st.valid[i] ? expf(comp_neg_exponent(pre, d)) : 1.f;
+        st.c[i][0] = comp_sigmoid_from_exp(expf(-r.x));
+        st.c[i][1] = comp_sigmoid_from_exp(expf(-r.y));
+        st.c[i][2] = comp_sigmoid_from_exp(expf(-r.z));
     }
-    float incl = wave_incl_prod(lane_prod);
-    float excl = __shfl_up(incl, 1, 64);
-    if (l == 0) excl = 1.f;
-    float a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    ray_finish<ITEMS>(st, sums);
+}
+
+// The fused kernel's form: `terms` holds, per sample, {e, c0, c1, c2} as the workgroup's waves computed them (comp_* above),
+// `zs` the depths; every sample of the ray exists (S = 64 ITEMS).  Same values as ray_forward on the raw rows they came from.
+template <int ITEMS>
+__device__ __forceinline__ void ray_forward_terms(const float *__restrict__ terms, const float *__restrict__ zs,
+                                                  RayState<ITEMS> &st, float sums[5]) {
+    const int l = lane_id();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        st.T[i] *= excl;
-        st.w[i] = st.valid[i] ? st.alpha[i] * st.T[i] : 0.f;
-        a_sum += st.w[i];
-        d_sum += st.w[i] * st.z[i];
-        c0 += st.w[i] * st.c[i][0];
-        c1 += st.w[i] * st.c[i][1];
-        c2 += st.w[i] * st.c[i][2];
+        const int s = l * ITEMS + i;
+        const float4 t = reinterpret_cast<const float4 *>(terms)[s];
+        st.valid[i] = true;
+        st.z[i] = zs[s];
+        st.e[i] = t.x;
+        st.c[i][0] = t.y; st.c[i][1] = t.z; st.c[i][2] = t.w;
     }
-    sums[0] = wave_sum(a_sum); sums[1] = wave_sum(d_sum);
-    sums[2] = wave_sum(c0); sums[3] = wave_sum(c1); sums[4] = wave_sum(c2);
+    ray_finish<ITEMS>(st, sums);
 }
 
 __device__ __forceinline__ float dir_norm(const float *__restrict__ row) {

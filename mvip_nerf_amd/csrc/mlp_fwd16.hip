@@ -32,8 +32,9 @@ namespace f16p {
 
 // FUSE (rays form only; DS_NeRF/run.py:1703-1847 render_rays as TWO launches per chunk instead of six):
 //   1  the COARSE pass: 64 samples per ray, a workgroup = two rays.  The depths are computed here (stratified_point, no z
-//      tensor), and after the network the first wave of each ray composites its 64 samples (raw2outputs) from the
-//      workgroup's raw values in LDS, draws the fine samples by inverse CDF from the weights still in its registers and
+//      tensor); after the network every wave evaluates the exponentials of raw2outputs for its 16 points, then the first
+//      wave of each ray composites its 64 samples from those terms in LDS (scan + sums: round 5, see the tail), draws the
+//      fine samples by inverse CDF from the weights still in its registers and
 //      writes the merged 128 depths: rgb0 / disp0 / acc0 (/ alpha0), z_std, z_merged -- no raw, weights or depth tensor of
 //      the coarse pass ever exists;
 //   2  the FINE pass: 128 samples per ray, a workgroup = one ray; wave 0 composites after the network.
@@ -71,29 +72,32 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     st.issue_chunk(1, 1);
 
     float px, py, pz, vx, vy, vz;
-    // fused tail (FUSE != 0): what its wave will need is fetched NOW and carried in a few registers through the network --
-    // the tail runs alone on its SIMD at the end of the workgroup, where a global-memory round trip is fully exposed
-    float zz = 0.f, tail_dnorm = 0.f, tail_u = 2.f, tail_nz[2] = {0.f, 0.f};
+    // fused tail (FUSE != 0): what it will need is fetched NOW and carried in a few registers through the network -- the next
+    // sample's depth, this point's density noise and the ray's direction norm (every wave evaluates the exponentials of ITS
+    // points after the network, see below), the tail wave's uniform; at the end of the workgroup a global-memory round trip
+    // would be fully exposed
+    float zz = 0.f, zn = 0.f, nz = 0.f, dnorm = 0.f, tail_u = 2.f;
+    int s_idx = 0;
     if constexpr (FROM_RAYS) {
         const int64_t ray = p / S;
         const float *row = in_a + ray * 11;
-        if constexpr (FUSE == 1) zz = stratified_point(row[6], row[7], fa.t_vals, (int)(p - ray * S), S, fa.lindisp,
-                                                        fa.t_rand ? fa.t_rand + p : nullptr);
-        else zz = in_b[p];
+        s_idx = (int)(p - ray * S);
+        if constexpr (FUSE == 1) {
+            zz = stratified_point(row[6], row[7], fa.t_vals, s_idx, S, fa.lindisp, fa.t_rand ? fa.t_rand + p : nullptr);
+            if (s_idx + 1 < S) zn = stratified_point(row[6], row[7], fa.t_vals, s_idx + 1, S, fa.lindisp, fa.t_rand ? fa.t_rand + p + 1 : nullptr);
+        } else {
+            zz = in_b[p];
+            if constexpr (FUSE == 2) { if (s_idx + 1 < S) zn = in_b[p + 1]; }
+        }
         px = row[0] + row[3] * zz; py = row[1] + row[4] * zz; pz = row[2] + row[5] * zz;
         vx = row[8]; vy = row[9]; vz = row[10];
         if constexpr (FUSE != 0) {
             constexpr int WPR_ = FUSE == 1 ? 4 : 8, SR_ = FUSE == 1 ? 64 : 128;
-            if (wave % WPR_ == 0) {                          // this wave composites its ray at the end: lane = sample(s)
-                tail_dnorm = dir_norm(row);
+            dnorm = dir_norm(row);
+            if (fa.noise) nz = fa.noise[p];
+            if (FUSE == 1 && wave % WPR_ == 0) {             // this wave draws the fine samples of its ray at the end: lane = uniform
                 const int64_t tray = (int64_t)blockIdx.x * (8 / WPR_) + wave / WPR_;
-                if (tray * SR_ < P) {
-                    if (FUSE == 1 && lane < fa.Nf) tail_u = fa.u_is_row ? fa.u[lane] : fa.u[tray * fa.Nf + lane];
-                    if (fa.noise) {
-#pragma unroll
-                        for (int i = 0; i < SR_ / 64; ++i) tail_nz[i] = fa.noise[tray * SR_ + lane * (SR_ / 64) + i];
-                    }
-                }
+                if (tray * SR_ < P && lane < fa.Nf) tail_u = fa.u_is_row ? fa.u[lane] : fa.u[tray * fa.Nf + lane];
             }
         }
     } else {
@@ -197,11 +201,19 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
     const float4 out4 = make_float4(r0 + sb[SB_BRGB], r1 + sb[SB_BRGB + 1], r2 + sb[SB_BRGB + 2], sigma);
     if (live && g == 0 && raw) reinterpret_cast<float4 *>(raw)[p] = out4;
     if constexpr (FUSE != 0) {
-        // ---- the rest of the pass, by the first wave of each ray, from the workgroup's raw values in LDS ----
-        float *z_s = raw_s + WG_POINTS * 4;                  // the points' depths, next to their raw values
-        if (g == 0) {
-            reinterpret_cast<float4 *>(raw_s)[wave * 16 + n] = out4;
-            z_s[wave * 16 + n] = zz;
+        // ---- the rest of the pass.  The exponentials of raw2outputs (DS_NeRF/run_nerf_helpers.py:373-393) are evaluated HERE, by
+        // all eight waves on their own 16 points: lane group g = 0 forms e = exp(-relu(sigma + noise) dist), groups 1..3 the
+        // sigmoid of one colour channel each (every lane holds the point's four raw values after the head reductions).  What
+        // remains for the ONE wave per ray that composites while the other seven have left -- its latency is exposed in full --
+        // is the transmittance scan and the five sums: round 4's tail evaluated all 8 x 128 exponentials and quotients itself.
+        // The terms are those of composite_device.h (comp_*), so every output stays bit-identical to the stand-alone kernels.
+        float *terms_s = raw_s, *z_s = raw_s + WG_POINTS * 4;     // {e, c0, c1, c2} per point, the points' depths next to them
+        {
+            const float rc = g == 1 ? out4.x : (g == 2 ? out4.y : out4.z);
+            const float x = g == 0 ? comp_neg_exponent(out4.w + nz, comp_dist(zz, zn, s_idx == S - 1, dnorm)) : -rc;
+            const float e = expf(x);
+            terms_s[(wave * 16 + n) * 4 + g] = g == 0 ? e : comp_sigmoid_from_exp(e);
+            if (g == 0) z_s[wave * 16 + n] = zz;
         }
         __syncthreads();
         constexpr int RAYS = FUSE == 1 ? 2 : 1, WPR = 8 / RAYS, SR = WG_POINTS / RAYS;      // rays, waves and samples per ray
@@ -214,10 +226,7 @@ mlp_forward16_kernel(const float *__restrict__ packed, const float *__restrict__
         constexpr int IT = SR / 64;
         RayState<IT> stt;
         float sums[5];
-        // depths and raw values from LDS, direction norm / noise / uniforms from the registers filled at the start: the
-        // tail touches global memory only to store
-        ray_forward<IT>(raw_s + (wave / WPR) * SR * 4, z_s + (wave / WPR) * SR, nullptr, tail_dnorm, SR, stt, sums,
-                        fa.noise ? tail_nz : nullptr);
+        ray_forward_terms<IT>(terms_s + (wave / WPR) * SR * 4, z_s + (wave / WPR) * SR, stt, sums);
         composite_store<IT>(stt, sums, ray, SR, fa.flags, fa.rgb, fa.disp, fa.acc, fa.depth, fa.weights, fa.alpha);
         if constexpr (FUSE == 1) {
             // inverse-CDF resampling + merge from the weights in registers: weight e of the pdf = coarse weight e + 1

@@ -57,7 +57,7 @@ def main():
     run.FUSED_RENDER, run.FUSED_RENDER_MAX_RAYS = True, default_max
     print(json.dumps(out, indent=1))
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(out, open('gpurun_out/r4_fused_render_ab.json', 'w'), indent=1)
+    json.dump(out, open('gpurun_out/r5_fused_render_ab.json', 'w'), indent=1)
 
 
 if __name__ == '__main__':
