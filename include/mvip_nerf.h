@@ -107,6 +107,11 @@ int mvip_mlp_forward_rays_f16x3_w16(const float *image, const float *rows, const
                                     float *raw, void *stream);
 int mvip_mlp_forward_points_f16x3_w16(const float *image, const float *pts, const float *dirs, int64_t P,
                                       float *raw, void *stream);
+/* ... and its stash-writing TRAINING form (train_precision = 1): raw + the activation stash of mvip_mlp_stash_floats(B*S) floats
+ * that mvip_mlp_backward_stash(precision = 1) consumes (same layout and values as mvip_mlp_forward_rays_stash(precision = 1) writes,
+ * up to fp32 summation order).  Renders under loss.backward(), DS_NeRF/run.py:948-974, :1030. */
+int mvip_mlp_forward_rays_stash_f16x3_w16(const float *image, const float *rows, const float *z, int64_t B, int S,
+                                          float *raw, float *stash, void *stream);
 
 /* Forward from geometry: rows [B,11], z [B,S] -> raw [B,S,4]; points are o + d*z, view dirs
  * are rows[:,8:11] (run.py:1783, :1787).

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'mvip_mlp_pack_f16x3_w16': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_rays_f16x3_w16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f]),
     'mvip_mlp_forward_points_f16x3_w16': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _c_f]),
+    'mvip_mlp_forward_rays_stash_f16x3_w16': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_f]),
     'mvip_mlp_forward_rays': (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _int, _c_f]),
     'mvip_mlp_forward_points': (_int, [_c_f, _c_f, _c_f, _i64, _c_f, _int, _c_f]),
     'mvip_mlp_pack16': (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f]),

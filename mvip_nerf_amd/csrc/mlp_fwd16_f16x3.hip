@@ -250,10 +250,15 @@ __device__ __forceinline__ void layer_h(const St &st, APairH &a0, APairH &a1, f3
     });
 }
 
-template <bool FROM_RAYS, int CHB, int NSL>
+// STASH = true is the TRAINING forward (train_precision = 1): every activation tile is also written, in fp32, to the stash the
+// split-precision backward kernels read ([row tile of 32 units][point tile of 32][32][32], mlp_device.h -- a wave's 16 x 16 tile
+// is four stores of four 64-byte row segments, the two waves that share a point tile filling the other half of each 128-byte
+// row), and the ReLU SIGN masks of the trunk and view-branch tiles (all the delta kernel reads of them): the same bytes as
+// mlp_forward_f16x3_kernel<.., true> writes.
+template <bool FROM_RAYS, bool STASH, int CHB, int NSL>
 __global__ void __launch_bounds__(512, 2)
 mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restrict__ in_a, const float *__restrict__ in_b,
-                             int64_t P, int S, float *__restrict__ raw) {
+                             int64_t P, int S, float *__restrict__ raw, float *__restrict__ stash = nullptr, int64_t n_pt = 0) {
     using St = StreamH<CHB, NSL>;
     __shared__ __attribute__((aligned(16))) float lds[St::ring_floats + SEC_B_FLOATS];
     const int lane = threadIdx.x & 63;
@@ -281,6 +286,33 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         px = in_a[p * 3]; py = in_a[p * 3 + 1]; pz = in_a[p * 3 + 2];
         vx = in_b[p * 3]; vy = in_b[p * 3 + 1]; vz = in_b[p * 3 + 2];
     }
+    // stash: 16-unit tile `t16` (two per 32-unit row tile) of this wave's 16 points -> rows 16 (t16 & 1) + 4 g + i of the block
+    // (row tile t16 >> 1, point tile 4 blockIdx + wave / 2), columns 16 (wave & 1) + n; the block address is wave-uniform.
+    // MI >= 0: the row tile's ReLU sign mask -- 16 bits per lane of the 32-point layout (bit 4 q + s <-> row 8 q + 4 hh + s of
+    // lane (column, hh)).  This lane (n, g) holds rows 4 g + i of each 16-unit tile, i.e. q = 2 (t16 & 1) + (g >> 1), hh = g & 1:
+    // one nibble per tile; the other two nibbles sit in lane l ^ 32 (g ^ 2), one half-wave swap joins them.
+    const int64_t pt_wave = (int64_t)blockIdx.x * 4 + (wave >> 1);
+    const int stash_lane = (4 * g) * 32 + 16 * (wave & 1) + n;
+    unsigned pm = 0;
+    auto stash16 = [&](auto t16_, const f32x4 &t, auto mi_) {
+        if constexpr (STASH) {
+            constexpr int t16 = decltype(t16_)::value, MI = decltype(mi_)::value;
+            float *q = stash + ((int64_t)(t16 >> 1) * n_pt + pt_wave) * 1024 + (t16 & 1) * 512 + stash_lane;
+            q[0] = t[0]; q[32] = t[1]; q[64] = t[2]; q[96] = t[3];
+            if constexpr (MI >= 0) {
+                unsigned nib = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nib |= (t[i] > 0.f ? 1u : 0u) << i;
+                const int sh = 4 * (g >> 1) + 8 * (t16 & 1);
+                if constexpr ((t16 & 1) == 0) pm = nib << sh;
+                else {
+                    pm |= nib << sh;
+                    const unsigned full = pm | __builtin_bit_cast(unsigned, dpp_xor<32>(__builtin_bit_cast(float, pm)));
+                    if (lane < 32) *mask_slot(stash, MI, n_pt, pt_wave, (g & 1) * 32 + 16 * (wave & 1) + n) = (unsigned short)full;
+                }
+            }
+        }
+    };
     // encoded point: 64 units (63 + a zero) = two k-steps of B fragments, split like every activation
     h16x8 emb_h[2], emb_l[2];
 #pragma unroll
@@ -297,6 +329,8 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         }
         split_into<0>(q0, emb_h[s], emb_l[s]);
         split_into<1>(q1, emb_h[s], emb_l[s]);
+        if (s == 0) { stash16(ic<2 * AT_EMB>{}, q0, ic<-1>{}); stash16(ic<2 * AT_EMB + 1>{}, q1, ic<-1>{}); }
+        else { stash16(ic<2 * AT_EMB + 2>{}, q0, ic<-1>{}); stash16(ic<2 * AT_EMB + 3>{}, q1, ic<-1>{}); }
     }
 
     __syncthreads();                                   // chunks 0, 1 and section B have landed
@@ -310,7 +344,10 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
     // layer 0: 63(+1) -> 256
     layer_h<OFF_L0, 16, KS_L0, false, SB_BIAS, SB_BIAS + 256, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{emb_h[ks.value], emb_l[ks.value]}; },
-        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) {
+            split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (sg.value == 2) stash16(ic<2 * AT_H + to.value>{}, ev, ic<AT_H + (to.value >> 1)>{});
+        });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     // layers 1..4
@@ -318,7 +355,10 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         constexpr int l = 1 + decltype(li)::value;
         layer_h<OFF_L1 + (l - 1) * LH_BLOCKS, 16, KS_LH, false, SB_BIAS + l * 256, SB_BIAS + (l + 1) * 256, 6, 6>(st, a0, a1, bias,
             [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-            [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
+            [&](auto to, auto sg, const f32x4 &acc) {
+                split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+                if constexpr (sg.value == 2) stash16(ic<2 * (AT_H + 8 * l) + to.value>{}, ev, ic<AT_H + 8 * l + (to.value >> 1)>{});
+            });
 #pragma unroll
         for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     });
@@ -328,13 +368,19 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
             if constexpr (ks.value < 2) return BPairH{emb_h[ks.value], emb_l[ks.value]};
             else return BPairH{h_h[ks.value - 2], h_l[ks.value - 2]};
         },
-        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) {
+            split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (sg.value == 2) stash16(ic<2 * (AT_H + 40) + to.value>{}, ev, ic<AT_H + 40 + (to.value >> 1)>{});
+        });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     // layer 6
     layer_h<OFF_L6, 16, KS_LH, false, SB_BIAS + 6 * 256, SB_BIAS + 7 * 256, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) {
+            split_stage<to.value & 1, true, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (sg.value == 2) stash16(ic<2 * (AT_H + 48) + to.value>{}, ev, ic<AT_H + 48 + (to.value >> 1)>{});
+        });
 #pragma unroll
     for (int t = 0; t < 8; ++t) { h_h[t] = o_h[t]; h_l[t] = o_l[t]; }
     // layer 7; sigma = alpha_linear(h7) accumulated in fp32 from the fp32 activations, tile by tile: stage 0 also asks for the
@@ -347,6 +393,7 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
             constexpr int S_ = decltype(sg)::value;
             if constexpr (S_ == 0) wq = st.template read_sb_async<SB_WALPHA + 16 * decltype(to)::value>();
             if constexpr (S_ < 6) split_stage<to.value & 1, true, S_>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (S_ == 2) stash16(ic<2 * (AT_H + 56) + decltype(to)::value>{}, ev, ic<AT_H + 56 + (decltype(to)::value >> 1)>{});
             if constexpr (S_ == 6) {
                 asm volatile("" : "+v"(wq));                       // ordered behind the k-step wait that covers the read
                 fmac2(sigma, wq[0], ev[0], wq[1], ev[1]);
@@ -361,7 +408,10 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
     // feature = feature_linear(h7), no activation
     layer_h<OFF_FEAT, 16, KS_LH, false, SB_BFEAT, SB_BVIEWS, 6, 6>(st, a0, a1, bias,
         [&](auto ks) { return BPairH{h_h[ks.value], h_l[ks.value]}; },
-        [&](auto to, auto sg, const f32x4 &acc) { split_stage<to.value & 1, false, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]); });
+        [&](auto to, auto sg, const f32x4 &acc) {
+            split_stage<to.value & 1, false, sg.value>(acc, ev, er, o_h[to.value >> 1], o_l[to.value >> 1]);
+            if constexpr (sg.value == 2) stash16(ic<2 * AT_FEAT + to.value>{}, ev, ic<-1>{});
+        });
     // view branch: cat[feature (256), encoded direction (27 + 5)] -> 128, relu; rgb = rgb_linear(v) in the epilogue.
     // The direction encoding is formed only now (8 fewer live registers through the trunk).
     h16x8 ed_h, ed_l;
@@ -378,6 +428,8 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         }
         split_into<0>(q0, ed_h, ed_l);
         split_into<1>(q1, ed_h, ed_l);
+        stash16(ic<2 * AT_EDIR>{}, q0, ic<-1>{});
+        stash16(ic<2 * AT_EDIR + 1>{}, q1, ic<-1>{});
     }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
     f32x4 w0, w1, w2;
@@ -396,7 +448,12 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
                 relu2(t0, t1, acc[0], acc[1]);
                 ev[0] = t0; ev[1] = t1;
             }
-            if constexpr (S_ == 1) { float t0, t1; relu2(t0, t1, acc[2], acc[3]); ev[2] = t0; ev[3] = t1; }
+            if constexpr (S_ == 1) {
+                float t0, t1;
+                relu2(t0, t1, acc[2], acc[3]);
+                ev[2] = t0; ev[3] = t1;
+                stash16(ic<2 * AT_V + TO_>{}, ev, ic<64 + (TO_ >> 1)>{});
+            }
             if constexpr (S_ == 2) {
                 asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
                 fmac2(r0, w0[0], ev[0], w0[1], ev[1]);
@@ -450,17 +507,25 @@ __global__ void mlp_pack_f16x3_w16_kernel(ParamPtrsH pp, _Float16 *__restrict__ 
 }
 
 template <bool FROM_RAYS>
-static int launch_w16(const float *img, const float *a, const float *b, int64_t P, int S, float *raw, void *stream) {
-    // ring geometry: MVIP_F16W16_RING = 0 (default): 4 slots of 16 KB (77 KB of LDS: a second workgroup's allocation fits
-    // beside a finishing one, see the LDS note in mlp_fwd16.hip); 1: 3 slots of 32 KB (half the barriers, 109 KB).  A/B switch.
+static int launch_w16(const float *img, const float *a, const float *b, int64_t P, int S, float *raw, float *stash, void *stream) {
+    // ring geometry: 4 slots of 16 KB (77 KB of LDS: a second workgroup's allocation fits beside a finishing one, see the LDS
+    // note in mlp_fwd16.hip).  -DMVIP_F16W16_BOTH_RINGS also builds 3 slots of 32 KB (half the barriers, 109 KB; MVIP_F16W16_RING=1).
     static const int ring = [] { const char *e = getenv("MVIP_F16W16_RING"); return e ? atoi(e) : 0; }();
-    const dim3 grid((unsigned)((P + WG_POINTS - 1) / WG_POINTS)), block(512);
+    (void)ring;
+    const int64_t wgs = (P + WG_POINTS - 1) / WG_POINTS;
+    const dim3 grid((unsigned)wgs), block(512);
     hipStream_t s = as_stream(stream);
-#ifndef MVIP_EXPERIMENT_F16W16_ONE_RING
-    if (ring == 1) hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, 32, 3>), grid, block, 0, s, img, a, b, P, S, raw);
+    if (stash) {
+        if constexpr (FROM_RAYS)
+            hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<true, true, 16, 4>), grid, block, 0, s, img, a, b, P, S, raw, stash, wgs * 4);
+        else return MVIP_EUNSUP;
+        return check_launch();
+    }
+#ifdef MVIP_F16W16_BOTH_RINGS                        // A/B builds only: the 3 x 32 KB ring measured equal (profiles/r5_f16x3_w16_experiments.json)
+    if (ring == 1) hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, false, 32, 3>), grid, block, 0, s, img, a, b, P, S, raw, (float *)nullptr, (int64_t)0);
     else
 #endif
-    hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, 16, 4>), grid, block, 0, s, img, a, b, P, S, raw);
+    hipLaunchKernelGGL((mlp_forward_f16x3_w16_kernel<FROM_RAYS, false, 16, 4>), grid, block, 0, s, img, a, b, P, S, raw, (float *)nullptr, (int64_t)0);
     return check_launch();
 }
 
@@ -494,7 +559,7 @@ extern "C" int mvip_mlp_forward_rays_f16x3_w16(const float *image, const float *
     if (B < 0 || S <= 0) return MVIP_EINVAL;
     if (B == 0) return MVIP_OK;
     if (!image || !rows || !z || !raw) return MVIP_EINVAL;
-    return f16h::launch_w16<true>(image, rows, z, B * S, S, raw, stream);
+    return f16h::launch_w16<true>(image, rows, z, B * S, S, raw, nullptr, stream);
 }
 
 extern "C" int mvip_mlp_forward_points_f16x3_w16(const float *image, const float *pts, const float *dirs, int64_t P,
@@ -502,5 +567,16 @@ extern "C" int mvip_mlp_forward_points_f16x3_w16(const float *image, const float
     if (P < 0) return MVIP_EINVAL;
     if (P == 0) return MVIP_OK;
     if (!image || !pts || !dirs || !raw) return MVIP_EINVAL;
-    return f16h::launch_w16<false>(image, pts, dirs, P, 1, raw, stream);
+    return f16h::launch_w16<false>(image, pts, dirs, P, 1, raw, nullptr, stream);
+}
+
+// Training forward (train_precision = 1) on the two-wave kernel: raw AND the activation stash of mvip_mlp_stash_floats(B*S) floats
+// (fp32 tiles + ReLU sign masks) that mvip_mlp_backward_stash(precision = 1) consumes -- the bytes mvip_mlp_forward_rays_stash
+// (precision = 1) writes, up to fp32 summation order (DS_NeRF/run.py:948-974 renders under loss.backward(), :1030).
+extern "C" int mvip_mlp_forward_rays_stash_f16x3_w16(const float *image, const float *rows, const float *z, int64_t B, int S,
+                                                     float *raw, float *stash, void *stream) {
+    if (B < 0 || S <= 0) return MVIP_EINVAL;
+    if (B == 0) return MVIP_OK;
+    if (!image || !rows || !z || !raw || !stash) return MVIP_EINVAL;
+    return f16h::launch_w16<true>(image, rows, z, B * S, S, raw, stash, stream);
 }

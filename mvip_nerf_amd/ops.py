@@ -2,10 +2,10 @@
 
 Every function of the NeRF render / training path here launches HIP kernels from libmvipnerf.so on the
 current torch stream; inputs must be dense fp32 tensors on the GPU and nothing computes on the CPU.
-Two places still call stock torch GPU ops and say so where they do: the hash-grid model's training
-forward / data-gradient products (`_LinearCM`: `W @ X` by default -- measured faster than this repo's streaming kernel,
-which is opt-in; its weight gradient is a HIP kernel) and a few reductions / softmaxes inside the VAE mid-block
-attention (`_VAEAttention`).
+No library contraction runs anywhere on this path: the hash-grid model's small layers take `csrc/skinny_gemm.hip` for the
+forward, the data gradient and the weight gradient (`_LinearCM`; `MVIP_SKINNY_LINEAR=0` switches back to `W @ X` for A/B
+timing only), the SDS networks the split-precision kernels.  What stock torch GPU ops remain are tensor allocation,
+concatenations and a few elementwise glue ops; they are named where they occur.
 """
 import weakref
 
@@ -255,8 +255,9 @@ class _MLPRays(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, z, packed, precision, packed16, *params):
-        """`packed` is the weight image of `precision` (0: fp32 image, 1: f16x3 image); `packed16` (precision 0 only,
-        optional) the image of the two-waves-per-SIMD kernel, which then runs the stash-writing forward."""
+        """`packed` is the weight image of `precision` (0: fp32 image, 1: f16x3 image); `packed16` (optional) the image of
+        the two-waves-per-SIMD kernel of that precision (mlp_pack16 / mlp_pack_f16x3_w16), which then runs the stash-writing
+        forward; the backward always works from `packed`."""
         B, S = z.shape
         raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)
         stash = _take_stash(B * S, z.device)
@@ -264,6 +265,8 @@ class _MLPRays(torch.autograd.Function):
             call('mvip_mlp_forward_rays', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), precision, stream())
         elif packed16 is not None and precision == 0:
             call('mvip_mlp_forward_rays_stash16', ptr(packed16), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), stream())
+        elif packed16 is not None and precision == 1:       # the two-wave split-precision kernel (its own image; the backward keeps `packed`)
+            call('mvip_mlp_forward_rays_stash_f16x3_w16', ptr(packed16), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), stream())
         else:
             call('mvip_mlp_forward_rays_stash', ptr(packed), ptr(rows), ptr(z), B, S, ptr(raw), ptr(stash), precision,
                  stream())
@@ -308,18 +311,20 @@ class _MLPPoints(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, train16=None, f16x3_w16=None):
+def mlp_rays(rows, z, packed, params, packed_f16x3=None, train_f16x3=None, packed16=None, train16=None, f16x3_w16=None,
+             train_f16x3_w16=None):
     """Fused forward from ray rows + depths.  `params` (the 24 tensors) are passed so autograd
     routes the gradients back to them; with no grad needed the Function is skipped.
     `packed_f16x3` selects the split-precision kernel (precision = 1) for no-grad calls,
     `train_f16x3` (the same kind of image) for calls that will be back-propagated, `packed16` the exact-fp32
     two-waves-per-SIMD inference kernel (no-grad calls at precision 0), `train16` the same image for the stash-writing
     training forward at precision 0, `f16x3_w16` (ops.mlp_pack_f16x3_w16) the two-waves-per-SIMD split-precision kernel
-    for no-grad calls (takes precedence over `packed_f16x3`)."""
+    for no-grad calls (takes precedence over `packed_f16x3`), `train_f16x3_w16` the same kind of image for the stash-writing
+    training forward at precision 1 (the backward keeps `train_f16x3`)."""
     rows, z = _f32c(rows), _f32c(z)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if train_f16x3 is not None:
-            return _MLPRays.apply(rows, z, train_f16x3, 1, None, *params)
+            return _MLPRays.apply(rows, z, train_f16x3, 1, train_f16x3_w16, *params)
         return _MLPRays.apply(rows, z, packed, 0, train16, *params)
     B, S = z.shape
     raw = torch.empty((B, S, 4), device=z.device, dtype=_F32)

@@ -168,13 +168,16 @@ class NeRF(nn.Module):
     def _train_image(self):
         return self.packed_f16x3() if self.train_precision == 1 else None
 
+    def _train_image_w16(self):
+        return self.packed_f16x3_w16() if (self.train_precision == 1 and self.two_wave_f16x3) else None
+
     def query_points(self, pts, dirs):
         return ops.mlp_points(pts, dirs, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
                               self._infer16(), self._fast_image_w16())
 
     def query_rays(self, rows, z):
         return ops.mlp_rays(rows, z, self.packed(), self.param_list(), self._fast_image(), self._train_image(),
-                            self._infer16(), self._train16(), self._fast_image_w16())
+                            self._infer16(), self._train16(), self._fast_image_w16(), self._train_image_w16())
 
 
 # Ray helpers -------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ CASES = [
      (P0, P0, P0, 0, 8, 63, 64, P0, P0, P0, P0)),
     ('mvip_mlp_forward_rays', (P0, P0, P0, 4, 0, P0, 0, P0), (P0, P0, P0, 0, 64, P0, 0, P0), (P0, P0, P0, 4, 64, P0, 0, P0)),
     ('mvip_mlp_forward_rays_f16x3_w16', (P0, P0, P0, 4, 0, P0, P0), (P0, P0, P0, 0, 64, P0, P0), (P0, P0, P0, 4, 64, P0, P0)),
+    ('mvip_mlp_forward_rays_stash_f16x3_w16', (P0, P0, P0, 4, 0, P0, P0, P0), (P0, P0, P0, 0, 64, P0, P0, P0), (P0, P0, P0, 4, 64, P0, P0, P0)),
     # SDS operand producers and contractions (rows a14-a16)
     ('mvip_resize_bilinear', (P0, 3, 0, 8, 16, 16, P0, P0), (P0, 0, 8, 8, 16, 16, P0, P0), (P0, 3, 8, 8, 16, 16, P0, P0)),
     ('mvip_absmax_scale', (P0, -1, P0, P0, P0), None, (P0, 16, P0, P0, P0)),

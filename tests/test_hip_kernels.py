@@ -496,6 +496,54 @@ def test_mlp_forward_f16x3_two_wave_accuracy(golden, cuda):
             np.testing.assert_allclose(N(got), N(ref32), rtol=5e-5, atol=1e-5 * float(ref32.abs().max()), err_msg=f'{B_} {S_}')
 
 
+def test_two_wave_f16x3_training_forward_stash(golden, cuda):
+    """The stash-writing split-precision training forward on the two-waves-per-SIMD kernel
+    (mvip_mlp_forward_rays_stash_f16x3_w16, round 5) against the 32-point split-precision stash kernel through the C ABI: raw,
+    EVERY fp32 stash element and EVERY ReLU sign-mask word (same layout: the buffers compare element by element; sign bits
+    may differ only where the activation itself is within rounding of zero), then the 24 parameter gradients through the
+    shared split-precision backward kernels, at ray counts that leave partly filled workgroups and point tiles."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd._lib import ptr, stream, call
+    g = golden('mlp_fwd_bwd')
+    for B, S in ((37, 64), (130, 64), (5, 128), (700, 128)):
+        ps = [p.clone().requires_grad_(True) for p in params_dev(g['seed'], cuda)]
+        packed = ops.mlp_pack(ps)
+        p32, pw = ops.mlp_pack_f16x3(ps, packed), ops.mlp_pack_f16x3_w16(ps, packed)
+        rows = torch.from_numpy(bench_like_rays(B, seed=3 + B)).float().to(cuda)
+        z = ops.stratified_z(rows, S, True)
+        n_stash = int(_lib.load().mvip_mlp_stash_floats(B * S))
+        st32 = torch.full((n_stash,), 7.0, device=cuda)
+        st16 = torch.full((n_stash,), 7.0, device=cuda)
+        raw32, raw16 = torch.empty(B, S, 4, device=cuda), torch.empty(B, S, 4, device=cuda)
+        call('mvip_mlp_forward_rays_stash', ptr(p32), ptr(rows), ptr(z), B, S, ptr(raw32), ptr(st32), 1, stream())
+        call('mvip_mlp_forward_rays_stash_f16x3_w16', ptr(pw), ptr(rows), ptr(z), B, S, ptr(raw16), ptr(st16), stream())
+        np.testing.assert_allclose(N(raw16), N(raw32), rtol=2e-5, atol=2e-6)
+        n_pt = ((B * S + 127) // 128) * 4
+        a32, a16 = N(st32).reshape(-1, n_pt, 1024), N(st16).reshape(-1, n_pt, 1024)
+        assert a32.shape[0] == 82                                       # 79 activation row tiles + 3 blocks of sign masks
+        live_pt = (B * S) // 32                                         # point tiles that hold only real points
+        np.testing.assert_allclose(a16[:79, :live_pt], a32[:79, :live_pt], rtol=2e-5, atol=2e-6)
+        m32 = a32[79:, :live_pt].copy().view(np.uint16).reshape(3, live_pt, 32, 64)     # [block][pt][mask index & 31][lane]
+        m16 = a16[79:, :live_pt].copy().view(np.uint16).reshape(3, live_pt, 32, 64)
+        used = np.zeros((3, 32), bool)
+        used.reshape(-1)[:68] = True                                    # 64 trunk tiles + 4 view-branch tiles
+        x = (m32.transpose(0, 2, 1, 3)[used] ^ m16.transpose(0, 2, 1, 3)[used])
+        diff_bits = int(np.unpackbits(np.ascontiguousarray(x).view(np.uint8)).sum())
+        total_bits = x.size * 16
+        assert diff_bits <= max(8, 2e-5 * total_bits), (diff_bits, total_bits)       # only activations within rounding of zero
+        d_raw = torch.randn(B, S, 4, generator=torch.Generator().manual_seed(B)).to(cuda)
+        out = {}
+        for name, tw in (('two_wave', pw), ('one_wave', None)):
+            for p in ps:
+                p.grad = None
+            raw = ops.mlp_rays(rows, z, packed, ps, train_f16x3=p32, train_f16x3_w16=tw)
+            raw.backward(d_raw)
+            out[name] = (N(raw), [N(p.grad) for p in ps])
+        np.testing.assert_allclose(out['two_wave'][0], out['one_wave'][0], rtol=2e-5, atol=2e-6)
+        for a_, b_ in zip(out['two_wave'][1], out['one_wave'][1]):
+            assert np.linalg.norm(a_ - b_) <= 1e-2 * np.linalg.norm(b_)
+
+
 def test_render_f16x3_matches_fp32_render(cuda):
     from mvip_nerf_amd import run
     import types as _t
