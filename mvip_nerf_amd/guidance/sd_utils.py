@@ -124,6 +124,35 @@ class _InjectGrad(torch.autograd.Function):
         return d_pred * upstream, None
 
 
+class _NoiseFeed:
+    """What StableDiffusion._randn hands out while a step is being captured / warmed up.  A captured step contains NO random
+    number generation (round 5): a hipGraph that draws reads the generator's seed / offset from device words the GENERATOR owns,
+    written by every replay's prologue -- two captured steps replaying side by side on different streams (nerf/utils.cal_loss)
+    then race on those words and draw from each other's offsets.  Instead the draws of a step are recorded once (shapes, order),
+    kept as static input buffers of the graph, and filled EAGERLY before each replay, in the recorded order, from the same
+    generator: the values an eager step would have drawn."""
+
+    def __init__(self):
+        self.recording, self.specs, self.buffers, self.pos = True, [], [], 0
+
+    def take(self, sd, shape, dtype):
+        if self.recording:
+            self.specs.append((tuple(shape), dtype))
+            return torch.randn(tuple(shape), device=sd.device, dtype=dtype, generator=sd.generator)
+        buf = self.buffers[self.pos]
+        assert tuple(buf.shape) == tuple(shape) and buf.dtype == dtype, 'the captured step draws what the recorded step drew'
+        self.pos += 1
+        return buf
+
+    def freeze(self, device):
+        self.recording = False
+        self.buffers = [torch.zeros(shape, device=device, dtype=dt) for shape, dt in self.specs]
+
+    def refill(self, generator):
+        for b in self.buffers:
+            b.normal_(generator=generator)
+
+
 class _GraphedStep:
     """The whole single-view SDS step -- resize, masking, two VAE encodes, add_noise, UNet (CFG batch),
     SDS gradient, and the backward through the VAE encoder to the image -- captured once as a hipGraph.
@@ -141,37 +170,44 @@ class _GraphedStep:
         self.acc = torch.zeros(1, 4, 64, 64, device=dev) if mode != 'single' else None
         self.scal = torch.zeros(4, device=dev)                  # sqrt(abar), sqrt(1-abar), 1-abar, t
         sd.networks.encode_prompt(prompt, guidance_scale > 1.0)    # cached constant, outside the capture
-        # Warm-up and capture run the body three times and DRAW each time; an eager step draws once.  The generator's state
-        # is put back afterwards, so that the first replay consumes exactly the draws an eager first step would have (measured:
-        # replays equal eager steps to atomics-level, 2e-6 relative, draw for draw -- profiles/r4_graph_vs_eager_draws.json --
-        # once the starting state is the same).
+        # The first warm-up run DRAWS (and records what it draws); the generator's state is put back afterwards, so that the
+        # first replay consumes exactly the draws an eager first step would have (measured: replays equal eager steps to
+        # atomics-level, 2e-6 relative, draw for draw -- profiles/r4_graph_vs_eager_draws.json).
         # the default generator of the device the draws are made on: a bare 'cuda' means the CURRENT device, not device 0
         dev_index = torch.device(dev).index
         if dev_index is None:
             dev_index = torch.cuda.current_device()
         gen = sd.generator if sd.generator is not None else torch.cuda.default_generators[dev_index]
         gen_state = gen.get_state()
+        # this graph's OWN scratch words (ops.ZERO_SCOPE): two captured steps may replay side by side on different streams
+        # (nerf/utils.Pretrain_Model.cal_loss runs the RGB / normal / collaborative terms concurrently)
+        from .. import ops as _ops
+        scope_before, _ops.ZERO_SCOPE = _ops.ZERO_SCOPE, ('graph', id(self))
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):                           # warm-up (library autotuning) before capture
-            for _ in range(2):
+        self.noise = _NoiseFeed()                               # first warm-up run: records what the step draws
+        sd._noise_feed = self.noise
+        try:
+            with torch.cuda.stream(side):                       # warm-up (library autotuning) before capture
                 self._body()
-        cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        self.generator = sd.generator
-        if sd.generator is not None:
-            # a private generator is invisible to the capture unless registered: its draws would be baked in
-            if not hasattr(self.graph, 'register_generator_state'):
-                raise RuntimeError('use_graphs with a private generator needs CUDAGraph.register_generator_state')
-            self.graph.register_generator_state(sd.generator)
-        # thread_local: another thread of this process (an RCCL watchdog, a data loader) may touch the device meanwhile
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.d_pred = self._body()
+                self.noise.freeze(dev)                          # from here on the draws are static input buffers
+                self.noise.pos = 0
+                self._body()
+            cur.wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            self.generator = sd.generator
+            self.noise.pos = 0
+            # thread_local: another thread of this process (an RCCL watchdog, a data loader) may touch the device meanwhile
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.d_pred = self._body()
+        finally:
+            sd._noise_feed = None
         # everything the capture read from per-prompt caches (the cross-attention's key / value planes, filled by the
         # warm-up above) lives as long as this graph, whatever another prompt does to those caches afterwards
         from . import transformer_cm
         self.pinned = transformer_cm.prompt_entries(sd.unet) if isinstance(sd.unet, nn.Module) else []
+        _ops.ZERO_SCOPE = scope_before
         gen.set_state(gen_state)
 
     def _body(self):
@@ -212,6 +248,7 @@ class _GraphedStep:
         self.mask.copy_(mask)
         if self.acc is not None:
             self.acc.copy_(acc.reshape(1, 4, 64, 64))
+        self.noise.refill(self.sd.generator)                    # this step's draws, eagerly, in the order an eager step makes them
         self.graph.replay()
         if self.mode == 'single':
             return self.d_pred.clone()
@@ -288,7 +325,11 @@ class StableDiffusion(nn.Module):
         self.generator = self._private_gen
         return self._private_gen
 
+    _noise_feed = None    # a _NoiseFeed while a step is being warmed up / captured (see _GraphedStep)
+
     def _randn(self, shape, dtype=torch.float32):
+        if self._noise_feed is not None:
+            return self._noise_feed.take(self, shape, dtype)
         return torch.randn(tuple(shape), device=self.device, dtype=dtype, generator=self.generator)
 
     def _encode_vae_image(self, image):

@@ -54,19 +54,54 @@ class Pretrain_Model(object):
         loss = 0
         if 'SD' in self.guidance:
             sd = self.guidance['SD']
+            terms = []                                  # in the reference's order (its random draws are made in this order)
             if opt.is_rgb_guidance:
-                loss = loss + sd.train_step_sd(i, masks, opt.text, self.pred_rgb, as_latent=True,
-                                               guidance_scale=opt.rgb_guidance_scale,
-                                               grad_scale=opt.lambda_guidance,
-                                               save_guidance_path=getattr(opt, 'save_guidance_path', None))
-            if opt.is_colla_guidance and i > 0:
-                loss = loss + sd.train_step_colla_sds(i, mask4, opt.text, self.rgbs4_tensor, as_latent=True,
-                                                      guidance_scale=opt.colla_guidance_scale,
+                terms.append(lambda: sd.train_step_sd(i, masks, opt.text, self.pred_rgb, as_latent=True,
+                                                      guidance_scale=opt.rgb_guidance_scale,
                                                       grad_scale=opt.lambda_guidance,
-                                                      save_guidance_path=getattr(opt, 'save_guidance_path', None))
+                                                      save_guidance_path=getattr(opt, 'save_guidance_path', None)))
+            if opt.is_colla_guidance and i > 0:
+                terms.append(lambda: sd.train_step_colla_sds(i, mask4, opt.text, self.rgbs4_tensor, as_latent=True,
+                                                             guidance_scale=opt.colla_guidance_scale,
+                                                             grad_scale=opt.lambda_guidance,
+                                                             save_guidance_path=getattr(opt, 'save_guidance_path', None)))
             if opt.is_normal_guidance and i > opt.normal_start:
-                loss = 1.0 * loss + 1.0 * sd.train_step_sd_normal(
+                terms.append(lambda: sd.train_step_sd_normal(
                     i, masks, opt.text_normal, self.pre_normal_map, as_latent=True,
                     guidance_scale=opt.normal_guidance_scale, normal_start=opt.normal_start,
-                    grad_scale=opt.lambda_guidance, save_guidance_path=getattr(opt, 'save_guidance_path', None))
+                    grad_scale=opt.lambda_guidance, save_guidance_path=getattr(opt, 'save_guidance_path', None)))
+            streams = self._term_streams(sd, len(terms))
+            if streams is None:
+                for fn in terms:
+                    loss = loss + fn()
+            else:
+                # The terms are independent diffusion-prior evaluations (the reference runs them one after the other,
+                # DS_NeRF/nerf/utils.py:280-302): each replays its captured step on a stream of its own -- thousands of small
+                # launches whose boundaries and bandwidth-bound passes fill each other's gaps -- and the sum joins them.  The host
+                # issues them in the reference's order, so the random draws keep their order.  MVIP_SDS_TERM_STREAMS=0: in line.
+                cur = torch.cuda.current_stream(self.device)
+                outs = []
+                for fn, st in zip(terms, streams):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        out = fn()
+                    if torch.is_tensor(out):
+                        out.record_stream(cur)
+                    outs.append(out)
+                for st in streams:
+                    cur.wait_stream(st)
+                for out in outs:
+                    loss = loss + out
         return loss
+
+    def _term_streams(self, sd, n):
+        """One stream per SDS term when the terms are captured steps on a GPU (n >= 2), else None."""
+        import os
+        if n < 2 or os.environ.get('MVIP_SDS_TERM_STREAMS', '1') == '0' or not getattr(sd, 'use_graphs', False):
+            return None
+        if torch.device(self.device).type != 'cuda':
+            return None
+        pool = self.__dict__.setdefault('_streams', [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=self.device))
+        return pool[:n]

@@ -1418,12 +1418,15 @@ def tokens_conv1x1(h, conv, residual):
 # Transformer blocks of the SDS UNet: attention and token-side kernels (csrc/attention.hip, csrc/transformer.hip) -----
 
 _ZERO_WORDS = {}
+ZERO_SCOPE = None      # set by a hipGraph capture (guidance/sd_utils._GraphedStep) to a token of its own: every capture runs on
+                       # torch's ONE shared capture stream, so without it all captured steps would bake in the SAME scratch words
+                       # -- harmless while graphs replay one after the other, a race once two of them replay on different streams
 
 
 def _zero_words(device):
-    """64 scratch words per (device, stream) that are zero between kernel launches: the absmax collectors use them
-    with atomics and the kernel that reads the maximum re-zeroes them (saves a zeroing launch per use)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """64 scratch words per (device, stream[, capturing graph]) that are zero between kernel launches: the absmax collectors
+    use them with atomics and the kernel that reads the maximum re-zeroes them (saves a zeroing launch per use)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, ZERO_SCOPE)
     if key not in _ZERO_WORDS:
         _ZERO_WORDS[key] = torch.zeros(64, device=device, dtype=torch.int32)
     return _ZERO_WORDS[key]

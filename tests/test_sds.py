@@ -1115,3 +1115,49 @@ def test_posterior_sample_and_timestep_embedding_kernels(cuda):
         np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=5e-7)
         ref64 = torch.cat([torch.cos(args.double()), torch.sin(args.double())], -1)          # and against the exact functions
         np.testing.assert_allclose(got.cpu().numpy(), ref64.cpu().numpy(), rtol=0, atol=5e-7)
+
+
+def test_concurrent_sds_terms_equal_sequential_terms(cuda):
+    """Pretrain_Model.cal_loss (DS_NeRF/nerf/utils.py:280-302) with its terms on one stream each (round 5: the captured RGB /
+    collaborative / normal steps replay side by side) against the same terms in line: same draws, the gradients with respect to
+    the RGB frame, the normal map and the neighbour views are EQUAL (each graph owns its scratch words, ops.ZERO_SCOPE; the steps
+    share nothing else that is written), three iterations in a row."""
+    import types
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    from mvip_nerf_amd.nerf.utils import Pretrain_Model
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False, use_graphs=True)
+    opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=True, is_normal_guidance=True, normal_start=0,
+                                text='a stone bench in a park', text_normal='a normal map of a stone bench in a park',
+                                rgb_guidance_scale=7.5, colla_guidance_scale=7.5, normal_guidance_scale=7.5, lambda_guidance=1.0,
+                                uniform_sphere_rate=0.5)
+    pm = Pretrain_Model(opt, cuda, {'SD': sd})
+    gen = torch.Generator(device=cuda).manual_seed(9)
+    H, W = 96, 128
+    rgb0 = torch.rand(1, 3, H, W, device=cuda, generator=gen)
+    nrm0 = torch.rand(1, 3, H // 2, W // 2, device=cuda, generator=gen)
+    nb0 = torch.rand(2, 3, H // 2, W // 2, device=cuda, generator=gen)
+    mask = torch.zeros(1, 1, H, W, device=cuda)
+    mask[:, :, 30:70, 40:100] = 1
+    mask4 = mask.expand(2, 1, H, W).contiguous()
+    real_streams = pm._term_streams
+    out = {}
+    for mode in ('streams', 'in_line', 'streams'):
+        pm._term_streams = real_streams if mode == 'streams' else (lambda sd_, n: None)
+        import random
+        random.seed(3)
+        torch.cuda.manual_seed(321)
+        grads = []
+        for it in (5, 6, 7):
+            rgb, nrm, nb = (t.clone().requires_grad_(True) for t in (rgb0, nrm0, nb0))
+            loss = pm.cal_loss(it, nb, nrm, None, rgb, None, mask, mask4, 1)
+            (1e-4 * loss).sum().backward()
+            grads.append((rgb.grad.clone(), nrm.grad.clone(), nb.grad.clone()))
+        out.setdefault(mode, []).append(grads)
+    assert pm.__dict__.get('_streams') and len(pm._streams) == 3
+    ref = out['in_line'][0]
+    for run_ in out['streams']:
+        for ga, gb in zip(run_, ref):
+            for a, b in zip(ga, gb):
+                assert float(b.abs().max()) > 0
+                assert float((a - b).norm() / b.norm()) < 1e-4           # graph replays differ by fp32 atomics order only
