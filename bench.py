@@ -595,6 +595,9 @@ def main():
         result['render_f16x3'] = {
             'rays_per_sec': rays_per_step * args.steps / dt_fast, 'ms_per_step': dt_fast / args.steps * 1e3,
             'dtype': 'f16x3 (fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate)',
+            'kernel': 'mvip::f16h::mlp_forward_f16x3_w16_kernel (csrc/mlp_fwd16_f16x3.hip: 16 points per wave on v_mfma_f32_16x16x32_f16, '
+                      'two waves per SIMD; round 4 ran the 32-point one-wave kernel at 102-104 ms per frame)',
+            'fp16_product_TFLOPs': round(3 * rays_per_step * args.steps * 192 * FLOP_PER_POINT / dt_fast / 1e12, 1),
             'psnr_vs_f32_render_dB': -10 * math.log10(max(mse_fast, 1e-30)),
             'max_abs_pixel_diff': float((fast_img - ref_img).abs().max())}
 
