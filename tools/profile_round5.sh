@@ -29,9 +29,8 @@ for r in rows[1:41]:
     r[0]=r[0][:110]; w.writerow(r)
 "
 find gpurun_out/prof_r5 -name '*kernel_trace.csv' -delete; find gpurun_out/prof_r5 -name '*.db' -delete
-MVIP_SDS_GRAPHS=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_r5 -o run -- python3 bench.py --steps 1 --warmup 0 --train-steps 1 --sds-steps 1 --no-cpu-baseline --no-hashgrid > gpurun_out/pmc_r5/line.json 2> gpurun_out/pmc_r5/err.log
-find gpurun_out/pmc_r5 -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_summary.py {} gpurun_out/r5_pmc_mfma_util.json > gpurun_out/pmc_r5/summary_top.txt
-find gpurun_out/pmc_r5 -name '*.csv' -delete; find gpurun_out/pmc_r5 -name '*.db' -delete
+MVIP_HEAD=$HEAD bash tools/pmc_mfma_util.sh > gpurun_out/pmc_r5/summary_top.txt 2>&1     # three bounded passes (see the script)
+cd /tmp; cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
   c=$(echo $C | tr A-Z a-z | sed 's/_size//')
   D=gpurun_out/pmc_r5_$c; mkdir -p $D
