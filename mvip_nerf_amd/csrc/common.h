@@ -84,10 +84,10 @@ __device__ __forceinline__ float dpp_from_next(float v, float last) { return dpp
 // rows 1 and 3) and row_bcast:31 (into rows 2 and 3) -- six dependent VALU steps
 template <class T, class Dpp>
 __device__ __forceinline__ T dpp_incl_scan_add(T v, Dpp) {
-    v += Dpp::template f<0x111>((T)0, v);
-    v += Dpp::template f<0x112>((T)0, v);
-    v += Dpp::template f<0x114>((T)0, v);
-    v += Dpp::template f<0x118>((T)0, v);
+    v += Dpp::template z<0x111>(v);
+    v += Dpp::template z<0x112>(v);
+    v += Dpp::template z<0x114>(v);
+    v += Dpp::template z<0x118>(v);
     v += Dpp::template f<0x142, 0xa>((T)0, v);
     v += Dpp::template f<0x143, 0xc>((T)0, v);
     return v;
@@ -102,8 +102,23 @@ __device__ __forceinline__ float dpp_incl_prod(float v) {
     v *= dpp_f32<0x143, 0xc>(1.f, v);
     return v;
 }
-struct DppF32 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ float f(float o, float v) { return dpp_f32<C, R, B>(o, v); } };
-struct DppF64 { template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ double f(double o, double v) { return dpp_f64<C, R, B>(o, v); } };
+// z<C>: the unmasked steps, a lane without a source reads zero (bound_ctrl) -- for the 64-bit form that is ONE v_mov_b32_dpp per
+// half with no zero-initialised destination (the masked form needs the "old" value in place: two more moves per step)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_zero(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(x >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+struct DppF32 {
+    template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ float f(float o, float v) { return dpp_f32<C, R, B>(o, v); }
+    template <int C> static __device__ __forceinline__ float z(float v) { return dpp_f32<C>(0.f, v); }
+};
+struct DppF64 {
+    template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ double f(double o, double v) { return dpp_f64<C, R, B>(o, v); }
+    template <int C> static __device__ __forceinline__ double z(double v) { return dpp_f64_zero<C>(v); }
+};
 __device__ __forceinline__ float dpp_incl_sum(float v) { return dpp_incl_scan_add<float>(v, DppF32{}); }
 __device__ __forceinline__ double dpp_incl_sum(double v) { return dpp_incl_scan_add<double>(v, DppF64{}); }
 // total over the wave, in every lane (the scan's last lane, read back through a scalar register)

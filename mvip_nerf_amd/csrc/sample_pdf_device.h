@@ -19,6 +19,30 @@ __device__ __forceinline__ float strided_get(const float (&v)[IT], int e) {
     return out;
 }
 
+// value of lane `src` (0 .. 63, NOT masked here) of v: ds_bpermute on the byte address -- HIP's __shfl adds a mask, an or and a
+// shift per read for widths and out-of-range lanes that do not occur in this file
+__device__ __forceinline__ float lane_read(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
+}
+
+// #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
+// +inf): six binary-search steps on cross-lane reads + one probe for the count 64.  The running count is kept as a BYTE
+// address (4 x count): the probe's lane (count + step - 1) is then that register plus a constant, which rides in the
+// instruction's offset field, and a successful probe sets one bit -- compare, select, or: three VALU instructions per step.
+template <bool STRICT>
+__device__ __forceinline__ int count_below(const float key, const float x) {
+    int cnt4 = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cnt4 + (step - 1) * 4, __builtin_bit_cast(int, key)));
+        cnt4 |= (STRICT ? c < x : c <= x) ? step * 4 : 0;
+    }
+    int cnt = cnt4 >> 2;
+    const float c63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), 63));   // the steps sum to at most 63
+    if (cnt == 63 && (STRICT ? c63 < x : c63 <= x)) cnt = 64;
+    return cnt;
+}
+
 // bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
 // Produces samples (strided) and inds; cdf_out strided (nb entries).
 // Up to 64 bins (the reference configuration: 63 midpoints of 64 coarse samples): everything in one register
@@ -43,18 +67,10 @@ __device__ __forceinline__ bool inverse_cdf_fast(const float bins, const float w
     const float incl = (float)run;                              // cdf[l + 1]
     const float cdf = dpp_from_prev(incl, 0.f);                 // cdf[l], valid for l < nb (cdf[0] = 0)
     const float key = l < nb ? cdf : INFINITY;
-    int cnt = 0;                                                // #{k < nb : cdf[k] <= u}
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int probe = cnt + step;
-        const float c = __shfl(key, (probe - 1) & 63, 64);
-        if (probe <= 64 && c <= u) cnt = probe;
-    }
-    const float c63 = __shfl(key, 63, 64);                      // the steps sum to at most 63: one more probe for 64
-    if (cnt == 63 && c63 <= u) cnt = 64;
+    const int cnt = count_below<false>(key, u);                 // #{k < nb : cdf[k] <= u}
     const int below = max(0, cnt - 1), above = min(nb - 1, cnt);
-    const float cb = __shfl(cdf, below, 64), ca = __shfl(cdf, above, 64);
-    const float bb = __shfl(bins, below, 64), ba = __shfl(bins, above, 64);
+    const float cb = lane_read(cdf, below), ca = lane_read(cdf, above);
+    const float bb = lane_read(bins, below), ba = lane_read(bins, above);
     float den = ca - cb;
     den = den < 1e-5f ? 1.f : den;
     const float t = (u - cb) / den;
@@ -219,22 +235,6 @@ __device__ __forceinline__ int dpp_incl_max_nonneg(int v) {
     return v;
 }
 
-// #{k < 64 : key[k] < x} (STRICT = true) or <= x, for a lane-sorted key register (lanes beyond the valid count hold
-// +inf): six binary-search steps on cross-lane reads + one probe for the count 64.
-template <bool STRICT>
-__device__ __forceinline__ int count_below(const float key, const float x) {
-    int cnt = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int probe = cnt + step;
-        const float c = __shfl(key, (probe - 1) & 63, 64);
-        if (probe <= 64 && (STRICT ? c < x : c <= x)) cnt = probe;
-    }
-    const float c63 = __shfl(key, 63, 64);
-    if (cnt == 63 && (STRICT ? c63 < x : c63 <= x)) cnt = 64;
-    return cnt;
-}
-
 // Merge of two SORTED lists of <= 64 values each by rank: element i of a lands at i + #{b < a_i}, element j of b at
 // j + #{a <= b_j} (ties: the coarse depth first; the VALUES equal those of sort(cat[a, b]) in every case).  12
 // cross-lane reads and two scattered 4-byte stores into the ray's own 512-byte row instead of the 28-stage / 54-shuffle
@@ -250,9 +250,9 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
     const int l = lane_id();
     const float a_key = l < na ? a : INFINITY;
     float b_key = l < nb ? b : INFINITY;
-    if (__any(a_key != a_key) || __any(b_key != b_key)) return false;      // NaN depths: leave it to the network
     const float a_next = dpp_from_next(a_key, a_key), b_next = dpp_from_next(b_key, b_key);
-    if (__any(l < 63 && a_next < a_key)) return false;
+    // NaN depths (leave them to the network) or coarse depths out of order: one ballot
+    if (__any((a_key != a_key) | (b_key != b_key) | (l < 63 && a_next < a_key))) return false;
     bool b_in_lane_order = true;
     if (__any(l < 63 && b_next < b_key)) {
         if (!b_may_be_unsorted) return false;
@@ -264,7 +264,7 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
     int cb = -1;
     if (b_in_lane_order && below_hint >= 0) {
         const int r0 = below_hint + 1;                           // a_0 .. a_{r0 - 1} <= b_j
-        const float a0 = __shfl(a_key, r0 & 63, 64), a1 = __shfl(a_key, (r0 + 1) & 63, 64);
+        const float a0 = lane_read(a_key, r0 & 63), a1 = lane_read(a_key, (r0 + 1) & 63);
         const float e0 = r0 < 64 ? a0 : INFINITY, e1 = r0 + 1 < 64 ? a1 : INFINITY;
         cb = r0 + (e0 <= b_key ? 1 : 0);
         if (__any(l < nb && !(e1 > b_key))) cb = -1;             // wave-uniform: the ballot covers every valid lane
@@ -277,7 +277,9 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
         // 65-word row of LDS (one writer per word), lane i reads word i, and an inclusive prefix maximum (six DPP steps)
         // finishes the count: 3 LDS operations + ~15 VALU instructions instead of the seven-step cross-lane search (~45).
         // One wave owns the row and LDS operations of a wave execute in order: no barrier.
-        volatile int *row = lds_w;
+        // LDS address space spelled out: through the generic pointer these were flat_store / flat_load with sc0 sc1 and a
+        // full s_waitcnt vmcnt(0) after each of the four accesses
+        volatile __attribute__((address_space(3))) int *row = (volatile __attribute__((address_space(3))) int *)lds_w;
         row[l] = 0;
         if (l == 0) row[64] = 0;
         const int cb_next = dpp_i32<0x130>(-1, cbj);            // lane l + 1's count (lane 63: -1 = "differs")
@@ -329,8 +331,12 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
         }
         if (cdf_out && e < nb) cdf_out[ray * nb + e] = cdf[i];
     }
-    // population std of the new samples (torch.std(unbiased=False))
-    const float mean = dpp_wave_sum(s1) / (float)Nf;
+    // population std of the new samples (torch.std(unbiased=False)).  1 / Nf by v_rcp_f32 (exact for the powers of two of the
+    // reference configurations, 1 ulp otherwise) and v_sqrt_f32 (1 ulp): the sums above are wave reductions, not torch's
+    // summation order, so the statistic is compared at a tolerance either way -- and two IEEE division sequences + one square
+    // root sequence were ~35 of this kernel's ~400 VALU instructions per ray
+    const float inv_nf = __builtin_amdgcn_rcpf((float)Nf);
+    const float mean = dpp_wave_sum(s1) * inv_nf;
     float s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -338,7 +344,7 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
         if (e < Nf) { const float d = smp[i] - mean; s2 += d * d; }
     }
     s2 = dpp_wave_sum(s2);
-    if (l == 0) z_std[ray] = sqrtf(s2 / (float)Nf);
+    if (l == 0) z_std[ray] = __builtin_amdgcn_sqrtf(s2 * inv_nf);
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
     if constexpr (IT == 1) {
