@@ -14,7 +14,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float *__restrict__ noise, int64_t B, int S, int flags, float *__restrict__ rgb,
     float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ depth,
     float *__restrict__ weights, float *__restrict__ alpha) {
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave index through readfirstlane: the ray number and the row bases are scalar values, not 64-bit vector arithmetic per access
+    const int64_t ray = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (ray >= B) return;
     const int l = lane_id();
     RayState<ITEMS> st;
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float *__restrict__ noise, int64_t B, int S, int flags, const float *__restrict__ g_rgb,
     const float *__restrict__ g_disp, const float *__restrict__ g_acc, const float *__restrict__ g_depth,
     const float *__restrict__ g_w, const float *__restrict__ g_alpha, float *__restrict__ d_raw) {
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave index through readfirstlane: the ray number and the row bases are scalar values, not 64-bit vector arithmetic per access
+    const int64_t ray = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (ray >= B) return;
     const int l = lane_id();
     RayState<ITEMS> st;

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256)
 stratified_zw_kernel(const float *__restrict__ rows, int ncols, int64_t B, int S, const float *__restrict__ t_vals,
                      int lindisp, const float *__restrict__ t_rand, float *__restrict__ z) {
     const int lane = threadIdx.x & 63;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ZW_RAYS;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * ZW_RAYS;     // scalar
     if (r0 >= B) return;
     const int nr = (int)((B - r0 < ZW_RAYS) ? B - r0 : ZW_RAYS);
     const int64_t rl = r0 + (lane < nr ? lane : nr - 1);
