@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_f16x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dt[r] = 0.f;
         if (hh == 0) { dt[0] = d.x; dt[1] = d.y; dt[2] = d.z; dt[3] = d.w; }
-        store_tile(stash_block(gst, GT_D, n_pt, pt), dt, j, hh);
+        store_tile<true>(stash_block(gst, GT_D, n_pt, pt), dt, j, hh);
     }
     // Per-point power-of-two scaling.  Delta propagation is linear in each point's d_raw, and a
     // column scale of the B operand is the same column scale of the MFMA result, so every point is
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void mlp_delta_f16x3_kernel(
         f32x16 u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) u[r] = t[r] * inv_s;
-        store_tile(stash_block(gst, row_tile, n_pt, pt), u, j, hh);
+        store_tile<true>(stash_block(gst, row_tile, n_pt, pt), u, j, hh);
     };
 
     unsigned vt[4];

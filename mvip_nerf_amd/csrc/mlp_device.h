@@ -249,10 +249,25 @@ constexpr int TILE_FLOATS = 1024;
 __device__ __forceinline__ float *stash_block(float *base, int row_tile, int64_t n_pt, int64_t pt) {
     return base + ((int64_t)row_tile * n_pt + pt) * TILE_FLOATS;
 }
+// Stash stores of the SPLIT-PRECISION training kernels are NON-TEMPORAL (global_store ... nt, round 5): 8 KB per point stream out
+// of them, and as ordinary stores they allocate in the 4-MB L2 of the XCD and evict the weight image every workgroup re-streams
+// from it -- the stash-writing split-precision forward ran 33.9 ms per configs[2] iteration with ordinary stores and 27.4 ms
+// with these, the whole iteration 154 -> 144 ms (profiles/r5_nt_stash_ab.json).  The exact-fp32 kernels (NT = false) keep
+// ordinary stores: they are bound by the fp32 matrix pipe and measured equal to slightly slower with the hint.
+template <bool NT>
+__device__ __forceinline__ void stash_store(float *p, float v) {
+#ifdef MVIP_EXPERIMENT_PLAIN_STASH                 // A/B build only: ordinary stores everywhere
+    *p = v;
+#else
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+#endif
+}
+template <bool NT = false>
 __device__ __forceinline__ void store_tile(float *__restrict__ block, const f32x16 &tile, int j, int hh) {
     float *p = block + hh * 128 + j;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[(8 * (r >> 2) + (r & 3)) * 32] = tile[r];
+    for (int r = 0; r < 16; ++r) stash_store<NT>(p + (8 * (r >> 2) + (r & 3)) * 32, tile[r]);
 }
 __device__ __forceinline__ f32x16 load_tile(const float *__restrict__ block, int j, int hh) {
     const float *p = block + hh * 128 + j;

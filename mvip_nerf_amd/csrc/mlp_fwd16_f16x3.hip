@@ -298,7 +298,7 @@ mlp_forward_f16x3_w16_kernel(const float *__restrict__ img, const float *__restr
         if constexpr (STASH) {
             constexpr int t16 = decltype(t16_)::value, MI = decltype(mi_)::value;
             float *q = stash + ((int64_t)(t16 >> 1) * n_pt + pt_wave) * 1024 + (t16 & 1) * 512 + stash_lane;
-            q[0] = t[0]; q[32] = t[1]; q[64] = t[2]; q[96] = t[3];
+            stash_store<true>(q, t[0]); stash_store<true>(q + 32, t[1]); stash_store<true>(q + 64, t[2]); stash_store<true>(q + 96, t[3]);      // non-temporal: mlp_device.h
             if constexpr (MI >= 0) {
                 unsigned nib = 0;
 #pragma unroll

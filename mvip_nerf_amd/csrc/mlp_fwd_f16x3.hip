@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_f16x3_kernel(
     const int64_t p = p_begin + pl;
     auto stash_tile = [&](int row_tile, const f32x16 &t) {          // fp32 activations, same stash as precision 0
         if constexpr (STASH) {
-            store_tile(stash_block(stash, row_tile, n_pt, pt), t, j, hh);
+            store_tile<true>(stash_block(stash, row_tile, n_pt, pt), t, j, hh);
             // + the ReLU sign mask of the trunk / view-branch tiles: all the delta kernel reads of them (mlp_device.h)
             if (row_tile < AT_FEAT) *mask_slot(stash, row_tile, n_pt, pt, lane) = (unsigned short)tile_sign_mask(t);
             else if (row_tile >= AT_V && row_tile < AT_V + 4)
