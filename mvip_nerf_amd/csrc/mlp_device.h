@@ -250,10 +250,11 @@ __device__ __forceinline__ float *stash_block(float *base, int row_tile, int64_t
     return base + ((int64_t)row_tile * n_pt + pt) * TILE_FLOATS;
 }
 // Stash stores of the SPLIT-PRECISION training kernels are NON-TEMPORAL (global_store ... nt, round 5): 8 KB per point stream out
-// of them, and as ordinary stores they allocate in the 4-MB L2 of the XCD and evict the weight image every workgroup re-streams
-// from it -- the stash-writing split-precision forward ran 33.9 ms per configs[2] iteration with ordinary stores and 27.4 ms
-// with these, the whole iteration 154 -> 144 ms (profiles/r5_nt_stash_ab.json).  The exact-fp32 kernels (NT = false) keep
-// ordinary stores: they are bound by the fp32 matrix pipe and measured equal to slightly slower with the hint.
+// of them.  Measured (profiles/r5_nt_stash_ab.json): the stash-writing split-precision forward 33.9 -> 27.4 ms per configs[2]
+// iteration, the iteration 154 -> 144 ms -- with the SAME L2 hit rate (0.73) and the SAME HBM bytes either way: as ordinary
+// write-back stores they fill the XCD's 4-MB L2 with dirty lines and the kernel's weight DMA queues behind them whenever the
+// write-backs back up; as streaming stores they drain without that.  The exact-fp32 kernels (NT = false) write the same bytes
+// over twice the time, measure equal to slightly slower with the hint, and keep ordinary stores.
 template <bool NT>
 __device__ __forceinline__ void stash_store(float *p, float v) {
 #ifdef MVIP_EXPERIMENT_PLAIN_STASH                 // A/B build only: ordinary stores everywhere
