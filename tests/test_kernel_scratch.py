@@ -175,3 +175,38 @@ def test_no_shipped_kernel_uses_scratch():
             continue
         bad.append(f'{stem}: {d[:140]}: scratch {scratch} B, {vspill} VGPRs / {sspill} SGPRs spilled')
     assert not bad, 'kernels with scratch:\n' + '\n'.join(bad)
+
+
+def _disassembly(obj, mangled):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, 'fat.bin'), os.path.join(d, 'k.co')
+        subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section', f'.hip_fatbin={fat}', obj], check=True)
+        subprocess.run([os.path.join(LLVM, 'clang-offload-bundler'), '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                        f'--input={fat}', f'--output={co}', '--unbundle'], check=True)
+        return subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', f'--disassemble-symbols={mangled}', co],
+                              capture_output=True, text=True, check=True).stdout
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, 'clang-offload-bundler')), reason='needs the ROCm LLVM tools')
+def test_split_precision_stash_stores_are_streaming_stores():
+    """Round 5: the activation / delta stash of the split-precision training kernels leaves through non-temporal stores
+    (csrc/mlp_device.h::stash_store<true>; configs[2] 154 -> 144 ms, profiles/r5_nt_stash_ab.json); the exact-fp32 kernels
+    keep ordinary stores.  Checked on the ISA of the in-tree build."""
+    from mvip_nerf_amd.csrc.build import build
+    build(verbose=False)
+    obj = lambda stem: glob.glob(os.path.join(ROOT, 'mvip_nerf_amd', 'lib', 'obj', stem + '.*.o'))[0]
+    count = lambda dis: (len(re.findall(r'global_store_dword\s[^\n]*\bnt\b', dis)), len(re.findall(r'global_store_dword\s', dis)))
+    # the stash-writing two-wave forward <rays, STASH, 16, 4>: 632 of its stores are stash rows, one is the raw output
+    nt, total = count(_disassembly(obj('mlp_fwd16_f16x3'), '_ZN4mvip4f16h28mlp_forward_f16x3_w16_kernelILb1ELb1ELi16ELi4EEEvPKfS3_S3_liPfS4_l'))
+    assert nt >= 600 and total - nt <= 4, (nt, total)
+    names = [k[0] for k in _kernels(obj('mlp_bwd_f16x3'))]
+    delta = [n for n in names if 'mlp_delta_f16x3_kernel' in n]
+    assert delta
+    nt, total = count(_disassembly(obj('mlp_bwd_f16x3'), delta[0]))
+    assert nt >= 100 and nt >= 0.9 * total, (nt, total)
+    # exact fp32: ordinary stores
+    names = [k[0] for k in _kernels(obj('mlp_bwd16'))]
+    d16 = [n for n in names if 'mlp_delta16_kernel' in n]
+    assert d16
+    nt, total = count(_disassembly(obj('mlp_bwd16'), d16[0]))
+    assert nt == 0 and total > 100, (nt, total)
