@@ -153,12 +153,14 @@ def mlp_unpack_grads(grad_packed, like):
 
 _WORKSPACE = {}
 import os as _os
-# points per backward tile: delta + weight-gradient launches per tile, 20 KB of G/activation workspace per point (21 GB at
-# 1,048,576 -- HBM is 288 GB).  Measured in round 5 on configs[2] / configs[3] iterations (one box, ms): 16,384 points 221 / -,
-# 32,768 175, 65,536 156, 131,072 146, 262,144 143.0 / 399.9 (the default until then), 524,288 141.9 / 397.9, 1,048,576
-# 140.9 / 397.0: the weight-gradient launches pay a ramp and a 256 x 256 atomic flush per workgroup and tile.  The configs[1]
-# iteration (2.6 M points) measures the same at every size from 262,144 up.
-BWD_TILE_POINTS = int(_os.environ.get('MVIP_BWD_TILE_POINTS', 1048576))
+# points per backward tile: delta + weight-gradient launches per tile, 20 KB of G/activation workspace per point (5.2 GB at
+# 262,144).  Measured in round 5 on configs[2] / configs[3] iterations (one box, ms): 16,384 points 221 / -, 32,768 175,
+# 65,536 156, 131,072 146, 262,144 143.0 / 399.9, 524,288 141.9 / 397.9, 1,048,576 140.9 / 397.0 (the weight-gradient launches
+# pay a ramp and a 256 x 256 atomic flush per workgroup and tile); the configs[1] iteration measures the same from 262,144 up.
+# The default stays at 262,144: as the default, the 21-GB workspace of 1,048,576 ran tests/test_configs_large.py's replicas
+# (several processes on one device beside a 116-GB parent) out of memory.  MVIP_BWD_TILE_POINTS=1048576 buys the 1.5 % on a
+# device the job owns.
+BWD_TILE_POINTS = int(_os.environ.get('MVIP_BWD_TILE_POINTS', 262144))
 
 
 def _zero_grads(device):
