@@ -305,20 +305,45 @@ def add_scaling_prediction(result, world):
         src, line = 'this run', result
     else:
         src, line = None, None
-        for name in ('r5_bench_line.json', 'r4_bench_line.json'):
+        for name in ('r6_bench_line.json', 'r5_bench_line.json', 'r4_bench_line.json'):
             path = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(path):
                 src, line = f'profiles/{name}', json.load(open(path))
                 break
         if line is None:
             return
-    measured = {'frame_ms': get(line, 'ms_per_step'), 'train_ms': get(line, 'train', 'ms_per_step'),
-                'sds_ms': get(line, 'sds', 'ms_per_step'), 'config2_ms': get(line, 'config2_rgb_normal_sds', 'ms_per_step'),
-                'config3_ms': get(line, 'config3_rgb_normal_colla_sds', 'ms_per_step')}
+    # The SDS step enters the model in the MODE the multi-rank legs run it in: next to a live process group the step is
+    # launched eagerly unless MVIP_GRAPHS_WITH_DIST=1 (extra_legs: graphs_ok), so the eager time is the model's input
+    # there, the hipGraph replay only when the multi-rank run will replay too.
+    graphs_with_dist = os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') == '1'
+    sds_key = 'ms_per_step' if graphs_with_dist else 'ms_per_step_eager'
+    sds_ms = get(line, 'sds', sds_key) or get(line, 'sds', 'ms_per_step')
+
+    def cfg_ms(name, mode):
+        v = get(line, name, mode, 'ms_per_step')
+        if v is None and mode == 'f16x3' and get(line, name, 'f32') is None:
+            v = get(line, name, 'ms_per_step')           # lines of rounds <= 5 printed only the split-precision leg
+        return v
+    measured = {'frame_ms': get(line, 'ms_per_step'), 'train_ms': get(line, 'train', 'ms_per_step'), 'sds_ms': sds_ms,
+                'config2_ms': cfg_ms('config2_rgb_normal_sds', 'f32'), 'config3_ms': cfg_ms('config3_rgb_normal_colla_sds', 'f32')}
+    measured_split = {'frame_ms': get(line, 'render_f16x3', 'ms_per_step'), 'train_ms': get(line, 'train_f16x3', 'ms_per_step'),
+                      'sds_ms': sds_ms, 'config2_ms': cfg_ms('config2_rgb_normal_sds', 'f16x3'),
+                      'config3_ms': cfg_ms('config3_rgb_normal_colla_sds', 'f16x3')}
     if measured['frame_ms'] is None:
         return
-    pred = predict(measured, ns=(2, 4, 8) if world == 1 else (world,))
+    ns = (2, 4, 8) if world == 1 else (world,)
+    # on one GPU the NeRF part of a measured iteration = iteration - its terms AS THAT RUN EXECUTED THEM (graph replays)
+    sds_one_gpu = get(line, 'sds', 'ms_per_step')
+    pred = predict(measured, ns=ns, sds_one_gpu_ms=sds_one_gpu)
+    pred['dtype'] = 'f32 NeRF kernels (the default path)'
+    pred['sds_mode'] = ('hipGraph replay (MVIP_GRAPHS_WITH_DIST=1)' if graphs_with_dist else
+                        'eager launches (what bench.py runs next to a live multi-rank process group)')
     pred['one_gpu_legs_from'] = src
+    if measured_split['frame_ms'] is not None:
+        ps = predict(measured_split, ns=ns, sds_one_gpu_ms=sds_one_gpu)
+        ps['dtype'] = 'f16x3 NeRF kernels (opt-in split precision)'
+        ps['sds_mode'] = pred['sds_mode']
+        mg['predicted_f16x3'] = ps
     if world > 1:
         row = pred['N'].get(world, {})
         got = {'ms_per_step': result.get('ms_per_step'), 'value': result.get('value'), 'strong_efficiency': result.get('strong_efficiency'),
@@ -326,6 +351,13 @@ def add_scaling_prediction(result, world):
                'config2_ms': mg.get('config2_ms'), 'config3_ms': mg.get('config3_ms')}
         pred['measured'] = got
         pred['measured_over_predicted'] = {k: round(got[k] / row[k], 3) for k in row if got.get(k) and row.get(k)}
+        if 'predicted_f16x3' in mg:
+            rs = mg['predicted_f16x3']['N'].get(world, {})
+            gs = {'ms_per_step': get(result, 'render_f16x3', 'ms_per_step'), 'train_ms': mg.get('train_f16x3_ms'),
+                  'train_with_sds_ms': mg.get('train_with_sds_f16x3_ms'), 'config2_ms': mg.get('config2_f16x3_ms'),
+                  'config3_ms': mg.get('config3_f16x3_ms')}
+            mg['predicted_f16x3']['measured'] = gs
+            mg['predicted_f16x3']['measured_over_predicted'] = {k: round(gs[k] / rs[k], 3) for k in rs if gs.get(k) and rs.get(k)}
     mg['predicted'] = pred
 
 
@@ -641,10 +673,12 @@ def main():
                 t = torch.tensor([dt_tr16], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_tr16 = float(t.item())
+            mg['train_f16x3_ms'] = dt_tr16 / args.train_steps * 1e3
             result['train_f16x3'] = {'rays_per_sec': n_rays * world / dt_tr16, 'ms_per_step': dt_tr16 / args.train_steps * 1e3,
+                                     'dtype': 'f16x3 (fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate)',
                                      'what': 'the same iteration with train_precision=1 (split-precision MFMA kernels)'}
             mg['train_ms'] = dt_tr / args.train_steps * 1e3
-            result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3,
+            result['train'] = {'rays_per_sec': n_rays * world / dt_tr, 'ms_per_step': dt_tr / args.train_steps * 1e3, 'dtype': 'f32',
                                'steps': args.train_steps, 'rays_per_step': n_rays * world // args.train_steps,
                                'what': 'second-stage iteration without the diffusion prior: masked-set render '
                                        '(11,544 rays) + 1024 colour rays + 1024 depth rays, losses, backward through '
@@ -729,7 +763,11 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
             # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
-            # collaborative SDS over <=5 neighbour views); NeRF kernels in split precision (train_ and inference_precision = 1)
+            # collaborative SDS over <=5 neighbour views), EACH IN BOTH ARITHMETICS of the NeRF kernels: "f32" = the package
+            # default (train_precision = inference_precision = 0, exact fp32 MFMA; what every config-level test runs and
+            # what the reference computes in) and "f16x3" = the opt-in split-precision mode (fp16 MFMA on hi + lo halves,
+            # three products, fp32 accumulate; config-level parity: tests/test_configs.py::test_split_precision_*).
+            # The top-level ms_per_step of each leg is the f32 one.
             for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
                 a2 = make_args()
                 a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
@@ -737,27 +775,38 @@ def main():
                 opt.text_normal = 'a normal map of a stone bench in a park'
                 tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
                                          rank=rank, dist=dist)
-                for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
-                    n.train_precision = n.inference_precision = 1       # split precision for every NeRF kernel of the step
-                tr2.step(999)
-                tr2.step(1000)
-                barrier()
-                t5 = time.perf_counter()
-                rays = 0
-                for k in range(nsteps):
-                    rays += tr2.step(1001 + k)[1]
-                barrier()
-                dt5 = time.perf_counter() - t5
-                if dist is not None:
-                    t = torch.tensor([dt5], device=device, dtype=torch.float64)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    dt5 = float(t.item())
-                mg['config3_ms' if colla else 'config2_ms'] = dt5 / nsteps * 1e3
-                result[name] = {'ms_per_step': dt5 / nsteps * 1e3, 'rays_with_grad_per_step_per_gpu': rays // nsteps,
+                legs = {}
+                for mode, prec in (('f32', 0), ('f16x3', 1)):
+                    for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
+                        n.train_precision = n.inference_precision = prec
+                    tr2.step(999)
+                    tr2.step(1000)
+                    barrier()
+                    t5 = time.perf_counter()
+                    rays = 0
+                    for k in range(nsteps):
+                        rays += tr2.step(1001 + k)[1]
+                    barrier()
+                    dt5 = time.perf_counter() - t5
+                    if dist is not None:
+                        t = torch.tensor([dt5], device=device, dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        dt5 = float(t.item())
+                    legs[mode] = {'ms_per_step': dt5 / nsteps * 1e3, 'steps': nsteps,
+                                  'dtype': ('f32 (exact fp32 MFMA NeRF kernels: the package default)' if prec == 0 else
+                                            'f16x3 (NeRF kernels on fp16 MFMA, both operands split hi+lo, 3 products, fp32 accumulate; '
+                                            'opt-in train_precision = inference_precision = 1)'),
+                                  'sds_dtype': 'f32 tensors, contractions in split precision (see sds.dtype)'}
+                    mg[('config3' if colla else 'config2') + ('_ms' if prec == 0 else '_f16x3_ms')] = dt5 / nsteps * 1e3
+                result[name] = {'ms_per_step': legs['f32']['ms_per_step'], 'dtype': legs['f32']['dtype'],
+                                'f32': legs['f32'], 'f16x3': legs['f16x3'],
+                                'rays_with_grad_per_step_per_gpu': rays // nsteps,
                                 'sds_evaluations_per_step': 2 + (5 if colla else 0)}
                 del tr2
             opt.is_normal_guidance = opt.is_colla_guidance = False
+            mg['train_with_sds_f16x3_ms'] = dt_full16 / args.sds_steps * 1e3
             result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,
+                                              'dtype': 'f16x3 NeRF kernels (3 fp16 products, fp32 accumulate); SDS as in sds.dtype',
                                               'iterations_per_sec': args.sds_steps / dt_full16,
                                               'what': 'the same iteration with train_precision=1 for the NeRF kernels'}
             from mvip_nerf_amd.guidance.flops import sds_step_flops
@@ -765,7 +814,7 @@ def main():
             sds_ms = dt_sds / args.sds_steps * 1e3
             ach = fl['per_step'] / (sds_ms * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            for name in ('r5_pmc_sds_traffic.json', 'r4_pmc_sds_traffic.json', 'r3_pmc_sds_traffic.json'):      # newest first
+            for name in ('r6_pmc_sds_traffic.json', 'r5_pmc_sds_traffic.json', 'r4_pmc_sds_traffic.json', 'r3_pmc_sds_traffic.json'):      # newest first
                 pmc_sds = os.path.join(ROOT, 'profiles', name)
                 if os.path.exists(pmc_sds):
                     traffic = json.load(open(pmc_sds)).get('hbm_bytes_per_step')
@@ -828,7 +877,7 @@ def main():
                           'iteration without the prior, train_with_sds_ms = configs[1] iteration, config2_ms / config3_ms = '
                           'configs[2] / configs[3] iterations at the metric resolution; allreduce_ms = the 4.77 MB gradient '
                           'bucket alone.  The headline `value` at N > 1 is strong scaling too (one frame over all ranks)')
-            result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3,
+            result['train_with_sds'] = {'ms_per_step': dt_full / args.sds_steps * 1e3, 'dtype': 'f32 NeRF kernels; SDS as in sds.dtype',
                                         'iterations_per_sec': args.sds_steps / dt_full,
                                         'what': 'full BASELINE configs[1] second-stage iteration: masked render + RGB SDS '
                                                 '+ colour/depth batches, backward, all-reduce, Adam (rays sharded over ranks)'}

@@ -160,12 +160,30 @@ class OverlappedGradBuckets(FlatGradBucket):
         self._seen = [False] * len(self.params)
         self._launched = 0                                   # groups 0 .. _launched-1 are on the wire (or done)
         self._handles = []
+        self._blocking = False
         self.launched_in_backward = 0                        # diagnostics (tests, bench): groups whose reduce overlapped
 
     def begin(self, dist, world):
         """Call before loss.backward(); with world == 1 nothing is hooked up."""
+        self.abort()                                         # a backward that raised after a launch left handles behind: wait, never drop
         self._reset()
         self.dist, self._armed = dist, world > 1
+        # device tensors over a transport other than RCCL (the several-ranks-on-one-GPU debug mode over gloo, where an
+        # asynchronous device-tensor collective faulted -- see sds_shard.evaluate) are reduced in place, blocking; asked once
+        # per backward, not inside every hook
+        self._blocking = bool(self._armed and self.flat.is_cuda and str(dist.get_backend()).lower() != 'nccl')
+
+    def abort(self):
+        """Error path (the trainer's try / finally around loss.backward()): issue every collective the peers will issue -- they
+        block in finish() otherwise -- wait for all of them and disarm.  The gradients of this iteration are not handed back."""
+        if getattr(self, '_armed', False):
+            self._armed = False
+            while self._launched < len(self.group_sizes):
+                self._launch(self._launched)
+        for h in getattr(self, '_handles', []):
+            if h is not None:
+                h.wait()
+        self._handles = []
 
     def _launch(self, g, asynchronous=True):
         lo, hi = self.bounds[g]
@@ -176,9 +194,7 @@ class OverlappedGradBuckets(FlatGradBucket):
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
-        # device tensors over a transport other than RCCL (the several-ranks-on-one-GPU debug mode over gloo, where an
-        # asynchronous device-tensor collective faulted -- see sds_shard.evaluate) are reduced in place, blocking
-        if self.flat.is_cuda and str(self.dist.get_backend()).lower() != 'nccl':
+        if self._blocking:
             torch.cuda.synchronize(self.flat.device)
             asynchronous = False
         self._handles.append(self.dist.all_reduce(self.flat[lo:hi], async_op=True) if asynchronous

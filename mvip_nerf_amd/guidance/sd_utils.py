@@ -202,13 +202,25 @@ class _GraphedStep:
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self.d_pred = self._body()
         finally:
+            # also on a failed warm-up / capture (out of memory, capture error): later eager kernels and later captures must not
+            # keep pointing at this graph's scratch words, and the warm-up's draws must not stay consumed
             sd._noise_feed = None
+            _ops.ZERO_SCOPE = scope_before
+            gen.set_state(gen_state)
+        self._scope = ('graph', id(self))
         # everything the capture read from per-prompt caches (the cross-attention's key / value planes, filled by the
         # warm-up above) lives as long as this graph, whatever another prompt does to those caches afterwards
         from . import transformer_cm
         self.pinned = transformer_cm.prompt_entries(sd.unet) if isinstance(sd.unet, nn.Module) else []
-        _ops.ZERO_SCOPE = scope_before
-        gen.set_state(gen_state)
+        self._done = None                                       # event after the last replay's output clones (see run)
+
+    def __del__(self):
+        try:                                                    # this graph's scratch words go with it
+            from .. import ops as _ops
+            for k in [k for k in _ops._ZERO_WORDS if k[2] == getattr(self, '_scope', None)]:
+                del _ops._ZERO_WORDS[k]
+        except Exception:                                       # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _body(self):
         sd = self.sd
@@ -240,6 +252,12 @@ class _GraphedStep:
         """Replays the step for this image / mask / timestep.  'single': d step / d pred.  'share': the updated running latent
         gradient.  'last': (d step / d pred, updated running latent gradient)."""
         abar = self.sd._alphas_host[t]
+        # One graph = one set of static input / output buffers: a run on ANOTHER stream (cal_loss replays the terms on streams
+        # of their own) must not rewrite them while the previous replay or its output clones are still in flight (ADVICE r5).
+        # _graph_for keys graphs by stream, so this wait is a no-op in the shipped callers; it keeps any other caller correct.
+        cur = torch.cuda.current_stream(self.pred.device)
+        if self._done is not None:
+            cur.wait_event(self._done)
         # scalars travel as kernel arguments of four fill launches: an asynchronous copy from a temporary host
         # tensor can execute after that tensor's memory has been reused (seen as sporadic garbage timesteps)
         for k, v in enumerate((abar ** 0.5, (1.0 - abar) ** 0.5, 1.0 - abar, float(t))):
@@ -251,10 +269,14 @@ class _GraphedStep:
         self.noise.refill(self.sd.generator)                    # this step's draws, eagerly, in the order an eager step makes them
         self.graph.replay()
         if self.mode == 'single':
-            return self.d_pred.clone()
-        if self.mode == 'share':
-            return self.acc.clone()
-        return self.d_pred.clone(), self.acc.clone()
+            out = self.d_pred.clone()
+        elif self.mode == 'share':
+            out = self.acc.clone()
+        else:
+            out = (self.d_pred.clone(), self.acc.clone())
+        self._done = torch.cuda.Event()
+        self._done.record(cur)
+        return out
 
 
 def seed_everything(seed):
@@ -417,7 +439,11 @@ class StableDiffusion(nn.Module):
         return latents, grad
 
     def _graph_for(self, mode, mask, prompt, pred, guidance_scale):
-        key = (mode, tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale), id(self.generator))
+        # ... and by the stream it will replay on: the RGB and the normal term use the same mode, and with the reference's defaults
+        # (--text == --text_normal, both scales 7.5, normalmap_render_factor 1) the same shapes, prompt and scale -- replayed
+        # side by side on two streams (nerf/utils.cal_loss) they must not resolve to ONE graph's static buffers
+        stream = torch.cuda.current_stream(pred.device).cuda_stream if pred.is_cuda else 0
+        key = (mode, tuple(pred.shape), tuple(mask.shape), prompt, float(guidance_scale), id(self.generator), stream)
         if key not in self._graphs:
             self._graphs[key] = _GraphedStep(self, pred.shape, mask.shape, prompt, guidance_scale, mode)
         return self._graphs[key]

@@ -82,10 +82,14 @@ def config_terms(config):
     raise ValueError(config)
 
 
-def predict(measured, ns=(2, 4, 8), H=378, W=504, constants=None, fwd_share=None):
+def predict(measured, ns=(2, 4, 8), H=378, W=504, constants=None, fwd_share=None, sds_one_gpu_ms=None):
     """measured: {'frame_ms', 'train_ms', 'sds_ms', 'config2_ms', 'config3_ms'} from ONE GPU (any may be None: its legs are
     skipped).  Returns {'inputs', 'constants', 'N': {n: {...}}} with value (rays/s), strong_efficiency, train_ms,
-    train_with_sds_ms, config2_ms, config3_ms and each leg's scaling ceiling (N -> infinity)."""
+    train_with_sds_ms, config2_ms, config3_ms and each leg's scaling ceiling (N -> infinity).
+
+    `sds_ms` is the step AS THE MULTI-RANK RUN EXECUTES IT (eager launches next to a live process group unless
+    MVIP_GRAPHS_WITH_DIST=1: bench.py's graphs_ok); `sds_one_gpu_ms` (default: the same) is the step as the ONE-GPU
+    config legs executed it (hipGraph replay) -- it is what gets subtracted from those legs to isolate their NeRF part."""
     c = dict(DEFAULTS)
     c.update(constants or {})
     if fwd_share is None:
@@ -103,6 +107,9 @@ def predict(measured, ns=(2, 4, 8), H=378, W=504, constants=None, fwd_share=None
                    'SDS-term ownership replayed); written before any multi-GPU run existed -- SCALE runs test it'}
     t_full = m['sds_ms']
     t_fwd = None if t_full is None else t_full * fwd_share
+    t_full_1 = t_full if sds_one_gpu_ms is None else float(sds_one_gpu_ms)
+    t_fwd_1 = None if t_full_1 is None else t_full_1 * fwd_share
+    out['inputs']['sds_one_gpu_ms'] = t_full_1
     # the NeRF part of an iteration with the prior = the measured iteration minus its terms (one GPU runs them back to back)
     nerf = {}
     if m['train_ms'] is not None:
@@ -110,7 +117,7 @@ def predict(measured, ns=(2, 4, 8), H=378, W=504, constants=None, fwd_share=None
     for cfg, key in ((2, 'config2_ms'), (3, 'config3_ms')):
         if m[key] is not None and t_full is not None:
             terms = config_terms(cfg)
-            nerf[cfg] = m[key] - sum(t_full if p == 2 else t_fwd for p, _ in terms)
+            nerf[cfg] = m[key] - sum(t_full_1 if p == 2 else t_fwd_1 for p, _ in terms)
     img_bytes = {1: 3 * H * W * 4, 2: 3 * H * W * 4, 3: 3 * H * W * 4}
     for n in ns:
         row = {}
@@ -137,7 +144,7 @@ def predict(measured, ns=(2, 4, 8), H=378, W=504, constants=None, fwd_share=None
         for cfg, key in ((1, 'train_with_sds_ms'), (2, 'config2_ms'), (3, 'config3_ms')):
             if cfg in nerf:
                 t_inf = c['c_iter_ms'] + sds_critical_path_ms(config_terms(cfg), 64, t_full, t_fwd, 0, c)
-                t_one = nerf[cfg] + sum(t_full if p == 2 else t_fwd for p, _ in config_terms(cfg))
+                t_one = nerf[cfg] + sum(t_full_1 if p == 2 else t_fwd_1 for p, _ in config_terms(cfg))
                 ceil[key] = {'ms_at_infinite_ranks': round(t_inf, 2), 'max_speedup': round(t_one / t_inf, 2)}
     out['scaling_ceiling'] = ceil
     return out

@@ -288,7 +288,14 @@ class SecondStageTrainer:
             loss = loss + args.sds_loss_weight * img2mse(rgb_masked, sc.images[img_i].reshape(-1, 3)[sel]) * wm
         if isinstance(self.bucket, OverlappedGradBuckets):
             self.bucket.begin(self.dist, self.world)       # the coarse half is reduced while the masked render's backward runs
-        loss.backward()
+        try:
+            loss.backward()
+        except BaseException:
+            # peers that did not fail are (or will be) waiting in finish(): issue this rank's share of the collectives
+            # so the error surfaces as an error here instead of a hang there
+            if isinstance(self.bucket, OverlappedGradBuckets):
+                self.bucket.abort()
+            raise
         self._allreduce_grads()
         self.optimizer.step()
 

@@ -66,29 +66,17 @@ def load(tr, sc, sf):
         net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed).items()})
 
 
-def test_config1_iteration_at_567x1008(cuda, full_sd, scene_f4):
-    """configs[1]: one second-stage iteration with the real prior at the real frame size, then the renderer's
-    properties at that size and its autograd against the oracle on a strided ray subset, driven by the image-space
-    gradient the diffusion prior actually produced."""
-    from mvip_nerf_amd import run, ops
+def _config1_gradient_vs_oracle(cuda, full_sd, sc, precision):
+    """The config-level autograd check of configs[1] (DS_NeRF/run.py:948-974, :1000-1031): masked-set render driven by the image-space
+    gradient the real prior produced + colour / depth supervision batches, backward through both MLPs, every parameter
+    gradient against the CPU oracle's autograd on the same rays -- with the NeRF kernels in `precision`
+    (0 = exact fp32 MFMA, the default; 1 = split-precision fp16 MFMA, train_precision = inference_precision = 1)."""
     from mvip_nerf_amd.trainer import SecondStageTrainer
-    sc = scene_f4
-    assert (sc.H, sc.W) == (567, 1008) and abs(sc.focal - 3069.17 / 4) < 1.0 and 1.0 < sc.near < 2.0 < sc.far
-    frac = float(sc.masks.float().mean())
-    assert 0.04 < frac < 0.08                                   # scene 1's masks cover ~6 % of the frame
-    tr = SecondStageTrainer(cfg_args(), sc, cuda, guidance=guidance(cuda, full_sd))
-    load(tr, 71, 72)
-    torch.manual_seed(0)
-    loss, n_rays = tr.step(1000, img_i=2)
-    assert torch.isfinite(loss) and n_rays == sc.masked_idx_of(2).numel() + 2 * 1024
-    assert 25000 < sc.masked_idx_of(2).numel() < 45000
-    grads = [p.grad for p in tr.grad_vars]
-    assert len(grads) == 48 and all(g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in grads)
-    del loss
-
     # -- the image-space gradient of the real prior w.r.t. the assembled frame, as the upstream of an autograd check
     tr2 = SecondStageTrainer(cfg_args(perturb=0., raw_noise_std=0.), sc, cuda, guidance=None)
     load(tr2, 71, 72)
+    for net in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
+        net.train_precision = net.inference_precision = precision
     pose, midx = sc.poses[2], sc.masked_idx_of(2)
     with torch.no_grad():
         rgb_m = tr2._render_pixels(pose, midx, retraw=True, **tr2.kw_test)['rgb_map']
@@ -140,7 +128,31 @@ def test_config1_iteration_at_567x1008(cuda, full_sd, scene_f4):
             worst.append((rel, k))
             assert rel <= 4e-2, (k, rel)
             assert np.abs(got - want).max() <= 8e-2 * np.abs(want).max() + 1e-12, k
-    print('config1 gradient check: worst relative L2 per tensor', sorted(worst)[-3:], 'median', float(np.median([w[0] for w in worst])))
+    print(f'config1 gradient check (precision {precision}): worst relative L2 per tensor', sorted(worst)[-3:], 'median', float(np.median([w[0] for w in worst])))
+    return tr2, pose, pc, pf, ro, rd
+
+
+def test_config1_iteration_at_567x1008(cuda, full_sd, scene_f4):
+    """configs[1]: one second-stage iteration with the real prior at the real frame size, then the renderer's
+    properties at that size and its autograd against the oracle on a strided ray subset, driven by the image-space
+    gradient the diffusion prior actually produced."""
+    from mvip_nerf_amd import run, ops
+    from mvip_nerf_amd.trainer import SecondStageTrainer
+    sc = scene_f4
+    assert (sc.H, sc.W) == (567, 1008) and abs(sc.focal - 3069.17 / 4) < 1.0 and 1.0 < sc.near < 2.0 < sc.far
+    frac = float(sc.masks.float().mean())
+    assert 0.04 < frac < 0.08                                   # scene 1's masks cover ~6 % of the frame
+    tr = SecondStageTrainer(cfg_args(), sc, cuda, guidance=guidance(cuda, full_sd))
+    load(tr, 71, 72)
+    torch.manual_seed(0)
+    loss, n_rays = tr.step(1000, img_i=2)
+    assert torch.isfinite(loss) and n_rays == sc.masked_idx_of(2).numel() + 2 * 1024
+    assert 25000 < sc.masked_idx_of(2).numel() < 45000
+    grads = [p.grad for p in tr.grad_vars]
+    assert len(grads) == 48 and all(g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in grads)
+    del loss
+
+    tr2, pose, pc, pf, ro, rd = _config1_gradient_vs_oracle(cuda, full_sd, sc, precision=0)
 
     # -- properties at 567 x 1008: chunk invariance bit-exact, strided sample == oracle
     with torch.no_grad():
@@ -154,6 +166,25 @@ def test_config1_iteration_at_567x1008(cuda, full_sd, scene_f4):
         ref = O.render_rays(rows, {k: v.detach() for k, v in pc.items()}, {k: v.detach() for k, v in pf.items()}, 64, 64,
                             lindisp=True, white_bkgd=True)
     np.testing.assert_allclose(N(a[0].reshape(-1, 3))[sel.numpy()], N(ref['rgb_map']), rtol=1e-4, atol=1e-5)
+
+
+def test_split_precision_config1_gradients_vs_oracle(cuda, full_sd, scene_f4):
+    """VERDICT r5 task 1b: the SAME config-level gradient check with train_precision = inference_precision = 1 (what bench.py's
+    *_f16x3 legs run): per-tensor relative L2 <= 4 %, no entry off by more than 8 % of the tensor's largest gradient -- the
+    bounds of the fp32 test (the mode's own error, ~3e-7 relative per layer output, is far inside the ReLU-gate noise those
+    bounds exist for) -- and one whole iteration with the real prior in that mode gives finite, non-zero gradients."""
+    from mvip_nerf_amd.trainer import SecondStageTrainer
+    sc = scene_f4
+    _config1_gradient_vs_oracle(cuda, full_sd, sc, precision=1)
+    tr = SecondStageTrainer(cfg_args(), sc, cuda, guidance=guidance(cuda, full_sd))
+    load(tr, 71, 72)
+    for net in (tr.kw_train['network_fn'], tr.kw_train['network_fine']):
+        net.train_precision = net.inference_precision = 1
+    torch.manual_seed(0)
+    loss, n_rays = tr.step(1000, img_i=2)
+    g1 = [p.grad.clone() for p in tr.grad_vars]
+    assert torch.isfinite(loss) and all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in g1)
+    assert n_rays == sc.masked_idx_of(2).numel() + 2 * 1024
 
 
 def test_config2_iteration_normal_sds_factor2(cuda, full_sd, scene_f4):
@@ -216,7 +247,8 @@ def test_config0_coarse_only_render_vs_oracle(cuda):
     assert all(p.grad is not None for p in grad_vars)
 
 
-def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path):
+@pytest.mark.parametrize('precision', [0, 1], ids=['f32', 'f16x3'])
+def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path, precision):
     """The north star's PSNR clause as a test: train on REAL data (SPIn-NeRF scene 1 at 1/16 resolution), render a
     held-out view through render_path (with the reference's on-disk layout), and compare PSNR-vs-ground-truth of the
     HIP render with that of the CPU-oracle render of the SAME weights on a fixed pixel subset: |dPSNR| < 0.05 dB."""
@@ -233,6 +265,9 @@ def test_heldout_psnr_hip_vs_oracle_within_0p05_dB(cuda, tmp_path):
     args = cfg_args(lrate=5e-4, white_bkgd=False, lindisp=False)
     torch.manual_seed(0)
     tr, te, _, grad_vars, opt = run.create_nerf(args, device=cuda)
+    for net in (tr['network_fn'], tr['network_fine']):          # precision 1: training AND the held-out render in split precision
+        net.train_precision = net.inference_precision = precision
+    assert te['network_fn'] is tr['network_fn'] and te['network_fine'] is tr['network_fine']
     kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
     g = torch.Generator(device=cuda).manual_seed(0)
     for it in range(1500):
@@ -273,7 +308,8 @@ FIXTURE_F8 = os.path.join(os.path.dirname(__file__), 'golden', 'scene1_f8.npz')
 
 
 @pytest.mark.slow
-def test_heldout_psnr_at_factor8_hip_vs_oracle_within_0p05_dB(cuda):
+@pytest.mark.parametrize('precision', [0, 1], ids=['f32', 'f16x3'])
+def test_heldout_psnr_at_factor8_hip_vs_oracle_within_0p05_dB(cuda, precision):
     """The PSNR clause at a BASELINE size (VERDICT r3 task 9): factor 8 = 283 x 504, configs[0]'s geometry, REAL pixels of
     SPIn-NeRF scene 1 (tests/golden/scene1_f8.npz: the factor-4 rasters of the reference's own loader box-filtered 2x, 15
     training views + view 30 held out; oracle/gen_golden_llff.py).  6,000 photometric iterations of 4,096 rays (3,000 reach
@@ -297,6 +333,9 @@ def test_heldout_psnr_at_factor8_hip_vs_oracle_within_0p05_dB(cuda):
     args = cfg_args(lrate=5e-4, white_bkgd=False, lindisp=False)
     torch.manual_seed(0)
     tr, te, _, grad_vars, opt = run.create_nerf(args, device=cuda)
+    for net in (tr['network_fn'], tr['network_fine']):          # precision 1: training AND the held-out render in split precision
+        net.train_precision = net.inference_precision = precision
+    assert te['network_fn'] is tr['network_fn'] and te['network_fine'] is tr['network_fine']
     kw_tr = {k: v for k, v in tr.items() if k not in ('ndc', 'use_viewdirs')}
     g = torch.Generator(device=cuda).manual_seed(0)
     for it in range(6000):

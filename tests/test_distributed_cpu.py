@@ -121,6 +121,40 @@ def _overlap_worker(rank, world, port, out):
             ob.finish()
             for pa, pb in zip(ps_a, ps_b):
                 assert torch.equal(pa.grad, pb.grad), (case, rank, 'second iteration')
+            # error path: rank 1's backward raises AFTER the coarse group went on the wire; abort() issues the
+            # remaining collectives so rank 0's finish() returns instead of hanging, no handle is dropped, and the next
+            # iteration through the same object is exact again
+            if case == 'even':
+                for pb in ps_b:
+                    pb.grad = None
+                ob.begin(dist, world)
+
+                class Boom(torch.autograd.Function):
+                    @staticmethod
+                    def forward(ctx, t):
+                        return t.clone()
+
+                    @staticmethod
+                    def backward(ctx, g):
+                        raise RuntimeError('boom')
+                a1, a2, b1, b2 = ps_b
+                first = torch.tanh(x @ a1.detach() + a2.detach()) @ (Boom.apply(b1) if rank == 1 else b1) + b2
+                late = torch.tanh(x @ a1 + a2) @ b1.detach()
+                failed = False
+                try:
+                    (first.pow(2).sum() + late.sum() * 0.5).backward()
+                    ob.finish()
+                except RuntimeError:
+                    failed = True
+                    ob.abort()
+                assert failed == (rank == 1) and not ob._handles and not ob._armed
+                for pb in ps_b:
+                    pb.grad = None
+                ob.begin(dist, world)
+                loss_of(ps_b).backward()
+                ob.finish()
+                for pa, pb in zip(ps_a, ps_b):
+                    assert torch.equal(pa.grad, pb.grad), (case, rank, 'after an aborted iteration')
         torch.save(res, os.path.join(out, f'ov{rank}.pt'))
     finally:
         dist.destroy_process_group()

@@ -252,6 +252,22 @@ def test_sample_pdf_merge_vs_oracle(cuda, Nc, Nf):
     np.testing.assert_array_equal(N(inds), inds_ref.numpy())
 
 
+@pytest.mark.parametrize('Nf', [17, 96, 100, 128])
+def test_z_std_contract_non_power_of_two(cuda, Nf):
+    """include/mvip_nerf.h's contract for z_std: fp64 sums, then v_rcp_f32 / v_sqrt_f32 (<= 1 ulp each) -- within
+    4e-7 relative of the fp64 population std of the kernel's OWN z_samples (torch.std(z_samples, -1, unbiased=False),
+    DS_NeRF/run.py:1836), also where 1 / Nf is not exact."""
+    from mvip_nerf_amd import ops
+    rs = np.random.RandomState(Nf)
+    B = 257
+    z = np.sort(rs.uniform(1.2, 7.7, size=(B, 64)), -1).astype(np.float32)
+    w = (rs.uniform(0, 1, size=(B, 64)) ** 3).astype(np.float32)
+    u = rs.uniform(0, 1, size=(B, Nf)).astype(np.float32)
+    zs, _, zstd, _, _ = ops.sample_pdf_merge(T(z, cuda), T(w, cuda), T(u, cuda))
+    want = N(zs).astype(np.float64).std(-1)
+    np.testing.assert_allclose(N(zstd).astype(np.float64), want, rtol=4e-7)
+
+
 def test_sample_pdf_merge_rank_paths(cuda):
     """The three routes of the merge give sort(cat[z, samples]) exactly: both lists sorted (deterministic u: rank merge
     only), samples unsorted (random u: 64-value sort + rank merge), coarse depths unsorted (full bitonic network)."""

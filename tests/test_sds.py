@@ -1161,3 +1161,68 @@ def test_concurrent_sds_terms_equal_sequential_terms(cuda):
             for a, b in zip(ga, gb):
                 assert float(b.abs().max()) > 0
                 assert float((a - b).norm() / b.norm()) < 1e-4           # graph replays differ by fp32 atomics order only
+
+
+def test_concurrent_terms_with_identical_prompt_scale_and_shape_do_not_share_a_graph(cuda):
+    """the reference's defaults give the RGB and the normal term the SAME prompt (--text == --text_normal),
+    the same guidance scale (7.5) and, with normalmap_render_factor = 1, the same shapes (DS_NeRF/nerf/utils.py:280-302); both use
+    mode 'single'.  Replayed on one stream each they must not resolve to one captured graph (one set of static input / output
+    buffers): the graph key carries the stream, and _GraphedStep.run waits for the previous run's clones.  Checked: one graph
+    per stream exists, the gradients equal the in-line evaluation's for three iterations, and ONE graph driven from two streams
+    back to back (the guard in run) equals the same two runs on one stream."""
+    import random
+    import types
+    from mvip_nerf_amd.guidance.sd_utils import StableDiffusion
+    from mvip_nerf_amd.nerf.utils import Pretrain_Model
+    torch.manual_seed(0)
+    sd = StableDiffusion(cuda, False, False, use_graphs=True)
+    opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=True, normal_start=0,
+                                text='a stone bench in a park', text_normal='a stone bench in a park',
+                                rgb_guidance_scale=7.5, colla_guidance_scale=7.5, normal_guidance_scale=7.5, lambda_guidance=1.0,
+                                uniform_sphere_rate=0.5)
+    pm = Pretrain_Model(opt, cuda, {'SD': sd})
+    gen = torch.Generator(device=cuda).manual_seed(11)
+    H, W = 96, 128
+    rgb0 = torch.rand(1, 3, H, W, device=cuda, generator=gen)
+    nrm0 = torch.rand(1, 3, H, W, device=cuda, generator=gen)
+    mask = torch.zeros(1, 1, H, W, device=cuda)
+    mask[:, :, 30:70, 40:100] = 1
+    real_streams = pm._term_streams
+    out = {}
+    for mode in ('streams', 'in_line', 'streams'):
+        pm._term_streams = real_streams if mode == 'streams' else (lambda sd_, n: None)
+        random.seed(3)
+        torch.cuda.manual_seed(321)
+        grads = []
+        for it in (5, 6, 7):
+            rgb, nrm = (t.clone().requires_grad_(True) for t in (rgb0, nrm0))
+            loss = pm.cal_loss(it, None, nrm, None, rgb, None, mask, None, 1)
+            (1e-4 * loss).sum().backward()
+            grads.append((rgb.grad.clone(), nrm.grad.clone()))
+        out.setdefault(mode, []).append(grads)
+    singles = [k for k in sd._graphs if k[0] == 'single']
+    assert len(singles) == 3 and len({k[-1] for k in singles}) == 3      # term stream 0, term stream 1, the in-line stream
+    ref = out['in_line'][0]
+    for run_ in out['streams']:
+        for ga, gb in zip(run_, ref):
+            for a, b in zip(ga, gb):
+                assert float(b.abs().max()) > 0
+                assert float((a - b).norm() / b.norm()) < 1e-4
+    # the two terms see different images: their gradients differ (a shared graph made them collide)
+    assert float((ref[0][0] - ref[0][1]).norm() / ref[0][0].norm()) > 1e-2
+    # the guard for callers that DO share a graph across streams: the same graph run from two streams back to back
+    g = sd._graphs[singles[0]]
+    s1, s2 = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    torch.cuda.synchronize()
+    torch.cuda.manual_seed(5)
+    with torch.cuda.stream(s1):
+        a1 = g.run(rgb0, mask, 500)
+    with torch.cuda.stream(s2):
+        a2 = g.run(nrm0, mask, 500)
+    torch.cuda.synchronize()
+    torch.cuda.manual_seed(5)
+    b1 = g.run(rgb0, mask, 500)
+    b2 = g.run(nrm0, mask, 500)
+    torch.cuda.synchronize()
+    assert float((a1 - b1).norm() / b1.norm()) < 1e-4 and float((a2 - b2).norm() / b2.norm()) < 1e-4
+    assert float((a1 - a2).norm() / a1.norm()) > 1e-2
