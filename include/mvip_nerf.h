@@ -214,9 +214,10 @@ int mvip_composite_backward(const float *raw, const float *z, const float *rows,
  * shared by all rays (det: torch.linspace(0,1,Nf)).  Outputs: z_samples [B,Nf], z_merged
  * [B,Nc+Nf] ascending, z_std [B] (population std of z_samples), inds int64 [B,Nf] nullable
  * (= #{cdf <= u}, searchsorted right=True), cdf [B,Nc-1] nullable.
- * z_std contract: sums in fp64; the final 1/Nf and square root are v_rcp_f32 / v_sqrt_f32 (<= 1 ulp each), so
- * z_std is within 2 ulp of torch.std(z_samples, -1, unbiased=False) -- not correctly rounded when Nf is not a
- * power of two (tests/test_hip_kernels.py::test_z_std_contract_non_power_of_two). */
+ * z_std contract: two-pass (mean, then squared deviations) fp32 wave-tree sums; 1/Nf and the square root are
+ * v_rcp_f32 / v_sqrt_f32 (<= 1 ulp each, 1/Nf exact for powers of two): within 3e-6 relative of
+ * torch.std(z_samples, -1, unbiased=False) evaluated in fp64, not correctly rounded
+ * (tests/test_hip_kernels.py::test_z_std_contract_non_power_of_two). */
 int mvip_sample_pdf_merge(const float *z, const float *weights, const float *u, int u_is_row,
                           int64_t B, int Nc, int Nf, float *z_samples, float *z_merged,
                           float *z_std, int64_t *inds, float *cdf, void *stream);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u, int u_is_row,
     int64_t B, int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
     float *__restrict__ z_std, int64_t *__restrict__ inds_out, float *__restrict__ cdf_out) {
-    __shared__ int rank_rows[4][80];                 // per wave: the 65-word row of rank_merge64's prefix-maximum count
+    __shared__ int rank_rows[4][RANK_LDS_WORDS];     // per wave: the count row of rank_merge64 + the rows of counting_merge64
     // the wave index through readfirstlane: the ray number and every row base derived from it are then SCALAR values (the
     // compiler cannot know that threadIdx.x >> 6 is wave-uniform; as a vector value each of the eight row accesses cost ~8
     // VALU instructions of 64-bit address arithmetic)

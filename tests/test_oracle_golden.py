@@ -187,3 +187,51 @@ def test_sds_wrapper_oracle(golden, name):
     assert float(loss) == 1.0
     (float(g['upstream']) * loss).sum().backward()
     np.testing.assert_allclose(pred.grad.numpy(), g['d_pred'], rtol=1e-4, atol=1e-6 * np.abs(g['d_pred']).max())
+
+
+@pytest.mark.parametrize('mode', ['det', 'pytest'])
+def test_oracle_follows_the_reference_trajectory(golden, mode):
+    """tests/golden/trajectory_100.npz (oracle/gen_golden_trajectory.py: 100 iterations of the reference's own
+    render + img2mse(rgb) + img2mse(rgb0) + Adam + lr decay, DS_NeRF/run.py:1000-1039, on real pixels): the oracle's
+    render_rays + torch.optim.Adam reproduce the first 8 losses of the reference's trajectory (2e-5 relative: same
+    torch-CPU arithmetic, a different grouping of a few sums), with the stochastic inputs of the 'pytest' trajectory drawn
+    as the reference's pytest=True hooks draw them (np.random.seed(0) + np.random.rand)."""
+    import os
+    g = golden('trajectory_100')
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scene1_small.npz'))
+    images = T(d['images'].astype(np.float32) / 255.)
+    poses = T(d['poses'][:, :, :4].astype(np.float32))
+    Nv, H, W, _ = images.shape
+    focal, near, far = float(g['focal']), float(g['near']), float(g['far'])
+    pc = {k: v.requires_grad_(True) for k, v in params(g['seed_coarse']).items()}
+    pf = {k: v.requires_grad_(True) for k, v in params(g['seed_fine']).items()}
+    opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=float(g['lrate']), betas=(0.9, 0.999))
+    rs = np.random.RandomState(int(g['seed_sel']))
+    i_train = [i for i in range(Nv) if i != int(g['held'])]
+    n_rays = int(g['n_rays'])
+    torch.set_num_threads(8)
+    for it in range(8):
+        v = i_train[int(rs.randint(0, len(i_train)))]
+        pix = T(rs.randint(0, H * W, size=n_rays).astype(np.int64))
+        assert v == int(g['sel_views'][it]) and int(pix.sum()) == int(g['sel_checksum'][it])
+        ro, rd = O.get_rays(H, W, focal, poses[v])
+        rows = O.assemble_ray_batch(ro.reshape(-1, 3)[pix], rd.reshape(-1, 3)[pix], near, far)
+        kw = {}
+        if mode == 'pytest':                                     # the hooks' draws, in the reference's order (run.py:1776, helpers :319, :378)
+            np.random.seed(0)
+            kw['t_rand'] = T(np.random.rand(n_rays, 64).astype(np.float32))
+            np.random.seed(0)
+            kw['noise0'] = T((np.random.rand(n_rays, 64) * 1.0).astype(np.float32))            # raw_noise_std = 1
+            np.random.seed(0)
+            kw['u'] = T(np.random.rand(n_rays, 64).astype(np.float32))
+            np.random.seed(0)
+            kw['noise1'] = T((np.random.rand(n_rays, 128) * 1.0).astype(np.float32))
+        r = O.render_rays(rows, pc, pf, 64, 64, lindisp=False, white_bkgd=False, **kw)
+        target = images[v].reshape(-1, 3)[pix]
+        loss = ((r['rgb_map'] - target) ** 2).mean() + ((r['rgb0'] - target) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for pg in opt.param_groups:
+            pg['lr'] = float(g['lrate']) * (0.1 ** (it / (int(g['lrate_decay']) * 1000)))
+        np.testing.assert_allclose(float(loss), float(g[f'{mode}/losses'][it]), rtol=2e-5, err_msg=f'iteration {it}')
