@@ -31,11 +31,13 @@ extern "C" {
 #define MVIP_ELAUNCH  -2   /* hipLaunch / runtime error (see mvip_last_hip_error) */
 #define MVIP_EUNSUP   -3   /* shape outside what the kernels are built for */
 
-#define MVIP_ABI_VERSION 4      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points;
+#define MVIP_ABI_VERSION 5      /* 2: `prec` on the SDS operand producers / contractions, operand-sink entry points;
                                    3: prec = 2 (two products for fp16-exact weights), mvip_packed_weights_two_product,
                                       mvip_build_is_experiment;
                                    4: mvip_mlp_*_f16x3_w16 (two-waves-per-SIMD split-precision forward) added,
-                                      mvip_mlp_forward_rays16_persistent removed */
+                                      mvip_mlp_forward_rays16_persistent removed;
+                                   5: LayerNorm statistics from the producing GEMM's epilogue (mvip_gemm_ln_segments,
+                                      mvip_gemm_f16x3_ws_ln, mvip_layernorm_split_planes_stats) */
 
 int         mvip_abi_version(void);
 int         mvip_build_is_experiment(void); /* 1: compiled with a -DMVIP_EXPERIMENT_* macro (timing build, WRONG results) */
@@ -450,6 +452,17 @@ int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, int64_t P);
 int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
                        float *y, void *workspace, int prec, void *stream);
+/* The same GEMM leaving, besides y, the LayerNorm statistics of y over its M rows (the unet(...) call,
+ * DS_NeRF/guidance/sd_utils.py:390-403: BasicTransformerBlock's norm1 / norm2 / norm3 read the residual stream a
+ * projection has just written): ln_part[((n * S + g) * 2 + {0, 1}) * P + p] = fp64 sum / sum of squares of the finished
+ * rows of segment g for column p, S = mvip_gemm_ln_segments(N, K, M, P, prec) segments of M / S rows each
+ * (N * S * 2 * P doubles).  mvip_gemm_ln_segments returns 0 for shapes whose launch cannot leave them (split-K
+ * launches, the square-tile kernel); mvip_gemm_f16x3_ws_ln then returns MVIP_EINVAL and the caller keeps
+ * mvip_layernorm_split_planes' own statistics pass. */
+int64_t mvip_gemm_ln_segments(int64_t N, int64_t K, int64_t M, int64_t P, int prec);
+int mvip_gemm_f16x3_ws_ln(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                          const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                          float *y, void *workspace, void *ln_part, int prec, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a14-a16  transformer blocks of the SD UNet (unet(...) at DS_NeRF/guidance/sd_utils.py:390-403 and :240;
@@ -541,6 +554,12 @@ int64_t mvip_layernorm_workspace_bytes(int64_t N, int64_t C, int64_t LP);
 int mvip_layernorm_split_planes(const float *x, const float *gamma, const float *beta, int64_t N, int64_t C,
                                 int64_t L, int64_t LP, float eps, float out_scale, void *workspace, void *xs,
                                 int prec, void *stream);
+/* The normalise + split half alone, from statistics `part` = [N][segments][2][LP] fp64 (sum, sum of squares) over
+ * `segments` disjoint channel ranges covering C -- what mvip_gemm_f16x3_ws_ln leaves: one launch, no pass over x for
+ * its moments.  C % 16 == 0. */
+int mvip_layernorm_split_planes_stats(const float *x, const float *gamma, const float *beta, const void *part,
+                                      int64_t segments, int64_t N, int64_t C, int64_t L, int64_t LP, float eps,
+                                      float out_scale, void *xs, int prec, void *stream);
 /* GEGLU: y [N][2R][LP] -> out [N][R][LP] = y[:, :R] * gelu(y[:, R:]) (erf form) for tokens < L, zero beyond;
  * scale2 = {2^k, 2^-k, -, -} from the result's absolute maximum; zero_word: one scratch word as in
  * mvip_absmax_scale_sections (zero on entry, zero on exit). */

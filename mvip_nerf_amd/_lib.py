@@ -113,6 +113,9 @@ _SIGNATURES = {
     'mvip_col2im': (_int, [_c_f, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _i64, _i64, _i64, _i64, _c_f, _c_f]),
     'mvip_gemm_workspace_bytes': (_i64, [_i64, _i64, _i64, _i64]),
     'mvip_gemm_f16x3_ws': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _int, _c_f]),
+    'mvip_gemm_ln_segments': (_i64, [_i64, _i64, _i64, _i64, _int]),
+    'mvip_gemm_f16x3_ws_ln': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f, _int, _c_f]),
+    'mvip_layernorm_split_planes_stats': (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _flt, _flt, _c_f, _int, _c_f]),
     'mvip_gemm_f16x3_cfg': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _c_f, _int, _int, _c_f]),
     'mvip_attention_supported': (_int, [_i64]),
     'mvip_attention_v_bytes': (_i64, [_i64, _i64, _i64, _i64]),
@@ -150,7 +153,7 @@ _SIGNATURES = {
 DECLARED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MvipError(RuntimeError):

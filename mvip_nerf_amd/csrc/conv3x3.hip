@@ -935,6 +935,11 @@ struct GemmArgs {
     struct Sec { char *ptr; float scale; int row_end, kind; } sec[3];
     int nsec, v_dt;              // v_dt: 32-row tiles per head in a kind-2 section
     int prec;                    // 1: single fp16 product (hi planes / hi fragments only; sinks write no lo halves)
+    // LayerNorm statistics of the OUTPUT (plain fp32 epilogue, unsplit launches only): the rows are the channels a later
+    // LayerNorm reduces over, so each workgroup leaves, per column (token), the fp64 sum and sum of squares of its 32 MT
+    // finished rows in the layout ln_stats_kernel (csrc/transformer.hip) writes for 64-channel segments:
+    // ln_part[((n * MB + mb) * 2 + {0, 1}) * P + p].  The statistics launch of the next LayerNorm disappears.
+    double *ln_part;
 #ifdef MVIP_EXPERIMENT_GEMM
     int dbg;                     // timing experiments: 1 = no epilogue stores, 2 = no MFMAs, 4 = no LDS reads either
 #endif
@@ -966,7 +971,9 @@ __device__ __forceinline__ void gemm_epilogue_vfrag(const GemmArgs &a, f32x16 (&
 }
 
 // epilogue shared by the 32/64-row GEMM kernels: acc[m][j] = 32 x 32 tile (row tile mb*MT + m, columns p0 + (2 wave + j)*32 ..)
-template <int MT>
+// LN: the instantiation can leave LayerNorm statistics (GemmArgs::ln_part; the B-in-registers kernel only -- in the
+// LDS-staged kernel the extra live registers spilled)
+template <int MT, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MT][2], int n, int mb, int64_t p0, int split,
                                               int wave, int lane) {
     const int l32 = lane & 31, kg = lane >> 5;
@@ -1118,7 +1125,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                 if (hc) v += cv[m][r];
                 if (hr) v += rv[m][j][r];
                 a.y[o] = v;
+                if constexpr (LN) acc[m][j][r] = v;             // kept for the statistics below
             }
+    if constexpr (LN) if (a.ln_part) {
+        // a lane holds 16 MT rows of each of its two columns; the other half-wave (kg) holds the other 16 MT rows of the
+        // same columns: in-register fp64 sums + one cross-half add, no LDS
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double sm = 0.0, q = 0.0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const double t = (double)acc[m][j][r]; sm += t; q += t * t; }
+            sm += __shfl_xor(sm, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (kg == 0) {
+                const int64_t p = p0 + (2 * wave + j) * 32 + l32;
+                double *dst = a.ln_part + (((int64_t)n * a.MB + mb) * 2) * a.P + p;
+                dst[0] = sm;
+                dst[a.P] = q;
+            }
+        }
+    }
 }
 
 template <int MT>
@@ -1361,7 +1389,7 @@ __global__ void __launch_bounds__(256, MT == 1 ? 3 : 2) gemm5_f16x3_kernel(const
     for (; base < nck; base += 12) cv_static_for<12>([&](auto t_) { step(base, t_, cic<1>{}); });
     if constexpr (SWAP) gemm_epilogue_vfrag<MT>(a, acc, n, mb, p0, wave, lane);
     else
-    gemm_epilogue<MT>(a, acc, n, mb, p0, split, wave, lane);
+    gemm_epilogue<MT, true>(a, acc, n, mb, p0, split, wave, lane);
 }
 
 // scale2 = {2^k, 2^-k} from the maximum collected in *bits, which is left zero (caller-owned scratch word)
@@ -1921,7 +1949,7 @@ extern "C" int64_t mvip_gemm_workspace_bytes(int64_t N, int64_t K, int64_t M, in
 
 static int gemm_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                        const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
-                       float *y, int cfg, void *workspace, int prec, void *stream) {
+                       float *y, int cfg, void *workspace, int prec, void *stream, double *ln_part = nullptr) {
     if (N < 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || prec < 0 || prec > 2)
         return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
@@ -1932,7 +1960,7 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     a.bias = bias; a.chan_add = chan_add; a.residual = residual; a.x_scale2 = x_scale2; a.y = y;
     a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M; a.P = P;
     a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 0; a.v_dt = 1; a.prec = prec;
-    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+    a.splits = 1; a.ln_part = nullptr; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = cfg >> 8; cfg &= 255;
 #endif
@@ -1945,6 +1973,7 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
     if (cfg < 0 || cfg > 5) return MVIP_EINVAL;
     if ((cfg == 2 || cfg == 3) && M % 128 != 0) return MVIP_EINVAL;
     if (cfg == 4 && M % 64 != 0) return MVIP_EINVAL;
+    if (ln_part && cfg != 1 && cfg != 5) return MVIP_EUNSUP;   // the 32/64-row kernels' epilogue only
     if (cfg == 2) {
         a.tiles = (int)(P / 256); a.MB = (int)(M / 128);
         hipLaunchKernelGGL((gemm2_f16x3_kernel<2, 4, 3>), dim3((unsigned)(N * a.tiles * a.MB)), dim3(512), 0, st, a);
@@ -1968,6 +1997,8 @@ static int gemm_launch(const void *xs, const void *packed, const float *bias, co
         // cfg 5 (and the automatic choice unless MVIP_GEMM_STREAM=0): the B-in-registers kernel
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
         const bool stream = cfg == 5 || (auto_cfg && stream_env);
+        if (ln_part && (a.splits > 1 || !stream || MT > 2)) return MVIP_EUNSUP;       // callers ask mvip_gemm_ln_segments first
+        a.ln_part = ln_part;
         if (prec == 1 && !(MT <= 2 && stream)) return MVIP_EUNSUP;             // (see above: no lo planes in fp16 mode)
         if (prec == 1) {
             if (MT == 2) hipLaunchKernelGGL((gemm5_f16x3_kernel<2, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -2018,6 +2049,31 @@ extern "C" int mvip_gemm_f16x3_ws(const void *xs, const void *packed, const floa
     return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, workspace, prec, stream);
 }
 
+// Segments (= workgroup row blocks of 32 or 64 rows) of the LayerNorm partial statistics mvip_gemm_f16x3_ws_ln leaves for
+// this shape, or 0 when the launch cannot leave them (split-K launches sum raw partial products in a second launch; the
+// square-tile kernel has an epilogue of its own): the caller then runs mvip_layernorm_split_planes' own statistics pass.
+extern "C" int64_t mvip_gemm_ln_segments(int64_t N, int64_t K, int64_t M, int64_t P, int prec) {
+    if (N <= 0 || M <= 0 || M % 32 != 0 || K <= 0 || K % 32 != 0 || P <= 0 || P % GM_PIX != 0 || P > GM_P_MAX || prec < 0 || prec > 2) return 0;
+    if ((prec ? 1 : gm_auto_cfg(N, M, P)) != 1) return 0;
+    const int64_t tiles = P / GM_PIX;
+    const int MT = gm_mt(M, N * tiles);
+    if (gm_splits(N * tiles * (M / (32 * MT)), K / 32) > 1) return 0;
+    static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
+    if (MT > 2 || !stream_env) return 0;               // the statistics live in the B-in-registers kernel's epilogue
+    return M / (32 * MT);
+}
+
+// mvip_gemm_f16x3_ws that ALSO leaves the LayerNorm statistics of its output over the M rows (DS_NeRF/guidance/sd_utils.py:390-403:
+// the unet(...) call -- BasicTransformerBlock's norm1 / norm2 / norm3 read the residual stream a projection just wrote): per
+// column p and segment g (mvip_gemm_ln_segments of them) the fp64 sum and sum of squares of the finished rows of the
+// segment, ln_part[((n * S + g) * 2 + {0, 1}) * P + p] -- what mvip_layernorm_split_planes_stats consumes.  N * S * 2 * P doubles.
+extern "C" int mvip_gemm_f16x3_ws_ln(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                     const float *residual, const float *x_scale2, int64_t N, int64_t K, int64_t M, int64_t P,
+                                     float *y, void *workspace, void *ln_part, int prec, void *stream) {
+    if (!ln_part || mvip_gemm_ln_segments(N, K, M, P, prec) == 0) return MVIP_EINVAL;
+    return gemm_launch(xs, packed, bias, chan_add, residual, x_scale2, N, K, M, P, y, 0, workspace, prec, stream, (double *)ln_part);
+}
+
 // First projection of the transformer feed-forward with the GEGLU fused into the epilogue:
 //   out[n][r][p] = (W_v x + b_v)[r] * gelu((W_g x + b_g)[r])   for p < L, zero beyond,
 // `packed` / `bias` hold the 2R rows interleaved in 32-row tiles (value rows 32 t .. 32 t + 31, then the gate rows of
@@ -2037,7 +2093,7 @@ extern "C" int mvip_gemm_geglu_f16x3(const void *xs, const void *packed, const f
         a.bias = bias; a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = out;
         a.N = (int)N; a.CK = (int)(K / 16); a.M = (int)M2; a.P = P; a.tiles = (int)(P / GM_PIX); a.MB = (int)(M2 / 64);
         a.geglu_L = (int)L; a.absmax_bits = (unsigned *)zero_word; a.nsec = 0; a.v_dt = 1; a.prec = prec;
-        a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+        a.splits = 1; a.ln_part = nullptr; a.sks = (int)(K / 32); a.partial = nullptr;
         const int64_t blocks = N * a.tiles * a.MB;
         if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
         static const bool stream_env = [] { const char *e = getenv("MVIP_GEMM_STREAM"); return e ? atoi(e) != 0 : true; }();
@@ -2084,7 +2140,7 @@ extern "C" int mvip_gemm_f16x3_sinks(const void *xs, const void *packed, const f
     a.chan_add = nullptr; a.residual = nullptr; a.x_scale2 = x_scale2; a.y = nullptr;
     a.N = (int)N; a.CK = (int)(K / 16); a.P = P;
     a.geglu_L = 0; a.absmax_bits = nullptr; a.v_dt = v_dt < 1 ? 1 : v_dt; a.prec = prec;
-    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+    a.splits = 1; a.ln_part = nullptr; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = 0;
 #endif
@@ -2149,7 +2205,7 @@ extern "C" int mvip_gemm_geglu_f16x3_sink(const void *xs, const void *packed, co
     a.geglu_L = (int)L; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1; a.prec = prec;
     for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
     a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)(M2 / 2); a.sec[0].kind = 1;
-    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+    a.splits = 1; a.ln_part = nullptr; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = 0;
 #endif
@@ -2180,7 +2236,7 @@ extern "C" int mvip_gemm_f16x3_planes_ws(const void *xs, const void *packed, con
     a.geglu_L = 0; a.absmax_bits = nullptr; a.nsec = 1; a.v_dt = 1; a.prec = prec;
     for (int i = 0; i < 3; ++i) { a.sec[i].ptr = nullptr; a.sec[i].scale = 1.f; a.sec[i].row_end = 0; a.sec[i].kind = 0; }
     a.sec[0].ptr = (char *)out_planes; a.sec[0].scale = out_scale; a.sec[0].row_end = (int)M; a.sec[0].kind = 1;
-    a.splits = 1; a.sks = (int)(K / 32); a.partial = nullptr;
+    a.splits = 1; a.ln_part = nullptr; a.sks = (int)(K / 32); a.partial = nullptr;
 #ifdef MVIP_EXPERIMENT_GEMM
     a.dbg = 0;
 #endif

@@ -386,7 +386,7 @@ template <int IT>
 __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const float (&wts)[IT], const float (&uu)[IT], int64_t ray,
                                                  int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
                                                  float *__restrict__ z_std, int64_t *__restrict__ inds_out,
-                                                 float *__restrict__ cdf_out, int *lds_w = nullptr) {
+                                                 float *__restrict__ cdf_out, int *lds_w = nullptr, bool counting = true) {
     const int l = lane_id();
     const int nb = Nc - 1;                           // midpoints
     float bins[IT], smp[IT], cdf[IT];
@@ -432,7 +432,7 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
     if constexpr (IT == 1) {
-        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1), lds_w, lds_w != nullptr, uu[0])) return;
+        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1), lds_w, counting && lds_w != nullptr, uu[0])) return;
     }
     constexpr int M = 2 * IT;
     float v[M];

@@ -64,8 +64,9 @@ ln_stats_kernel(const float *__restrict__ x, int C, int L, int LP, double *__res
 __global__ void __launch_bounds__(256)
 ln_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                 const double *__restrict__ part, int C, int L, int LP, float eps, float out_scale,
-                uint4 *__restrict__ xs, int prec) {
-    const int CK = C / 16, S = C / 64;
+                uint4 *__restrict__ xs, int prec, int S) {
+    // S: segments of the partial statistics (C / 64 from ln_stats_kernel, the producing GEMM's row blocks otherwise)
+    const int CK = C / 16;
     const int ck = blockIdx.y % CK, n = blockIdx.y / CK;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= LP) return;
@@ -240,7 +241,23 @@ extern "C" int mvip_layernorm_split_planes(const float *x, const float *gamma, c
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)(LP / 64), (unsigned)(C / 64), (unsigned)N), dim3(256), 0, st, x,
                        (int)C, (int)L, (int)LP, (double *)workspace);
     hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)(LP / 256), (unsigned)(N * (C / 16))), dim3(256), 0, st, x, gamma,
-                       beta, (const double *)workspace, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs, prec);
+                       beta, (const double *)workspace, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs, prec, (int)(C / 64));
+    return check_launch();
+}
+
+// The apply half alone, on statistics somebody else left: `part` = [N][segments][2][LP] fp64 sums / sums of squares over
+// `segments` disjoint channel ranges that cover C (mvip_gemm_f16x3_ws_ln's output): one launch instead of two, no extra
+// pass over x.  Same arithmetic from the statistics on (fp64 mean / variance, then fp32).
+extern "C" int mvip_layernorm_split_planes_stats(const float *x, const float *gamma, const float *beta, const void *part,
+                                                 int64_t segments, int64_t N, int64_t C, int64_t L, int64_t LP, float eps,
+                                                 float out_scale, void *xs, int prec, void *stream) {
+    if ((prec < 0 || prec > 2) || N < 0 || C <= 0 || C % 16 != 0 || L <= 0 || LP < L || LP % 256 != 0 || N * (C / 16) > 65535 ||
+        segments < 1 || segments > C)
+        return MVIP_EINVAL;
+    if (N == 0) return MVIP_OK;
+    if (!x || !xs || !part) return MVIP_EINVAL;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)(LP / 256), (unsigned)(N * (C / 16))), dim3(256), 0, as_stream(stream), x, gamma,
+                       beta, (const double *)part, (int)C, (int)L, (int)LP, eps, out_scale, (uint4 *)xs, prec, (int)segments);
     return check_launch();
 }
 

@@ -241,26 +241,28 @@ def _prompt_kv(pk, ctx, want_vmax=False):
     return hit if want_vmax else hit[:-1]
 
 
-def _block_sinks(h, pk, ctx, N, L, LP):
-    """The block with every contraction writing the next one's operands (module docstring, USE_SINKS)."""
+def _block_sinks(h, pk, ctx, N, L, LP, st_h=None):
+    """The block with every contraction writing the next one's operands (module docstring, USE_SINKS).  st_h: the LayerNorm
+    statistics of h its producer left (ops.gemm_f16x3 with ln_stats); round 6: each projection that writes the residual
+    stream leaves the next LayerNorm's statistics from its epilogue."""
     C, R, heads, D = pk.C, pk.R, pk.heads, pk.D
     # ---- self-attention: LayerNorm planes -> {Q planes, K planes, V fragments} -> attention -> o planes -> projection ----
     g, b, eps, s, st = pk.ln[0]
-    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s, stats=st_h)
     qs, ks, vp = ops.gemm_f16x3_sinks(xs, pk.qkv1_s, N, C, LP, [(R, 'planes', pk.s_q1), (R, 'planes', pk.s_k1),
                                                                 (pk.RV, 'vfrag', pk.s_v1)], x_scale2=st, v_dt=pk.DT)
     op = ops.attention_f16x3_sink(qs, ks, vp, pk.t_q1, pk.t_k1, pk.t_v1, N, heads, D, L, LP, L, L, LP, LP, LP // 16)
-    h = ops.gemm_f16x3(op, pk.o1, N, C, C, LP, bias=pk.bo1, residual=h, x_scale2=pk.t_v1)
+    h, st_h = ops.gemm_f16x3(op, pk.o1, N, C, C, LP, bias=pk.bo1, residual=h, x_scale2=pk.t_v1, ln_stats=True)
     # ---- cross-attention onto the prompt tokens (their K planes / V fragments are cached per prompt) ----
     g, b, eps, s, st = pk.ln[1]
-    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s, stats=st_h)
     (qs,) = ops.gemm_f16x3_sinks(xs, pk.q2, N, C, LP, [(R, 'planes', pk.s_q2)], x_scale2=st)
     ks2, vp2, sk2, sv2, T, TP, vmax2 = _prompt_kv(pk, ctx, want_vmax=True)
     op = ops.attention_f16x3_sink(qs, ks2, vp2, pk.t_q2, sk2, sv2, N, heads, D, L, LP, T, TP, LP, TP, TP // 16)
-    h = ops.gemm_f16x3(op, pk.o2, N, C, C, LP, bias=pk.bo2, residual=h, x_scale2=sv2)
+    h, st_h = ops.gemm_f16x3(op, pk.o2, N, C, C, LP, bias=pk.bo2, residual=h, x_scale2=sv2, ln_stats=True)
     # ---- GEGLU feed-forward: the product leaves the first projection as the second one's operand planes ----
     g, b, eps, s, st = pk.ln[2]
-    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s)
+    xs = ops.layernorm_split(h, g, b, eps, N, C, L, LP, s, stats=st_h)
     ap = ops.gemm_geglu_f16x3_sink(xs, pk.ff1, pk.b1, N, C, 8 * C, LP, L, pk.s_act, x_scale2=st)
     # the finished residual stream leaves as proj_out's operand planes (its fp32 form has no other reader)
     s_h3, t_h3 = _h3_scale(pk, L, vmax2)
@@ -324,7 +326,7 @@ def transformer2d_forward(mod, x, ctx):
     xc = x.detach().contiguous()
     if L % 256 == 0:
         LP = L
-        h = ops.norm_conv1x1(xc, mod.norm, mod.proj_in)                              # GroupNorm + 1x1 conv: [N, C, L]
+        h, st_h = ops.norm_conv1x1(xc, mod.norm, mod.proj_in, ln_stats=True)             # GroupNorm + 1x1 conv: [N, C, L]
         res = xc.reshape(N, C, L)
     else:                                                                            # the 8x8 level: pad the token axis
         LP = (L + 255) // 256 * 256
@@ -332,11 +334,11 @@ def transformer2d_forward(mod, x, ctx):
         hp = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
         hp[:, :, :L] = hn.reshape(N, C, L)
         xs, s2 = ops._scaled_planes(hp, N, C, LP, C * LP, LP, 1, forward_activation=True)
-        h = ops.gemm_f16x3(xs, pk.pin, N, C, C, LP, bias=pk.bin, x_scale2=s2)
+        h, st_h = ops.gemm_f16x3(xs, pk.pin, N, C, C, LP, bias=pk.bin, x_scale2=s2, ln_stats=True)
         res = torch.zeros((N, C, LP), device=x.device, dtype=torch.float32)
         res[:, :, :L] = xc.reshape(N, C, L)
     if USE_SINKS:
-        xs, s2 = _block_sinks(h, pk, ctx, N, L, LP)
+        xs, s2 = _block_sinks(h, pk, ctx, N, L, LP, st_h)
     else:
         h = _block(h, pk, ctx, N, L, LP)
         xs, s2 = ops._scaled_planes(h, N, C, LP, C * LP, LP, 1, forward_activation=True)

@@ -1066,9 +1066,14 @@ def split_planes_strided(x, N, K, P, sn, sc, sp, scale2=None):
 GEMM_CFG = 0       # 0: tile chosen by shape; 1..4 force a workgroup tile (A/B timing switch, see include/mvip_nerf.h)
 
 
-def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None, out=None):
+LN_STATS_FROM_GEMM = True      # A/B switch: False = every LayerNorm computes its statistics from its input (one launch more)
+
+
+def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, x_scale2=None, out=None, ln_stats=False):
     """Y[n][m][p] = sum_k A[m][k] X[n][k][p] (+ bias[m] + chan_add[n][m] + residual[n][m][p]), fp32 [N, M, P].
-    out: a contiguous fp32 tensor of N * M * P elements to write instead of a new one (e.g. a slice of a larger result)."""
+    out: a contiguous fp32 tensor of N * M * P elements to write instead of a new one (e.g. a slice of a larger result).
+    ln_stats: returns (Y, stats) -- stats = (fp64 partial moments of Y over its rows, segments) for `layernorm_split(...,
+    stats=)` when this shape's launch can leave them in its epilogue (round 6), else None."""
     if out is not None:
         assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == N * M * P
         y = out
@@ -1077,12 +1082,19 @@ def gemm_f16x3(xs, packed, N, K, M, P, bias=None, chan_add=None, residual=None, 
     if GEMM_CFG:
         call('mvip_gemm_f16x3_cfg', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
              ptr(residual), ptr(x_scale2), N, K, M, P, ptr(y), int(GEMM_CFG), _prec_w(packed), stream())
-        return y
+        return (y, None) if ln_stats else y
     nbytes = int(_lib.load().mvip_gemm_workspace_bytes(N, K, M, P))            # split-K partial sums (few shapes)
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
+    if ln_stats:
+        S = int(_lib.load().mvip_gemm_ln_segments(N, K, M, P, _prec_w(packed))) if (LN_STATS_FROM_GEMM and not GEMM_CFG) else 0
+        if S:
+            part = torch.empty(N * S * 2 * P, device=y.device, dtype=torch.float64)
+            call('mvip_gemm_f16x3_ws_ln', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
+                 ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), ptr(part, torch.float64), _prec_w(packed), stream())
+            return y, (part, S)
     call('mvip_gemm_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add), ptr(residual),
          ptr(x_scale2), N, K, M, P, ptr(y), ptr(ws), _prec_w(packed), stream())
-    return y
+    return (y, None) if ln_stats else y
 
 
 # Opt-in: split the forward ACTIVATIONS of the UNet (evaluated under no_grad) at a fixed scale of 1 instead of a
@@ -1384,8 +1396,9 @@ def conv_gemm(x, conv, pads=None):
     return _ConvGemm.apply(x, conv, tuple(int(v) for v in pads))
 
 
-def norm_conv1x1(x, norm, conv):
-    """conv1x1(group_norm(x)) + bias, forward only (the UNet's transformer proj_in; runs under no_grad)."""
+def norm_conv1x1(x, norm, conv, ln_stats=False):
+    """conv1x1(group_norm(x)) + bias, forward only (the UNet's transformer proj_in; runs under no_grad).
+    ln_stats: as gemm_f16x3's (returns (y, stats))."""
     xc = x.detach().contiguous()
     N, C, H, W = xc.shape
     L, G, dev = H * W, norm.num_groups, xc.device
@@ -1404,7 +1417,7 @@ def norm_conv1x1(x, norm, conv):
         call('mvip_groupnorm_split_planes_moments', ptr(xc), ptr(gw), ptr(gb), ptr(rm, torch.float64), float(norm.eps),
              N, C, L, G, 0, ptr(xs, torch.float16), _prec(), stream())
     bias = None if conv.bias is None else conv.bias.detach().contiguous()
-    return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias)     # [N, Cout, L]
+    return gemm_f16x3(xs, _conv1x1_packed(conv, False), N, C, conv.out_channels, L, bias=bias, ln_stats=ln_stats)     # [N, Cout, L]
 
 
 def tokens_conv1x1(h, conv, residual):
@@ -1445,10 +1458,16 @@ def absmax_scale_sections(x, outer, sections, length):
     return sc
 
 
-def layernorm_split(x, weight, bias, eps, N, C, L, LP, out_scale):
+def layernorm_split(x, weight, bias, eps, N, C, L, LP, out_scale, stats=None):
     """LayerNorm over the channel axis of channel-major x [N, C, LP] (tokens < L), times the power of two
-    `out_scale`, as fp16 hi/lo split planes (the B operand of gemm_f16x3 with P = LP)."""
+    `out_scale`, as fp16 hi/lo split planes (the B operand of gemm_f16x3 with P = LP).  stats: the (partial moments,
+    segments) pair the GEMM that produced x left (gemm_f16x3(..., ln_stats=True)): the statistics launch is skipped."""
     xs = _split_buffer(N, C, LP, x.device)
+    if stats is not None:
+        part, S = stats
+        call('mvip_layernorm_split_planes_stats', ptr(x), ptr(weight), ptr(bias), ptr(part, torch.float64), int(S), int(N), int(C),
+             int(L), int(LP), float(eps), float(out_scale), ptr(xs, torch.float16), _prec(), stream())
+        return xs
     ws = torch.empty(int(_lib.load().mvip_layernorm_workspace_bytes(N, C, LP)) // 8, device=x.device, dtype=torch.float64)
     call('mvip_layernorm_split_planes', ptr(x), ptr(weight), ptr(bias), int(N), int(C), int(L), int(LP), float(eps),
          float(out_scale), ptr(ws, torch.float64), ptr(xs, torch.float16), _prec(), stream())

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert _lib.load().mvip_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().mvip_abi_version() == _lib.ABI_VERSION == 5
     assert _lib.load().mvip_build_is_experiment() == 0       # the product library is never a timing-experiment build
     assert _lib.load().mvip_mlp_packed_floats() == 597248
     assert _lib.load().mvip_strerror(-1).decode().startswith('invalid')

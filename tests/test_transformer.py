@@ -122,6 +122,55 @@ def test_layernorm_split_feeds_gemm(cuda):
         np.testing.assert_allclose(N(y), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
 
 
+def test_layernorm_statistics_from_the_producing_gemm(cuda):
+    """Round 6 (VERDICT r5 task 2): a projection that writes the residual stream leaves the NEXT LayerNorm's statistics from its
+    epilogue (mvip_gemm_f16x3_ws_ln: per token and 32 / 64-row segment the fp64 sum and sum of squares of the finished rows, bias
+    and residual included), and mvip_layernorm_split_planes_stats normalises from them: one launch instead of two, no pass over
+    the tensor for its moments.  Checked per shape of the UNet's levels: y is bit-equal to the plain GEMM's, the partial moments
+    equal fp64 sums of y's rows, the planes equal those of the two-launch LayerNorm (the same fp64 statistics up to the order
+    of the additions: bit-equal in all but a handful of elements) and W2 LN(y) agrees with fp64.  A split-K shape declines
+    (segments = 0) and falls back."""
+    from mvip_nerf_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    lib = ops._lib.load()
+    for Nb, C, L, LP in ((2, 320, 4096, 4096), (2, 640, 1024, 1024), (1, 320, 256, 256), (2, 1280, 64, 256)):
+        K = C
+        x = torch.randn(Nb, K, LP, generator=gen)
+        W = torch.randn(C, K, generator=gen) / K ** 0.5
+        bias = torch.randn(C, generator=gen) * 0.1
+        res = torch.randn(Nb, C, LP, generator=gen) * 3.0 + 1.5              # a residual stream with a mean (cancellation in E[x^2] - mean^2)
+        g = torch.randn(C, generator=gen) * 0.3 + 1.0
+        b = torch.randn(C, generator=gen) * 0.2
+        xd, s2 = ops._scaled_planes(x.to(cuda), Nb, K, LP, K * LP, LP, 1)
+        packed = ops.gemm_pack_a(W.to(cuda), C, K, K, 1, weights=True)
+        S = int(lib.mvip_gemm_ln_segments(Nb, K, C, LP, ops._prec_w(packed)))
+        y0 = ops.gemm_f16x3(xd, packed, Nb, K, C, LP, bias=bias.to(cuda), residual=res.to(cuda), x_scale2=s2)
+        y1, st = ops.gemm_f16x3(xd, packed, Nb, K, C, LP, bias=bias.to(cuda), residual=res.to(cuda), x_scale2=s2, ln_stats=True)
+        assert torch.equal(y0, y1)
+        if C == 1280:                                                       # 80 workgroups x 40 stages: split over K
+            assert S == 0 and st is None
+            continue
+        assert S in (C // 32, C // 64) and st is not None and st[1] == S
+        part = st[0].reshape(Nb, S, 2, LP).cpu().numpy()
+        yd = y1.double().cpu().reshape(Nb, S, C // S, LP)
+        np.testing.assert_allclose(part[:, :, 0], yd.sum(2).numpy(), rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(part[:, :, 1], (yd * yd).sum(2).numpy(), rtol=1e-12)
+        a = ops.layernorm_split(y1, g.to(cuda), b.to(cuda), 1e-5, Nb, C, L, LP, 16.0)
+        c = ops.layernorm_split(y1, g.to(cuda), b.to(cuda), 1e-5, Nb, C, L, LP, 16.0, stats=st)
+        same = float((a == c).float().mean())
+        assert same > 0.999, same
+        af, cf = a.float().cpu().numpy(), c.float().cpu().numpy()
+        assert np.abs(af - cf).max() <= 2e-3 * max(np.abs(af).max(), 1.0)   # a differing hi half moves by one fp16 ulp at most
+        M2 = 64
+        W2 = torch.randn(M2, C, generator=gen) / C ** 0.5
+        sc = torch.tensor([16.0, 1 / 16.0, 0, 0], device=cuda)
+        out = ops.gemm_f16x3(c, ops.gemm_pack_a(W2.to(cuda), M2, C, C, 1), Nb, C, M2, LP, x_scale2=sc)
+        ln = torch.nn.functional.layer_norm(y1.double().cpu().transpose(1, 2), (C,), g.double(), b.double(), 1e-5)
+        ref = torch.einsum('mc,nlc->nml', W2.double(), ln)
+        ref[:, :, L:] = 0
+        np.testing.assert_allclose(N(out), ref.float().numpy(), rtol=0, atol=3e-6 * float(ref.abs().max()))
+
+
 def test_geglu_and_linear_small(cuda):
     from mvip_nerf_amd import ops
     gen = torch.Generator().manual_seed(4)
