@@ -17,61 +17,35 @@
 // statistic, LDS address space spelled out for the rank row; ~400 before).
 // HBM traffic per ray (Nc=Nf=64): 512 B in (z, weights) + 256 B (u) and 512+256+4 B out.
 #include "sample_pdf_device.h"
-#include <stdlib.h>
 
 namespace mvip {
 
-// RPW rays per wavefront, consecutive, the next ray's rows requested BEFORE the current ray is worked on.  One ray per wave
-// (RPW = 1) is the right shape while the rows come out of the L2 / Infinity Cache (a frame's 190,512 rays: 0.079 / 0.125 ms
-// against 0.085 / 0.137 with four rays per wave, round 5); past the Infinity Cache the launch is bound by
-// latency x bytes in flight (32 waves per CU x 768 B = 24 KB per CU: 2.5 TB/s whatever the arithmetic does, round 6) and the
-// prefetching form doubles what a wave keeps in flight.  The host picks RPW by the ray count (MVIP_SAMPLE_RPW overrides).
-// counting: 0 = sort unsorted samples (the round-5 route; MVIP_SAMPLE_COUNTING=0, A/B switch), 1 = counting_merge64.
-template <int IT, int RPW>
+// One ray per wavefront.  (Round 5 tried four consecutive rays per wave with the next ray's rows requested before the current
+// ray is worked on: 0.085 / 0.137 ms against 0.079 / 0.125 -- the launch is not bound by latency x occupancy.)
+template <int IT>
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(
     const float *__restrict__ z, const float *__restrict__ weights, const float *__restrict__ u, int u_is_row,
     int64_t B, int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
-    float *__restrict__ z_std, int64_t *__restrict__ inds_out, float *__restrict__ cdf_out, int counting) {
-    __shared__ int rank_rows[4][RANK_LDS_WORDS];     // per wave: the count row of rank_merge64 + the rows of counting_merge64
+    float *__restrict__ z_std, int64_t *__restrict__ inds_out, float *__restrict__ cdf_out) {
+    __shared__ int rank_rows[4][80];                 // per wave: the 65-word row of rank_merge64's prefix-maximum count
     // the wave index through readfirstlane: the ray number and every row base derived from it are then SCALAR values (the
     // compiler cannot know that threadIdx.x >> 6 is wave-uniform; as a vector value each of the eight row accesses cost ~8
     // VALU instructions of 64-bit address arithmetic)
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t ray0 = ((int64_t)blockIdx.x * 4 + wave_in_block) * RPW;
-    if (ray0 >= B) return;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wave_in_block;
+    if (ray >= B) return;
     const int l = lane_id();
     const int nb = Nc - 1;                           // midpoints
-    auto load = [&](int64_t ray, float (&zc)[IT], float (&wts)[IT], float (&uu)[IT]) {
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int e = i * 64 + l;
-            zc[i] = e < Nc ? z[ray * Nc + e] : 0.f;
-            // weights[..., 1:-1]: weight e of the pdf is coarse weight e+1
-            wts[i] = e < nb - 1 ? weights[ray * Nc + e + 1] : 0.f;
-            uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
-        }
-    };
-    int *lds_row = counting ? rank_rows[wave_in_block] : nullptr;
     float zc[IT], wts[IT], uu[IT];
-    load(ray0, zc, wts, uu);
-    if constexpr (RPW == 1) {
-        sample_merge_ray<IT>(zc, wts, uu, ray0, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out, rank_rows[wave_in_block], counting != 0);
-    } else {
-        (void)lds_row;
-#pragma unroll 1
-        for (int k = 0; k < RPW; ++k) {
-            const int64_t ray = ray0 + k;
-            if (ray >= B) break;
-            float zn[IT], wn[IT], un[IT];
-            const bool more = k + 1 < RPW && ray + 1 < B;
-            if (more) load(ray + 1, zn, wn, un);
-            sample_merge_ray<IT>(zc, wts, uu, ray, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out, rank_rows[wave_in_block], counting != 0);
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < IT; ++i) { zc[i] = zn[i]; wts[i] = wn[i]; uu[i] = un[i]; }
-            }
-        }
+    for (int i = 0; i < IT; ++i) {
+        const int e = i * 64 + l;
+        zc[i] = e < Nc ? z[ray * Nc + e] : 0.f;
+        // weights[..., 1:-1]: weight e of the pdf is coarse weight e+1
+        wts[i] = e < nb - 1 ? weights[ray * Nc + e + 1] : 0.f;
+        uu[i] = e < Nf ? (u_is_row ? u[e] : u[ray * Nf + e]) : 2.f;
     }
+    sample_merge_ray<IT>(zc, wts, uu, ray, Nc, Nf, z_samples, z_merged, z_std, inds_out, cdf_out, rank_rows[wave_in_block]);
 }
 
 template <int IT>
@@ -115,15 +89,10 @@ extern "C" int mvip_sample_pdf_merge(const float *z, const float *weights, const
     if (B == 0) return MVIP_OK;
     if (!z || !weights || !u || !z_samples || !z_merged || !z_std) return MVIP_EINVAL;
     const int mx = Nc > Nf ? Nc : Nf;
-    static const int counting = [] { const char *e = getenv("MVIP_SAMPLE_COUNTING"); return e ? atoi(e) : 1; }();     // A/B switch
-    static const int rpw_env = [] { const char *e = getenv("MVIP_SAMPLE_RPW"); return e ? atoi(e) : 0; }();           // tuning
-    // rays per wave: 1 while a launch's rows (1,540 B per ray) stay inside the 256 MB Infinity Cache, 4 with prefetch beyond
-    const int rpw = mx > 64 ? 1 : (rpw_env == 1 || rpw_env == 2 || rpw_env == 4 ? rpw_env : (B * (int64_t)(Nc + 2 * Nf + Nc + Nf) * 4 > ((int64_t)200 << 20) ? 4 : 1));
-    const dim3 grid((unsigned)((B + 4 * rpw - 1) / (4 * rpw))), block(256);
-#define CALL(I, R) hipLaunchKernelGGL((sample_pdf_merge_kernel<I, R>), grid, block, 0, as_stream(stream), z, weights, u, \
-                                      u_is_row, B, Nc, Nf, z_samples, z_merged, z_std, inds, cdf, counting)
-    if (mx <= 64) { if (rpw == 4) CALL(1, 4); else if (rpw == 2) CALL(1, 2); else CALL(1, 1); }
-    else if (mx <= 128) { CALL(2, 1); } else if (mx <= 256) { CALL(4, 1); } else return MVIP_EUNSUP;
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define CALL(I) hipLaunchKernelGGL(sample_pdf_merge_kernel<I>, grid, block, 0, as_stream(stream), z, weights, u, \
+                                   u_is_row, B, Nc, Nf, z_samples, z_merged, z_std, inds, cdf)
+    if (mx <= 64) { CALL(1); } else if (mx <= 128) { CALL(2); } else if (mx <= 256) { CALL(4); } else return MVIP_EUNSUP;
 #undef CALL
     return check_launch();
 }

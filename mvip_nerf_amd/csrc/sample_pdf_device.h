@@ -235,86 +235,6 @@ __device__ __forceinline__ int dpp_incl_max_nonneg(int v) {
     return v;
 }
 
-// inclusive prefix SUM of integers over the 64 lanes (the six DPP steps of common.h::dpp_incl_scan_add)
-__device__ __forceinline__ int dpp_incl_sum_i32(int v) {
-    v += dpp_i32<0x111>(0, v);
-    v += dpp_i32<0x112>(0, v);
-    v += dpp_i32<0x114>(0, v);
-    v += dpp_i32<0x118>(0, v);
-    v += dpp_i32<0x142, 0xa>(0, v);
-    v += dpp_i32<0x143, 0xc>(0, v);
-    return v;
-}
-
-// words of LDS one wave hands rank_merge64 (lds_w): the 65-word count row + four 64-word rows of counting_merge64
-constexpr int RANK_LDS_WORDS = 80 + 4 * 64;
-
-// Merge of the sorted coarse depths a with UNSORTED new samples b (random uniforms) WITHOUT sorting b: a counting merge.
-//   * rank of b_j among the coarse depths: the inverse CDF's own interval (below_hint) + one compare, as in rank_merge64;
-//   * rank of b_j among the samples: the inverse CDF is monotone, so the samples' order is the order of their uniforms u_j.
-//     64 uniforms fall into the 64 buckets floor(64 u) about one per bucket WHATEVER the pdf looks like (a peaked pdf piles
-//     the samples into a few depth intervals, not the uniforms into a few buckets): a histogram by LDS atomics (the returned
-//     old count = arrival index inside the bucket), its exclusive prefix sum (six DPP steps) = samples in lower buckets, and
-//     a loop over the bucket's members (as long as the fullest bucket: ~4 trips) that ranks by VALUE inside the bucket;
-//   * #{b < a_i} for the coarse depths = inclusive prefix sum of the histogram of the samples' coarse ranks.
-// ~60 VALU instructions + ~14 LDS operations instead of the 21-stage sort (~85), the seven-step search (~25) and the
-// prefix-maximum count (~20).  The order by (bucket, value) is CHECKED against the order by value (the interpolation can round
-// a sample one ulp past its interval's upper midpoint): the ranks are used only if the sequence they produce is sorted.
-// Returns false with nothing written -- the caller sorts -- if the check fails, a bucket holds more than COUNTING_MAX_BUCKET
-// samples (adversarial uniforms) or the interval hint does not bracket a sample (coinciding depths).
-constexpr int COUNTING_MAX_BUCKET = 12;
-__device__ __forceinline__ bool counting_merge64(const float a_key, int na, const float b_key, int nb, const float u, int below_hint,
-                                                 float *__restrict__ out_row, int *lds_w) {
-    typedef __attribute__((address_space(3))) int lds_int;
-    const int l = lane_id();
-    lds_int *cnt_row = (lds_int *)lds_w;                         // [65] histogram of the samples' ranks among the coarse depths
-    lds_int *hist = cnt_row + 80;                                // [64] samples per uniform bucket
-    lds_int *base_row = hist + 64;                               // [64] samples in lower buckets
-    lds_int *memb = base_row + 64;                               // [64] sample values grouped by bucket, arrival order inside
-    lds_int *sorted = memb + 64;                                 // [64] sample values by rank (the check)
-    const bool valid = l < nb;
-    const int r0 = below_hint + 1;                               // a_0 .. a_{r0 - 1} <= b_j
-    const float a0 = lane_read(a_key, r0 & 63), a1 = lane_read(a_key, (r0 + 1) & 63);
-    const float e0 = r0 < 64 ? a0 : INFINITY, e1 = r0 + 1 < 64 ? a1 : INFINITY;
-    if (__any(valid && !(e1 > b_key))) return false;
-    const int cbj = min(r0 + (e0 <= b_key ? 1 : 0), na);        // #{a <= b_j}
-    const int bk = max(0, min(63, (int)(u * 64.f)));
-    // one wave owns the rows and a wave's LDS operations execute in order; the compiler is kept from reordering them
-    *(volatile lds_int *)(hist + l) = 0;
-    *(volatile lds_int *)(cnt_row + l) = 0;
-    if (l == 0) *(volatile lds_int *)(cnt_row + 64) = 0;
-    asm volatile("" ::: "memory");
-    int arrival = 0;
-    if (valid) {
-        arrival = __hip_atomic_fetch_add(hist + bk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(cnt_row + cbj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    asm volatile("" ::: "memory");
-    const int h = *(volatile lds_int *)(hist + l);
-    if (__any(h > COUNTING_MAX_BUCKET)) return false;
-    const int incl = dpp_incl_sum_i32(h);
-    *(volatile lds_int *)(base_row + l) = incl - h;
-    const int ca = dpp_incl_sum_i32(*(volatile lds_int *)(cnt_row + l));      // #{b < a_l} = samples whose coarse rank is <= l
-    asm volatile("" ::: "memory");
-    const int base = *(volatile lds_int *)(base_row + bk);
-    const int cnt = valid ? *(volatile lds_int *)(hist + bk) : 0;
-    if (valid) *(volatile lds_int *)(memb + base + arrival) = __builtin_bit_cast(int, b_key);
-    asm volatile("" ::: "memory");
-    int rank = base;
-    for (int t = 0; __any(t < cnt); ++t) {
-        const float other = __builtin_bit_cast(float, *(volatile lds_int *)(memb + ((base + t) & 63)));
-        rank += (t < cnt && (other < b_key || (other == b_key && t < arrival))) ? 1 : 0;
-    }
-    if (valid) *(volatile lds_int *)(sorted + rank) = __builtin_bit_cast(int, b_key);
-    asm volatile("" ::: "memory");
-    const float sv = valid ? __builtin_bit_cast(float, *(volatile lds_int *)(sorted + l)) : INFINITY;
-    const float sn = dpp_from_next(sv, sv);
-    if (__any(l < 63 && sn < sv)) return false;
-    if (l < na) out_row[l + ca] = a_key;
-    if (valid) out_row[rank + cbj] = b_key;
-    return true;
-}
-
 // Merge of two SORTED lists of <= 64 values each by rank: element i of a lands at i + #{b < a_i}, element j of b at
 // j + #{a <= b_j} (ties: the coarse depth first; the VALUES equal those of sort(cat[a, b]) in every case).  12
 // cross-lane reads and two scattered 4-byte stores into the ray's own 512-byte row instead of the 28-stage / 54-shuffle
@@ -325,11 +245,8 @@ __device__ __forceinline__ bool counting_merge64(const float a_key, int na, cons
 // checks that the depth after that is strictly greater (it is, unless depths coincide or the interpolation rounded past
 // the upper midpoint), and the wave falls back to the search if any lane fails the check.  Only meaningful while b is in
 // its original lane order, i.e. when it did not have to be sorted.
-// u_of_b (with lds_w of RANK_LDS_WORDS words and a hint): the uniform lane j's sample was drawn with -- unsorted samples are
-// then merged by counting_merge64 instead of being sorted first; has_u is wave-uniform.
 __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int nb, bool b_may_be_unsorted,
-                                             float *__restrict__ out_row, int below_hint = -1, int *lds_w = nullptr,
-                                             bool has_u = false, float u_of_b = 0.f) {
+                                             float *__restrict__ out_row, int below_hint = -1, int *lds_w = nullptr) {
     const int l = lane_id();
     const float a_key = l < na ? a : INFINITY;
     float b_key = l < nb ? b : INFINITY;
@@ -339,8 +256,7 @@ __device__ __forceinline__ bool rank_merge64(const float a, int na, float b, int
     bool b_in_lane_order = true;
     if (__any(l < 63 && b_next < b_key)) {
         if (!b_may_be_unsorted) return false;
-        if (has_u && lds_w && below_hint >= 0 && counting_merge64(a_key, na, b_key, nb, u_of_b, below_hint, out_row, lds_w)) return true;
-        bitonic_sort64(b_key);                                   // no uniforms / the counting merge declined: sort the 64 new samples (21 stages)
+        bitonic_sort64(b_key);                                   // random u: sort the 64 new samples (21 stages)
         b_in_lane_order = false;
     }
     // counts clamped to the VALID entries: a valid key equal to +inf (far = inf, non-lindisp) would otherwise count the
@@ -386,7 +302,7 @@ template <int IT>
 __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const float (&wts)[IT], const float (&uu)[IT], int64_t ray,
                                                  int Nc, int Nf, float *__restrict__ z_samples, float *__restrict__ z_merged,
                                                  float *__restrict__ z_std, int64_t *__restrict__ inds_out,
-                                                 float *__restrict__ cdf_out, int *lds_w = nullptr, bool counting = true) {
+                                                 float *__restrict__ cdf_out, int *lds_w = nullptr) {
     const int l = lane_id();
     const int nb = Nc - 1;                           // midpoints
     float bins[IT], smp[IT], cdf[IT];
@@ -432,7 +348,7 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
     // merge: sort(cat[z, z_samples]).  Both lists are sorted in the reference configuration (stratified coarse depths;
     // the inverse CDF is monotone, so the new samples are sorted whenever u is -- always in deterministic mode): rank merge.
     if constexpr (IT == 1) {
-        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1), lds_w, counting && lds_w != nullptr, uu[0])) return;
+        if (rank_merge64(zc[0], Nc, smp[0], Nf, true, z_merged + ray * (Nc + Nf), max(0, inds[0] - 1), lds_w)) return;
     }
     constexpr int M = 2 * IT;
     float v[M];
