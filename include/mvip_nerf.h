@@ -37,7 +37,8 @@ extern "C" {
                                    4: mvip_mlp_*_f16x3_w16 (two-waves-per-SIMD split-precision forward) added,
                                       mvip_mlp_forward_rays16_persistent removed;
                                    5: LayerNorm statistics from the producing GEMM's epilogue (mvip_gemm_ln_segments,
-                                      mvip_gemm_f16x3_ws_ln, mvip_layernorm_split_planes_stats) */
+                                      mvip_gemm_f16x3_ws_ln, mvip_layernorm_split_planes_stats), GroupNorm moments
+                                      from the unsplit convolution's epilogue (mvip_conv3x3_f16x3_tile_moments) */
 
 int         mvip_abi_version(void);
 int         mvip_build_is_experiment(void); /* 1: compiled with a -DMVIP_EXPERIMENT_* macro (timing build, WRONG results) */
@@ -390,6 +391,17 @@ int mvip_conv3x3_f16x3_ws_moments(const void *xs, const void *packed, const floa
                                   const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                                   int64_t H, int64_t W, float *y, void *workspace, void *row_moments, int prec,
                                   void *stream);
+/* Unsplit launches (mvip_conv3x3_workspace_bytes == 0, images wider than 8 pixels): the same moments from partials the
+ * convolution's epilogue leaves per (image, channel, pixel tile, wave) -- fp32 sums of 64 finished values, added in fp64 in
+ * index order by a second, small launch (N * Cout rows) -- instead of a pass over y (DS_NeRF/guidance/sd_utils.py:330-352,
+ * :390-403: the resnet chains of the VAE encoder and the UNet).  tile_scratch: mvip_conv3x3_tile_moments_scratch_bytes(...)
+ * bytes (0 = this shape cannot: use mvip_conv3x3_f16x3_ws / _ws_moments); moments: mvip_groupnorm_workspace_bytes(N, Cout,
+ * H * W) bytes in mvip_groupnorm_stats' workspace layout (what mvip_groupnorm_split_planes_moments reads). */
+int64_t mvip_conv3x3_tile_moments_scratch_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W);
+int mvip_conv3x3_f16x3_tile_moments(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                    const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
+                                    int64_t H, int64_t W, float *y, void *tile_scratch, void *moments, int prec,
+                                    void *stream);
 int mvip_conv3x3_f16x3_ws(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                           int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream);

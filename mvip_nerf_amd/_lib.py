@@ -137,6 +137,9 @@ _SIGNATURES = {
     'mvip_groupnorm_backward': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _int, _int, _int, _c_f, _c_f,
                                        _c_f]),
     'mvip_conv3x3_row_moments_doubles': (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    'mvip_conv3x3_tile_moments_scratch_bytes': (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    'mvip_conv3x3_f16x3_tile_moments': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f,
+                                               _int, _c_f]),
     'mvip_conv3x3_f16x3_ws_moments': (_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64, _i64, _i64, _i64, _i64, _c_f, _c_f, _c_f,
                                              _int, _c_f]),
     'mvip_groupnorm_backward_maxima': (_i64, [_i64, _i64, _i64]),

@@ -463,6 +463,11 @@ struct ConvArgs {
     // writes its raw accumulators to partial[split][n][Cout][H][W]; cv_split_reduce_kernel sums them in order
     int splits, cks;
     float *partial;
+    // GroupNorm moment partials of the OUTPUT from the unsplit epilogue (round 6; null = none): per (image, output channel,
+    // pixel tile, wave) the fp32 sum and sum of squares of the wave's 64 finished values, tile_part[(((n * Cout + co) * tiles
+    // + tile) * 4 + wave) * 2 + {0, 1}]; gn_moments_from_tiles_kernel adds them in fp64 in index order.  The GroupNorm
+    // that reads y next then needs no pass over y for its statistics (it was gn_moments_kernel: one full read of y).
+    float *tile_part;
     int prio;                    // 1: the co-resident workgroups alternate their wave priority stage by stage
 #ifdef MVIP_EXPERIMENT_CONV
     int dbg;                     // timing experiments (MVIP_CONV_DBG): 1 = no epilogue, 2 = no MFMAs, 4 = no input DMA, 8 = no weight DMA, 16 = no barrier, 32 = linear B reads
@@ -748,20 +753,58 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? (MT <= 2 ? 2 : 1) : (MT <=
                 bv[m][r] = hb ? a.bias[co] : 0.f;
                 cv[m][r] = hc ? a.chan_add[(int64_t)n_out * a.Cout + co] : 0.f;
             }
+        bool with_moments = false;
+        if constexpr (TW != 8 && NW == 4) with_moments = a.tile_part != nullptr;
+        if (!with_moments) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int co;
-                    const int64_t o = out_index(m, j, r, co);
-                    float v = acc[m][j][r] * inv;
-                    if (hb) v += bv[m][r];
-                    if (hc) v += cv[m][r];
-                    if (hr) v += rv[m][j][r];
-                    a.y[o] = v;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        int co;
+                        const int64_t o = out_index(m, j, r, co);
+                        float v = acc[m][j][r] * inv;
+                        if (hb) v += bv[m][r];
+                        if (hc) v += cv[m][r];
+                        if (hr) v += rv[m][j][r];
+                        a.y[o] = v;
+                    }
+        }
+        if constexpr (TW != 8 && NW == 4) {
+            if (with_moments) {
+                // The same stores, channel by channel (both pixels of a register pair finished together), and the channel's
+                // moment partial right behind them.  Register r of lane (l32, kg) holds output channel 8 (r >> 2) + 4 kg + (r & 3)
+                // of row tile m at the two pixels (j = 0, 1) of column l32: the channel's sum over the wave's 64 pixels = the two
+                // values added, then the total over the 32 lanes of the half-wave -- four row_shr steps (lane 15 of each 16-lane
+                // row = the row's total) and one row_bcast:15 into rows 1 and 3 (lanes 31 / 63 = the half-waves' totals).  Five
+                // DPP adds per statistic and channel on the VALU, under the co-resident workgroup's MFMAs; no LDS, no barrier.
+                const int tiles = a.tilesX * a.tilesY, tile_lin = ty * a.tilesX + tx;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co;
+                        const int64_t o0 = out_index(m, 0, r, co), o1 = out_index(m, 1, r, co);
+                        float v0 = acc[m][0][r] * inv, v1 = acc[m][1][r] * inv;
+                        if (hb) { v0 += bv[m][r]; v1 += bv[m][r]; }
+                        if (hc) { v0 += cv[m][r]; v1 += cv[m][r]; }
+                        if (hr) { v0 += rv[m][0][r]; v1 += rv[m][1][r]; }
+                        a.y[o0] = v0;
+                        a.y[o1] = v1;
+                        float sm = v0 + v1, q = v0 * v0 + v1 * v1;
+                        sm += dpp_f32<0x111>(0.f, sm); q += dpp_f32<0x111>(0.f, q);
+                        sm += dpp_f32<0x112>(0.f, sm); q += dpp_f32<0x112>(0.f, q);
+                        sm += dpp_f32<0x114>(0.f, sm); q += dpp_f32<0x114>(0.f, q);
+                        sm += dpp_f32<0x118>(0.f, sm); q += dpp_f32<0x118>(0.f, q);
+                        sm += dpp_f32<0x142, 0xa>(0.f, sm); q += dpp_f32<0x142, 0xa>(0.f, q);
+                        if (l32 == 31) {
+                            float2 *dst = reinterpret_cast<float2 *>(a.tile_part) + (((int64_t)n_out * a.Cout + co) * tiles + tile_lin) * 4 + wave;
+                            *dst = make_float2(sm, q);
+                        }
+                    }
+            }
+        }
     }
 #ifdef MVIP_EXPERIMENT_CONV
     if (a.probe && tid == 0) {
@@ -864,6 +907,26 @@ cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, in
         q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
     if (lr == LPR - 1) { moments[row * 2] = sm; moments[row * 2 + 1] = q; }
+}
+
+// GroupNorm moments of a convolution output from the tile partials its unsplit epilogue left (ConvArgs::tile_part): one wave per
+// (image, channel) row adds the row's `parts` (sum, sum of squares) pairs in fp64 -- lane-strided, then the xor tree: a fixed
+// order, bit-reproducible -- and writes them in the layout gn_moments_kernel leaves for this row length (`chunks` pairs per row:
+// the total in the first, zeros in the rest), which is what cv_to_split_kernel<GN> and gn_finalize_kernel read.
+__global__ void __launch_bounds__(256)
+gn_moments_from_tiles_kernel(const float2 *__restrict__ part, int parts, int64_t rows, int chunks, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float2 *p = part + row * parts;
+    double sm = 0.0, q = 0.0;
+    for (int i = lane; i < parts; i += 64) { const float2 t = p[i]; sm += (double)t.x; q += (double)t.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane < chunks) {
+        out[(row * chunks + lane) * 2] = lane == 0 ? sm : 0.0;
+        out[(row * chunks + lane) * 2 + 1] = lane == 0 ? q : 0.0;
+    }
 }
 
 // The same reduction whose result leaves as split planes [N][M/16][2][2][P][8 halves] * out_scale (an operand sink behind a
@@ -1778,7 +1841,7 @@ extern "C" int64_t mvip_conv3x3_workspace_bytes(int64_t N, int64_t Cin, int64_t 
 static int conv3x3_launch(const void *xs, const void *packed, const float *bias, const float *chan_add,
                           const float *residual, const float *x_scale2, int64_t N, int64_t Cin, int64_t Cout,
                           int64_t H, int64_t W, float *y, void *workspace, int prec, void *stream,
-                          double *row_moments = nullptr) {
+                          double *row_moments = nullptr, float *tile_part = nullptr) {
     if (N < 0 || !mvip_conv3x3_supported(Cout, Cin, H, W) || prec < 0 || prec > 2) return MVIP_EINVAL;
     if (N == 0) return MVIP_OK;
     if (!xs || !packed || !y) return MVIP_EINVAL;
@@ -1794,7 +1857,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     a.N = (int)N; a.CK = (int)(Cin / 16); a.Cout = (int)Cout; a.H = (int)H; a.W = (int)W;
     a.tilesX = (int)(W / tw); a.tilesY = (int)(H / th); a.MB = (int)(Cout / (32 * MT));
     if (tw == 8) { a.tilesX = 1; a.tilesY = 1; }
-    a.splits = 1; a.cks = a.CK; a.partial = nullptr;
+    a.splits = 1; a.cks = a.CK; a.partial = nullptr; a.tile_part = nullptr;
     { static const int pr = [] { const char *e = getenv("MVIP_CONV_PRIO"); return e ? atoi(e) : 0; }(); a.prio = pr; }
 #ifdef MVIP_EXPERIMENT_CONV
     { const char *e = getenv("MVIP_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -1830,6 +1893,10 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     }
     blocks *= a.splits;
     if (blocks > 0x7fffffffLL) return MVIP_EINVAL;
+    if (tile_part) {                                           // callers ask mvip_conv3x3_tile_moments_scratch_bytes first
+        if (a.partial || tw == 8 || !row_moments) return MVIP_EINVAL;
+        a.tile_part = tile_part;
+    }
 #define MVIP_CV_LAUNCH(F16_)   /* F16_ = NP: products per step */                                                                                             \
     do {                                                                                                                      \
         if (tw == 8) hipLaunchKernelGGL((conv3x3_f16x3_kernel<1, 8, 4, F16_>), dim3((unsigned)blocks), dim3(256), 0, st, a);         \
@@ -1840,6 +1907,13 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     } while (0)
     if (prec == 1) MVIP_CV_LAUNCH(1); else if (prec == 2) MVIP_CV_LAUNCH(2); else MVIP_CV_LAUNCH(3);
 #undef MVIP_CV_LAUNCH
+    if (tile_part) {
+        const int64_t HW = H * W, rows = N * Cout;
+        const int chunks = (int)(mvip_groupnorm_workspace_bytes(1, 1, HW) / 16);
+        hipLaunchKernelGGL(gn_moments_from_tiles_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float2 *)tile_part,
+                           a.tilesX * a.tilesY * 4, rows, chunks, row_moments);
+        return check_launch();
+    }
     if (row_moments && !a.partial) return MVIP_EINVAL;         // callers ask mvip_conv3x3_row_moments_doubles first
     if (a.partial) {
         const int64_t total = N * Cout * H * W, HW = H * W;
@@ -1874,6 +1948,35 @@ extern "C" int mvip_conv3x3_f16x3_ws_moments(const void *xs, const void *packed,
     if (!workspace || !row_moments || mvip_conv3x3_row_moments_doubles(N, Cin, Cout, H, W) == 0) return MVIP_EINVAL;
     return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, workspace, prec, stream,
                           (double *)row_moments);
+}
+
+// Bytes of `tile_scratch` for mvip_conv3x3_f16x3_tile_moments, or 0 when this shape's launch cannot leave moment partials from
+// its epilogue: channel-split launches (they have mvip_conv3x3_f16x3_ws_moments), the 8 x 8 level, the eight-wave tiles.
+extern "C" int64_t mvip_conv3x3_tile_moments_scratch_bytes(int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W) {
+    if (N <= 0 || !mvip_conv3x3_supported(Cout, Cin, H, W)) return 0;
+    if (mvip_conv3x3_workspace_bytes(N, Cin, Cout, H, W) != 0) return 0;
+    static const int wide_mode = [] { const char *e = getenv("MVIP_CONV_WIDE"); return e ? atoi(e) : 0; }();
+    if (wide_mode) return 0;
+    int tw, MT;
+    int64_t blocks;
+    cv_geometry(N, Cout, H, W, tw, MT, blocks);
+    if (tw == 8) return 0;
+    const int th = 256 / tw;
+    return N * Cout * (W / tw) * (H / th) * 4 * 2 * (int64_t)sizeof(float);
+}
+
+// The unsplit convolution that ALSO leaves the GroupNorm moments of y (the statistics pass of the GroupNorm that reads y next:
+// norm2 after conv1, the next block's norm1 after conv2 -- the resnet chains of the VAE encoder and the UNet,
+// DS_NeRF/guidance/sd_utils.py:330-352, :390-403): moments = [N][Cout][chunks][2] fp64 in the layout of mvip_groupnorm_stats'
+// workspace (mvip_groupnorm_workspace_bytes(N, Cout, H * W) bytes), what mvip_groupnorm_split_planes_moments reads.  Two
+// launches (the convolution; a reduction of N * Cout rows of tile partials) instead of convolution + a full read of y.
+extern "C" int mvip_conv3x3_f16x3_tile_moments(const void *xs, const void *packed, const float *bias, const float *chan_add,
+                                               const float *residual, const float *x_scale2, int64_t N, int64_t Cin,
+                                               int64_t Cout, int64_t H, int64_t W, float *y, void *tile_scratch, void *moments,
+                                               int prec, void *stream) {
+    if (!tile_scratch || !moments || mvip_conv3x3_tile_moments_scratch_bytes(N, Cin, Cout, H, W) == 0) return MVIP_EINVAL;
+    return conv3x3_launch(xs, packed, bias, chan_add, residual, x_scale2, N, Cin, Cout, H, W, y, nullptr, prec, stream,
+                          (double *)moments, (float *)tile_scratch);
 }
 
 extern "C" int mvip_conv3x3_f16x3(const void *xs, const void *packed, const float *bias, const float *chan_add,

@@ -823,6 +823,7 @@ class _NormActConv3x3(torch.autograd.Function):
 # reads the moments directly).  One entry; the strong reference keeps the address from being reused.
 _LAST_Y = [None]
 ROW_MOMENTS = True             # A/B switch: False = every GroupNorm computes its moments from its input
+TILE_MOMENTS = _os.environ.get('MVIP_TILE_MOMENTS', '1') != '0'   # A/B switch: unsplit convolutions leave moment partials too (round 6)
 STATS_FROM_PLANE_WRITER = True # A/B switch: False = mean / rstd of a forward with grad come from gn_finalize (one launch more)
 
 
@@ -845,6 +846,17 @@ def _conv3x3_launch(xs, packed, bias, chan_add, residual, scale2, N, Cin, Cout, 
             rm = torch.empty(nd, device=y.device, dtype=torch.float64)
             call('mvip_conv3x3_f16x3_ws_moments', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
                  ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(ws), ptr(rm, torch.float64), _prec_w(packed), stream())
+            _LAST_Y[0] = (y, y._version, rm)
+            return
+    if moments and ROW_MOMENTS and TILE_MOMENTS and not nbytes:
+        # an unsplit launch: moment partials per (pixel tile, wave) from the epilogue + a small reduction (round 6), instead of
+        # the next GroupNorm's pass over y
+        sb = int(_lib.load().mvip_conv3x3_tile_moments_scratch_bytes(N, Cin, Cout, H, W))
+        if sb:
+            tp = torch.empty(sb // 4, device=y.device, dtype=torch.float32)
+            rm = torch.empty(int(_lib.load().mvip_groupnorm_workspace_bytes(N, Cout, H * W)) // 8, device=y.device, dtype=torch.float64)
+            call('mvip_conv3x3_f16x3_tile_moments', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),
+                 ptr(residual), ptr(scale2), N, Cin, Cout, H, W, ptr(y), ptr(tp), ptr(rm, torch.float64), _prec_w(packed), stream())
             _LAST_Y[0] = (y, y._version, rm)
             return
     call('mvip_conv3x3_f16x3_ws', ptr(xs, torch.float16), ptr(packed, torch.uint8), ptr(bias), ptr(chan_add),

@@ -468,6 +468,71 @@ def test_split_reduction_leaves_row_moments(cuda, N_, cin, cout, H, W):
     assert ops._row_moments_of(y1) is None
 
 
+@pytest.mark.parametrize('N_,cin,cout,H,W', [(1, 128, 128, 256, 256), (2, 320, 320, 64, 64), (1, 128, 256, 128, 128), (1, 64, 32, 128, 256),
+                                             (3, 128, 128, 128, 128)])
+def test_unsplit_convolution_leaves_moments_from_its_epilogue(cuda, N_, cin, cout, H, W):
+    """Round 6 (VERDICT r5 task 2): an UNSPLIT convolution leaves the GroupNorm moments of its output too
+    (mvip_conv3x3_f16x3_tile_moments: fp32 partials per pixel tile and wave from the epilogue -- five DPP adds per channel --
+    summed in fp64 by a small second launch): y bit-identical to the plain launch, the moments equal to mvip_groupnorm_stats'
+    partial sums of y at the accuracy of a 64-term fp32 sum (<= 4e-6 of sum |y| resp. sum y^2, mean offset included: the
+    residual carries one), and the next forward-only GroupNorm consumes them without a pass over y.  A channel-split shape keeps
+    its own route (scratch bytes = 0)."""
+    from mvip_nerf_amd import ops, _lib
+    from mvip_nerf_amd.ops import call, ptr, stream
+    from mvip_nerf_amd.guidance.sd_nets import GroupNorm, norm_act_conv
+    lib = _lib.load()
+    sb = int(lib.mvip_conv3x3_tile_moments_scratch_bytes(N_, cin, cout, H, W))
+    split = int(lib.mvip_conv3x3_workspace_bytes(N_, cin, cout, H, W)) > 0
+    assert (sb == 0) == split
+    if split:
+        assert (N_, H) == (2, 64)                          # the UNet's 64 x 64 level at 320 channels: 160 workgroups, channel-split
+        return
+    g = torch.Generator(device=cuda).manual_seed(cin + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(cuda)
+    x = torch.randn(N_, cin, H, W, device=cuda, generator=g)
+    rs = torch.randn(N_, cout, H, W, device=cuda, generator=g) * 2 + 1.5
+    ca = torch.randn(N_, cout, device=cuda, generator=g)
+    s2 = ops.absmax_scale(x)
+    xs = ops._split_buffer(N_, cin, H * W, cuda)
+    call('mvip_split_planes', ptr(x), N_, cin, H * W, ptr(s2), ptr(xs, torch.float16), 0, stream())
+    packed, bias = ops._conv_packed(conv, False), conv.bias.detach().contiguous()
+    y0, y1 = torch.empty(N_, cout, H, W, device=cuda), torch.empty(N_, cout, H, W, device=cuda)
+    ops._conv3x3_launch(xs, packed, bias, ca, rs, s2, N_, cin, cout, H, W, y0)
+    ops._LAST_Y[0] = None
+    ops._conv3x3_launch(xs, packed, bias, ca, rs, s2, N_, cin, cout, H, W, y1, moments=True)
+    assert torch.equal(y0, y1)
+    assert ops._LAST_Y[0] is not None and ops._LAST_Y[0][0] is y1
+    rm = ops._LAST_Y[0][2]
+    ws = ops._gn_workspace(N_, cout, H * W, cuda)
+    assert ws.numel() == rm.numel()
+    chunks = rm.numel() // (N_ * cout * 2)
+    got = rm.reshape(N_ * cout, chunks, 2).sum(1).cpu().numpy()
+    yd = y1.double().reshape(N_ * cout, -1)
+    want = torch.stack([yd.sum(1), (yd * yd).sum(1)], 1).cpu().numpy()
+    scale = torch.stack([yd.abs().sum(1), (yd * yd).sum(1)], 1).cpu().numpy()
+    assert np.abs(got - want).max() <= 4e-6 * scale.max() and (np.abs(got - want) <= 4e-6 * scale).all()
+    assert float(rm.reshape(N_ * cout, chunks, 2)[:, 1:].abs().max()) == 0.0 if chunks > 1 else True
+    norm = GroupNorm(32, cout).to(cuda)
+    conv2 = torch.nn.Conv2d(cout, 64, 3, padding=1).to(cuda)
+    for p in list(norm.parameters()) + list(conv2.parameters()):
+        p.requires_grad_(False)
+    calls = []
+    orig = ops.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    ops.call = counting
+    try:
+        with torch.no_grad():
+            z1 = norm_act_conv(norm, conv2, y1)
+            z0 = norm_act_conv(norm, conv2, y0)            # nothing registered for y0: the ordinary path
+    finally:
+        ops.call = orig
+    assert calls.count('mvip_groupnorm_stats') == 1 and calls.count('mvip_groupnorm_split_planes_moments') == 2
+    np.testing.assert_allclose(N(z1), N(z0), rtol=0, atol=2e-6 * float(z0.abs().max()))
+
+
 def test_groupnorm_planes_from_moment_partials(cuda):
     """mvip_groupnorm_split_planes_moments (statistics reduced inside the plane writer) writes the same bytes as
     mvip_groupnorm_stats + mvip_groupnorm_split_planes, for group sizes that do and do not divide 16."""

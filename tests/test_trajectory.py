@@ -114,6 +114,8 @@ def test_hundred_iterations_follow_the_reference_trajectory(cuda, mode, precisio
     want = g[f'{mode}/losses']
     np.testing.assert_allclose(lrs, g[f'{mode}/lrs'], rtol=1e-12)
     rel = np.abs(losses - want) / np.abs(want)
+    if os.environ.get('MVIP_TRAJECTORY_DUMP'):               # calibration runs: the whole curve, one file per run
+        np.save(os.path.join(os.environ['MVIP_TRAJECTORY_DUMP'], f'traj_{mode}_{precision}_{os.getpid()}.npy'), losses)
     # the reference against itself (1 BLAS thread vs 8) on THIS trajectory: the amplification any implementation
     # sees; cumulative maximum so the bound never tightens after a divergence has happened
     self_rel = np.abs(g[f'{mode}_1thread/losses'] - g[f'{mode}/losses']) / np.abs(g[f'{mode}/losses'])

@@ -10,7 +10,8 @@
 #  (5) one SDS step per kernel + hipGraph replay, fp32 networks and --fp16  -> r6_sds_step_f32.json, r6_sds_step_fp16.json
 #  (6) isolated HBM-bound stage kernels                                      -> r6_micro_hbm_kernels.jsonl
 #  (7) configs[2] / configs[3] iterations per kernel                         -> r6_config2_step_kernels.json, r6_config3_step_kernels.json
-#  (8) the round's A/B on the final build: LayerNorm statistics from the GEMM epilogue on / off -> r6_ln_stats_ab.json
+#  (8) the round's A/B on the final build: LayerNorm statistics from the GEMM epilogue x GroupNorm moments from the
+#      unsplit convolution's epilogue, each on / off                        -> r6_sds_fusion_ab.json
 #      (the sample_pdf_merge experiment's A/B and PMC view were taken on commit dbca558, which holds the experiment's code:
 #       profiles/r6_sample_merge_ab.jsonl, profiles/r6_pmc_stage_kernels.json)
 # PMC runs are their own processes with --kernel-trace only (never combined with --stats / sys-trace), with the SDS steps launched
@@ -60,7 +61,7 @@ python3 tools/sds_step_profile.py --fp16 --graphs --out=r6_sds_step_fp16.json > 
 python3 tools/micro_bench.py 2>/dev/null | grep '^{' > gpurun_out/r6_micro_hbm_kernels.jsonl
 python3 tools/config_step_profile.py 2 > gpurun_out/r6_config2.txt 2>&1
 python3 tools/config_step_profile.py 3 > gpurun_out/r6_config3.txt 2>&1
-python3 tools/ln_stats_ab.py > gpurun_out/r6_ln_stats_ab.txt 2>&1
+python3 tools/sds_fusion_ab.py > gpurun_out/r6_sds_fusion_ab.txt 2>&1
 # ---- stamp: the commit goes INTO every JSON (a list becomes {"head", "rows"}), and next to the CSV / text files ----
 MVIP_HEAD=$HEAD python3 - <<'P'
 import glob, json, os

@@ -1,7 +1,8 @@
-"""A/B of the SDS step with the LayerNorm statistics left by the producing GEMM's epilogue (round 6, ops.LN_STATS_FROM_GEMM,
-MVIP_LN_STATS_FROM_GEMM=1, the default) against the two-launch LayerNorm: median of 15 steps, hipGraph replay and eager, launch
-count of one eager step, each setting in its own child process, two rounds.
-    python tools/ln_stats_ab.py -> gpurun_out/r6_ln_stats_ab.json"""
+"""A/B of the SDS step with round 6's two statistics fusions, each on / off: LayerNorm statistics left by the producing GEMM's
+epilogue (ops.LN_STATS_FROM_GEMM, MVIP_LN_STATS_FROM_GEMM) and GroupNorm moments left by the unsplit convolution's epilogue
+(ops.TILE_MOMENTS, MVIP_TILE_MOMENTS); both default to on.  Median of 15 steps, hipGraph replay and eager, kernel launches of
+one eager step, each setting in its own child process, two rounds.
+    python tools/sds_fusion_ab.py -> gpurun_out/r6_sds_fusion_ab.json"""
 import json
 import os
 import subprocess
@@ -56,14 +57,15 @@ def child():
 def main():
     res = {'what': __doc__.split('\n')[0]}
     for rnd in range(2):
-        for two in ('1', '0'):
+        for ln, tile in (('1', '1'), ('0', '1'), ('1', '0'), ('0', '0')):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child'], capture_output=True, text=True,
-                               env=dict(os.environ, MVIP_LN_STATS_FROM_GEMM=two), cwd=ROOT)
+                               env=dict(os.environ, MVIP_LN_STATS_FROM_GEMM=ln, MVIP_TILE_MOMENTS=tile), cwd=ROOT)
             line = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')]
-            res[f'ln_stats_from_gemm={two}_round{rnd}'] = json.loads(line[-1][7:]) if line else {'error': r.stderr[-1500:]}
-            print(two, rnd, res[f'ln_stats_from_gemm={two}_round{rnd}'], flush=True)
+            key = f'ln_stats_from_gemm={ln},tile_moments={tile},round{rnd}'
+            res[key] = json.loads(line[-1][7:]) if line else {'error': r.stderr[-1500:]}
+            print(key, res[key], flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r6_ln_stats_ab.json'), 'w'), indent=1)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'r6_sds_fusion_ab.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
