@@ -468,7 +468,7 @@ def test_split_reduction_leaves_row_moments(cuda, N_, cin, cout, H, W):
     assert ops._row_moments_of(y1) is None
 
 
-@pytest.mark.parametrize('N_,cin,cout,H,W', [(1, 128, 128, 256, 256), (2, 320, 320, 64, 64), (1, 128, 256, 128, 128), (1, 64, 32, 128, 256),
+@pytest.mark.parametrize('N_,cin,cout,H,W', [(1, 128, 128, 256, 256), (2, 320, 320, 64, 64), (1, 128, 256, 128, 128), (1, 64, 128, 128, 256),
                                              (3, 128, 128, 128, 128)])
 def test_unsplit_convolution_leaves_moments_from_its_epilogue(cuda, N_, cin, cout, H, W):
     """Round 6 (VERDICT r5 task 2): an UNSPLIT convolution leaves the GroupNorm moments of its output too
