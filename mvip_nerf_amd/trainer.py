@@ -248,8 +248,10 @@ class SecondStageTrainer:
             rays_c, target_clf, _ = sc.next_batch('rays_rgb_clf', self.N_rand, None if records is None else records[0])
             rays_d, _, target_inp = sc.next_batch('rays_inp', self.N_rand, None if records is None else records[1])
             n_clf, n_inp = rays_c.shape[1], rays_d.shape[1]
+            # (min: a batch with fewer rays than ranks leaves the last ranks an EMPTY shard -- torch.arange refuses start > end;
+            #  found by tests/test_distributed_gpu.py::test_eight_ranks_issue_one_collective_sequence)
             take = lambda t, dim: t if self.world == 1 else t.index_select(
-                dim, torch.arange(self.rank, t.shape[dim], self.world, device=t.device))
+                dim, torch.arange(min(self.rank, t.shape[dim]), t.shape[dim], self.world, device=t.device))
             rays_c, target_clf = take(rays_c, 1), take(target_clf, 0)
             rays_d, target_inp = take(rays_d, 1), take(target_inp, 0)
             r2 = self._render_records(rays_c, retraw=True, **self.kw_train)
