@@ -50,4 +50,4 @@ for e in ev[:28]:
     rows.append([round(e.device_time_total / 1e3, 3), e.count, e.key[:120]])
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump({'config': cfg, 'wall_ms': ts, 'device_busy_ms': busy, 'sd_network_kernels_ms': sds, 'top': rows},
-          open(f'gpurun_out/r5_config{cfg}_step_kernels.json', 'w'), indent=1)
+          open(f"gpurun_out/{os.environ.get('MVIP_ROUND', 'r6')}_config{cfg}_step_kernels.json", 'w'), indent=1)

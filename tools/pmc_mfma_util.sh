@@ -1,6 +1,6 @@
 # Matrix-pipe utilisation per kernel, SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128), in THREE bounded counter passes --
 # the render legs of bench.py, the training iteration (tools/train_speed.py) and eager SDS steps (tools/sds_profile_steps.py) --
-# merged into gpurun_out/r5_pmc_mfma_util.json.  Round 5: the one-pass form (the whole bench under --pmc) took rocprofv3 down
+# merged into gpurun_out/${MVIP_ROUND:-r6}_pmc_mfma_util.json.  Round 5: the one-pass form (the whole bench under --pmc) took rocprofv3 down
 # twice (a SIGSEGV inside the tool, then "AQL packet is malformed" followed by a hang until the timeout), so each leg is its
 # own process with a hard KILL timeout; the three commands are recorded in the output.
 #   gpurun -- "MVIP_HEAD=$(git rev-parse HEAD) bash tools/pmc_mfma_util.sh"
@@ -33,7 +33,7 @@ for name, cmd in cmds.items():
         rows = sorted(rows, key=lambda r: -r['total_ms'])[:40]
     out['passes'][name] = {'command': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- ' + cmd,
                            'rows': rows}
-json.dump(out, open('gpurun_out/r5_pmc_mfma_util.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/' + os.environ.get('MVIP_ROUND', 'r6') + '_pmc_mfma_util.json', 'w'), indent=1)
 for name, p in out['passes'].items():
     print(name, 'MISSING' if p['rows'] is None else '')
     for r in (p['rows'] or [])[:8]:
