@@ -909,23 +909,35 @@ cv_split_reduce_moments_kernel(const float *__restrict__ partial, int splits, in
     if (lr == LPR - 1) { moments[row * 2] = sm; moments[row * 2 + 1] = q; }
 }
 
-// GroupNorm moments of a convolution output from the tile partials its unsplit epilogue left (ConvArgs::tile_part): one wave per
-// (image, channel) row adds the row's `parts` (sum, sum of squares) pairs in fp64 -- lane-strided, then the xor tree: a fixed
-// order, bit-reproducible -- and writes them in the layout gn_moments_kernel leaves for this row length (`chunks` pairs per row:
-// the total in the first, zeros in the rest), which is what cv_to_split_kernel<GN> and gn_finalize_kernel read.
+// GroupNorm moments of a convolution output from the tile partials its unsplit epilogue left (ConvArgs::tile_part): the
+// (image, channel) row's `parts` (sum, sum of squares) pairs added in fp64 and written in the layout gn_moments_kernel leaves
+// for this row length (`chunks` pairs per row: the total in the first, zeros in the rest), which is what
+// cv_to_split_kernel<GN> and gn_finalize_kernel read.
 __global__ void __launch_bounds__(256)
 gn_moments_from_tiles_kernel(const float2 *__restrict__ part, int parts, int64_t rows, int chunks, double *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    // one WORKGROUP per row (the first version -- one wave per row, one load in flight per lane -- took 17.6 us per launch at
+    // 4,096 partials per row: as long as the pass over y it replaces): thread t adds partials t, t + 256, ... four at a time,
+    // then the xor tree inside each wave and the four waves in index order -- a fixed order, bit-reproducible
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
     const float2 *p = part + row * parts;
     double sm = 0.0, q = 0.0;
-    for (int i = lane; i < parts; i += 64) { const float2 t = p[i]; sm += (double)t.x; q += (double)t.y; }
+    int i = threadIdx.x;
+    for (; i + 768 < parts; i += 1024) {
+        const float2 t0 = p[i], t1 = p[i + 256], t2 = p[i + 512], t3 = p[i + 768];
+        sm += ((double)t0.x + (double)t1.x) + ((double)t2.x + (double)t3.x);
+        q += ((double)t0.y + (double)t1.y) + ((double)t2.y + (double)t3.y);
+    }
+    for (; i < parts; i += 256) { const float2 t = p[i]; sm += (double)t.x; q += (double)t.y; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
-    if (lane < chunks) {
-        out[(row * chunks + lane) * 2] = lane == 0 ? sm : 0.0;
-        out[(row * chunks + lane) * 2 + 1] = lane == 0 ? q : 0.0;
+    if (lane == 0) { red[0][wave] = sm; red[1][wave] = q; }
+    __syncthreads();
+    if (threadIdx.x < chunks) {
+        const double ts = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], tq = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        out[(row * chunks + threadIdx.x) * 2] = threadIdx.x == 0 ? ts : 0.0;
+        out[(row * chunks + threadIdx.x) * 2 + 1] = threadIdx.x == 0 ? tq : 0.0;
     }
 }
 
@@ -1910,7 +1922,7 @@ static int conv3x3_launch(const void *xs, const void *packed, const float *bias,
     if (tile_part) {
         const int64_t HW = H * W, rows = N * Cout;
         const int chunks = (int)(mvip_groupnorm_workspace_bytes(1, 1, HW) / 16);
-        hipLaunchKernelGGL(gn_moments_from_tiles_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float2 *)tile_part,
+        hipLaunchKernelGGL(gn_moments_from_tiles_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const float2 *)tile_part,
                            a.tilesX * a.tilesY * 4, rows, chunks, row_moments);
         return check_launch();
     }
