@@ -166,7 +166,7 @@ def kernel_roofline(run_mod, nets, device, reps=3):
     points = rows.shape[0] * (N_SAMPLES + N_IMPORTANCE)
     tflops = points * FLOP_PER_POINT / (ms * 1e-3) / 1e12
     traffic, src = None, None
-    for name in ('r5_pmc_mlp_forward.json', 'r4_pmc_mlp_forward.json', 'r3_pmc_mlp_forward.json', 'r2_pmc_mlp_forward.json'):     # separate --pmc passes of this launch, newest first
+    for name in ('r6_pmc_mlp_forward.json', 'r5_pmc_mlp_forward.json', 'r4_pmc_mlp_forward.json', 'r3_pmc_mlp_forward.json', 'r2_pmc_mlp_forward.json'):     # separate --pmc passes of this launch, newest first
         pmc = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
