@@ -228,6 +228,33 @@ def test_scaling_model_predictions():
     bench.add_scaling_prediction(line, 1)
     assert sorted(line['multi_gpu']['predicted']['N']) == [2, 4, 8]
     json.dumps(line)
+    # round 6 (VERDICT r5 tasks 1 / 6): legs in both arithmetics -> two predictions, each on its own legs; the SDS step enters
+    # in the mode the multi-rank legs will run it in (eager unless MVIP_GRAPHS_WITH_DIST=1), while the terms subtracted from
+    # the ONE-GPU config legs are the graph replays those legs ran
+    line = {'ms_per_step': 300.0, 'train': {'ms_per_step': 54.0}, 'train_f16x3': {'ms_per_step': 30.0}, 'render_f16x3': {'ms_per_step': 90.0},
+            'sds': {'ms_per_step': 21.0, 'ms_per_step_eager': 22.5},
+            'config2_rgb_normal_sds': {'ms_per_step': 280.0, 'f32': {'ms_per_step': 280.0}, 'f16x3': {'ms_per_step': 150.0}},
+            'config3_rgb_normal_colla_sds': {'ms_per_step': 850.0, 'f32': {'ms_per_step': 850.0}, 'f16x3': {'ms_per_step': 400.0}}}
+    old_env = os.environ.pop('MVIP_GRAPHS_WITH_DIST', None)
+    try:
+        bench.add_scaling_prediction(line, 1)
+        pf, ps = line['multi_gpu']['predicted'], line['multi_gpu']['predicted_f16x3']
+        assert pf['inputs']['sds_ms'] == 22.5 and pf['inputs']['sds_one_gpu_ms'] == 21.0 and 'eager' in pf['sds_mode']
+        assert pf['inputs']['config2_ms'] == 280.0 and ps['inputs']['config2_ms'] == 150.0 and ps['inputs']['frame_ms'] == 90.0
+        assert pf['N'][8]['config3_ms'] > ps['N'][8]['config3_ms'] > 0 and 'f32' in pf['dtype'] and 'f16x3' in ps['dtype']
+        # the NeRF part isolated from a one-GPU leg does not depend on the multi-rank mode of the step
+        direct = sm.predict({'frame_ms': 300.0, 'train_ms': 54.0, 'sds_ms': 21.0, 'config2_ms': 280.0, 'config3_ms': 850.0})
+        assert pf['N'][8]['config2_ms'] > direct['N'][8]['config2_ms']           # eager terms on the critical path: slower than replays
+        os.environ['MVIP_GRAPHS_WITH_DIST'] = '1'
+        line.pop('multi_gpu')
+        bench.add_scaling_prediction(line, 1)
+        assert line['multi_gpu']['predicted']['inputs']['sds_ms'] == 21.0 and 'replay' in line['multi_gpu']['predicted']['sds_mode']
+        assert abs(line['multi_gpu']['predicted']['N'][8]['config2_ms'] - direct['N'][8]['config2_ms']) < 1e-9
+    finally:
+        os.environ.pop('MVIP_GRAPHS_WITH_DIST', None)
+        if old_env is not None:
+            os.environ['MVIP_GRAPHS_WITH_DIST'] = old_env
+    json.dumps(line)
 
 
 def test_sd_checkpoint_manifest_and_strict_loading(tmp_path):
