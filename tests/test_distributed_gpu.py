@@ -350,3 +350,13 @@ def test_bench_two_ranks_on_one_device_reports_strong_scaling(cuda):
     assert d['ranks_share_one_device'] is True and d['strong_efficiency'] is None
     assert d['multi_gpu']['rccl_world'] == 2
     assert d['metric'].startswith('rays_per_sec') and d['unit'] == 'rays/s'
+    # round 6 (VERDICT r5 task 1): every leg says which arithmetic it ran in; configs[2] / [3] carry BOTH, the f32 one on top
+    assert d['dtype'] == 'f32'
+    for leg in ('train', 'train_f16x3', 'train_with_sds', 'train_with_sds_f16x3', 'render_f16x3', 'sds'):
+        assert 'dtype' in d[leg], leg
+    for leg in ('config2_rgb_normal_sds', 'config3_rgb_normal_colla_sds'):
+        assert d[leg]['f32']['dtype'].startswith('f32') and d[leg]['f16x3']['dtype'].startswith('f16x3')
+        assert d[leg]['ms_per_step'] == d[leg]['f32']['ms_per_step'] and d[leg]['dtype'] == d[leg]['f32']['dtype']
+        assert d[leg]['f16x3']['ms_per_step'] < d[leg]['f32']['ms_per_step']
+    mg = d['multi_gpu']
+    assert 'f32' in mg['predicted']['dtype'] and 'f16x3' in mg['predicted_f16x3']['dtype'] and 'sds_mode' in mg['predicted']
