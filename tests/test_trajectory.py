@@ -136,7 +136,7 @@ def test_hundred_iterations_follow_the_reference_trajectory(cuda, mode, precisio
     print(f'[{mode}/precision {precision}] held-out PSNR {psnr:.4f} dB, reference {p_ref:.4f} dB (reference vs itself: {p_self:.4f} dB)')
     assert abs(psnr - p_ref) < max(0.05, 2.0 * p_self), (psnr, p_ref, p_self)
     # pixels: the two renders of independently trained weights agree far better than either agrees with the photograph
-    ref_rgb = torch.from_numpy(g[f'{mode}/heldout_rgb_every3'])
+    ref_rgb = torch.from_numpy(g[f'{mode}/heldout_rgb_every3'].astype(np.float32))
     assert float(-10 * torch.log10(((rgb[::3] - ref_rgb) ** 2).mean())) > psnr + 15.0
     # the SAME (HIP-trained) weights through the CPU oracle: the clause as a same-weights comparison, on every 7th pixel
     H, W, focal, near, far, pose = cam
