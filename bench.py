@@ -762,6 +762,7 @@ def main():
                 t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
+            full = None                                     # (its networks, optimizer state and cached buffers: not this leg's)
             # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
             # collaborative SDS over <=5 neighbour views), EACH IN BOTH ARITHMETICS of the NeRF kernels: "f32" = the package
             # default (train_precision = inference_precision = 0, exact fp32 MFMA; what every config-level test runs and
@@ -773,10 +774,20 @@ def main():
                 a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
                 opt.is_normal_guidance, opt.is_colla_guidance, opt.normal_start = True, colla, 500
                 opt.text_normal = 'a normal map of a stone bench in a park'
-                tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
-                                         rank=rank, dist=dist)
                 legs = {}
                 for mode, prec in (('f32', 0), ('f16x3', 1)):
+                    # a trainer and an allocator pool of its own per leg: the legs must not time each other's leftovers.  (These legs
+                    # still read ~7 ms above the same iteration in a fresh process -- tools/config_step_profile.py, same box: 144.6 vs
+                    # 152 ms for configs[2] f16x3 -- in both arithmetics; one contributor was found and removed
+                    # (guidance/sd_utils._OffDefaultStream, mvip_nerf_amd/streams.py), the rest is not isolated: DESIGN.md 0b.)
+                    tr2 = None
+                    torch.cuda.empty_cache()
+                    if os.environ.get('MVIP_BENCH_PER_STEP') == '1':
+                        fr, tot = torch.cuda.mem_get_info(device)
+                        print(f'[bench] before {name} {mode}: allocated {torch.cuda.memory_allocated(device) / 2**30:.1f} GiB, reserved '
+                              f'{torch.cuda.memory_reserved(device) / 2**30:.1f} GiB, driver-free {fr / 2**30:.1f} of {tot / 2**30:.1f} GiB', file=sys.stderr)
+                    tr2 = SecondStageTrainer(a2, scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}), world=world,
+                                             rank=rank, dist=dist)
                     for n in (tr2.kw_train['network_fn'], tr2.kw_train['network_fine']):
                         n.train_precision = n.inference_precision = prec
                     tr2.step(999)
@@ -784,10 +795,25 @@ def main():
                     barrier()
                     t5 = time.perf_counter()
                     rays = 0
+                    _per = []
                     for k in range(nsteps):
+                        _t = time.perf_counter()
                         rays += tr2.step(1001 + k)[1]
+                        if os.environ.get('MVIP_BENCH_PER_STEP') == '1':        # diagnostic: per-step wall times (adds a sync per step)
+                            torch.cuda.synchronize()
+                            _per.append(round((time.perf_counter() - _t) * 1e3, 1))
                     barrier()
                     dt5 = time.perf_counter() - t5
+                    if _per:
+                        print(f'[bench] {name} {mode} per-step ms {_per}', file=sys.stderr)
+                    if os.environ.get('MVIP_BENCH_PROFILE_LEG') == f'{name}:{mode}':     # diagnostic: one step of this leg per kernel
+                        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                            tr2.step(1100)
+                            torch.cuda.synchronize()
+                        ev = sorted([e for e in prof.key_averages() if e.device_time_total > 0], key=lambda e: -e.device_time_total)
+                        print(f'[bench] {name} {mode}: device-busy {sum(e.device_time_total for e in ev) / 1e3:.1f} ms, {sum(e.count for e in ev)} launches', file=sys.stderr)
+                        for e in ev[:16]:
+                            print(f'[bench]   {e.device_time_total / 1e3:8.3f} ms x{e.count:4d}  {e.key[:100]}', file=sys.stderr)
                     if dist is not None:
                         t = torch.tensor([dt5], device=device, dtype=torch.float64)
                         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -153,6 +153,48 @@ class _NoiseFeed:
             b.normal_(generator=generator)
 
 
+class _OffDefaultStream:
+    """Captured SDS steps never capture or replay on the device's DEFAULT stream: a caller that is on it hops onto a pool
+    stream for the duration of the step (the default stream waits for it afterwards).  Why (round 6, same-box experiments,
+    DESIGN.md 0b): once ONE captured step had been captured / replayed from the default stream, the replays of two LATER graphs
+    on two other streams no longer overlapped for the rest of the process -- the BASELINE configs[2] iteration took 149.3 ms
+    instead of 142.5, whatever was released afterwards and with 4 or 8 hardware queues -- while the same earlier step issued
+    from a pool stream left the later concurrency intact (142.7 ms).  That is exactly what a configs[2] / configs[3] training run
+    does: iterations up to `normal_start` evaluate ONE term in line (default stream), every later one two or three terms on
+    streams of their own (nerf/utils.Pretrain_Model.cal_loss).  Cost: +0.4 ms on a single-term step (21.3 -> 21.7 ms: the stream
+    hand-over); MVIP_SDS_OFF_DEFAULT_STREAM=0 switches the hop off (A/B)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.hop = None
+
+    def __enter__(self):
+        import os
+        if self.device.type != 'cuda' or os.environ.get('MVIP_SDS_OFF_DEFAULT_STREAM', '1') == '0':      # A/B switch
+            return self
+        self.cur = torch.cuda.current_stream(self.device)
+        if self.cur.cuda_stream == torch.cuda.default_stream(self.device).cuda_stream:
+            from .. import streams as _streams
+            self.hop = _streams.get(self.device, 'term', 0)
+            self.hop.wait_stream(self.cur)
+            self._ctx = torch.cuda.stream(self.hop)
+            self._ctx.__enter__()
+        return self
+
+    def keep(self, *tensors):
+        """Results made on the hop stream and read by the caller's stream afterwards."""
+        if self.hop is not None:
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.cur)
+
+    def __exit__(self, *exc):
+        if self.hop is not None:
+            self._ctx.__exit__(*exc)
+            self.cur.wait_stream(self.hop)
+        return False
+
+
 class _GraphedStep:
     """The whole single-view SDS step -- resize, masking, two VAE encodes, add_noise, UNet (CFG batch),
     SDS gradient, and the backward through the VAE encoder to the image -- captured once as a hipGraph.
@@ -184,7 +226,8 @@ class _GraphedStep:
         from .. import ops as _ops
         scope_before, _ops.ZERO_SCOPE = _ops.ZERO_SCOPE, ('graph', id(self))
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        from .. import streams as _streams
+        side = _streams.get(dev, 'capture')                     # one warm-up stream per process, not one per captured graph (streams.py)
         side.wait_stream(cur)
         self.noise = _NoiseFeed()                               # first warm-up run: records what the step draws
         sd._noise_feed = self.noise
@@ -334,6 +377,18 @@ class StableDiffusion(nn.Module):
         self._graphs = {}
         self.scaling_factor = float(getattr(getattr(self.vae, 'config', None), 'scaling_factor', 0.18215))
 
+    def release_graphs(self):
+        """Drop every captured step (and the private memory pool each one holds: the activations of a UNet forward and of the
+        VAE encoder's forward + backward at 512^2, GBs per graph).  Graphs are keyed by (mode, shapes, prompt, scale, generator,
+        stream) and kept for the life of the object; a caller that moves on to other shapes / prompts / streams -- bench.py between
+        its legs -- returns the memory to the NeRF backward's activation stash, whose budget is a fraction of what is free
+        (ops._stash_budget).  The next step of a released key captures again."""
+        import gc
+        self._graphs.clear()
+        gc.collect()
+        if torch.device(self.device).type == 'cuda':
+            torch.cuda.empty_cache()
+
     # -- hooks (tests replay recorded draws through _randn) --------------------------------------
     generator = None      # optional torch.Generator (default: the device's global generator, like the reference)
 
@@ -414,7 +469,8 @@ class StableDiffusion(nn.Module):
         if os.environ.get('MVIP_SDS_TWO_STREAMS', '1') == '0':
             return None
         if self.__dict__.get('_side') is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            from .. import streams as _streams
+            self._side = _streams.get(self.device, 'encode')    # shared by every wrapper of the process (streams.py)
         return self._side
 
     def _noise_and_predict(self, init_image, mask64, masked_image_latents, prompt_embeds, cfg, t, guidance_scale,
@@ -449,7 +505,9 @@ class StableDiffusion(nn.Module):
         return self._graphs[key]
 
     def _graphed(self, t, mask, prompt, pred, guidance_scale):
-        d_pred = self._graph_for('single', mask, prompt, pred, guidance_scale).run(pred, mask, t)
+        with _OffDefaultStream(pred.device) as hop:
+            d_pred = self._graph_for('single', mask, prompt, pred, guidance_scale).run(pred, mask, t)
+            hop.keep(d_pred)
         return _InjectGrad.apply(pred, d_pred)
 
     # -- the three step methods ---------------------------------------------------------------------
@@ -488,12 +546,16 @@ class StableDiffusion(nn.Module):
             t = self._timestep(k / 10000)
             last = k == NN - 1
             if self.use_graphs:
-                g = self._graph_for('last' if last else 'share', mask_k, prompt, pred_k, guidance_scale)
+                with _OffDefaultStream(pred_k.device) as hop:
+                    g = self._graph_for('last' if last else 'share', mask_k, prompt, pred_k, guidance_scale)
+                    if last:
+                        d_pred, grad = g.run(pred_k, mask_k, t, grad)
+                        hop.keep(d_pred, grad)
+                    else:
+                        grad = g.run(pred_k, mask_k, t, grad)
+                        hop.keep(grad)
                 if last:
-                    d_pred, grad = g.run(pred_k, mask_k, t, grad)
                     loss = _InjectGrad.apply(pred_k, d_pred)
-                else:
-                    grad = g.run(pred_k, mask_k, t, grad)
                 continue
             # `loss` of a non-final view is overwritten before anything reads it, so no gradient ever flows through that view:
             # it runs without an autograd graph (same draws, same values; no saved activations)

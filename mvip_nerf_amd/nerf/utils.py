@@ -101,7 +101,7 @@ class Pretrain_Model(object):
             return None
         if torch.device(self.device).type != 'cuda':
             return None
-        pool = self.__dict__.setdefault('_streams', [])
-        while len(pool) < n:
-            pool.append(torch.cuda.Stream(device=self.device))
-        return pool[:n]
+        from .. import streams as _streams               # a process-wide pool: see streams.py (hardware queues are few)
+        pool = _streams.term_streams(self.device, n)
+        self.__dict__['_streams'] = pool
+        return pool
