@@ -716,70 +716,36 @@ def main():
             # the step as the product runs it by default: fp32 networks (split-precision MFMA kernels), ONE captured hipGraph
             # (StableDiffusion.use_graphs defaults to True for the built-in networks; thread-local capture, so a live RCCL
             # communicator's watchdog thread does not disturb it) -- and the same step launch by launch
-            n_sds = max(args.sds_steps, 3)
+            # ---- BASELINE configs[2] / configs[3] FIRST: their SDS terms replay on term streams, and a captured step that has been
+            #      replayed from the DEFAULT stream -- which is where the one-term legs below run, because that is faster for them --
+            #      would cost these legs' term streams their concurrency for the rest of the process (guidance/sd_utils._OffDefaultStream,
+            #      profiles/r6_stream_experiments.json: 152 instead of 144.6 ms for configs[2] f16x3, 280 instead of 273 in f32, when these
+            #      legs ran last; in this order every leg reads what the same iteration reads in a process of its own,
+            #      tools/config_step_profile.py).  A training run is one configuration; only this script is several.
+            import types
+            from mvip_nerf_amd.nerf.utils import Pretrain_Model
+            from mvip_nerf_amd.trainer import SecondStageTrainer, SyntheticScene
             graphs_ok = world == 1 or os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') == '1'    # eager next to a live multi-rank group unless asked
-            sds_times = timed_steps(sd, 1e-4, graphs_ok, n_sds)
-            dt_sds = float(np.median(sds_times)) * args.sds_steps
-            ms_eager32 = float(np.median(timed_steps(sd, 1e-4, False, n_sds))) * 1e3
-            # the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66) on the SAME hand-written kernels in their
-            # single-product instantiations (round 3; it used to fall onto MIOpen / CK / AOTriton kernels)
-            ms_graph16 = ms_eager16 = None
-            if world == 1:
-                try:
-                    sd16 = StableDiffusion(device, True, False)
-                    ms_graph16 = float(np.median(timed_steps(sd16, 1.0, True, n_sds))) * 1e3
-                    ms_eager16 = float(np.median(timed_steps(sd16, 1.0, False, n_sds))) * 1e3
-                    del sd16
-                except Exception as e:                            # reported, never fatal for the bench line
-                    print(f'[bench] fp16-mode leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
-                torch.cuda.empty_cache()
             sd.use_graphs = graphs_ok
             opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
                                         text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
                                         colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
                                         lambda_guidance=1)
             scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
-            full = SecondStageTrainer(make_args(), scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}),
-                                      world=world, rank=rank, dist=dist)
-            full.step(999)                 # two untimed iterations (allocator pool after the SDS leg's empty_cache)
-            full.step(1000)
-            barrier()
-            t3 = time.perf_counter()
-            for k in range(args.sds_steps):
-                full.step(1001 + k)
-            barrier()
-            dt_full = time.perf_counter() - t3
-            for n in (full.kw_train['network_fn'], full.kw_train['network_fine']):
-                n.train_precision = 1
-            full.step(2000)
-            barrier()
-            t4 = time.perf_counter()
-            for k in range(args.sds_steps):
-                full.step(2001 + k)
-            barrier()
-            dt_full16 = time.perf_counter() - t4
-            if dist is not None:
-                t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
-            full = None                                     # (its networks, optimizer state and cached buffers: not this leg's)
             # BASELINE configs[2] (RGB + normal SDS, normalmap_render_factor=2) and configs[3] (+ multi-view
             # collaborative SDS over <=5 neighbour views), EACH IN BOTH ARITHMETICS of the NeRF kernels: "f32" = the package
             # default (train_precision = inference_precision = 0, exact fp32 MFMA; what every config-level test runs and
             # what the reference computes in) and "f16x3" = the opt-in split-precision mode (fp16 MFMA on hi + lo halves,
             # three products, fp32 accumulate; config-level parity: tests/test_configs.py::test_split_precision_*).
             # The top-level ms_per_step of each leg is the f32 one.
-            for name, colla, nsteps in (('config2_rgb_normal_sds', False, args.sds_steps), ('config3_rgb_normal_colla_sds', True, 2)):
+            for name, colla, nsteps in (('config3_rgb_normal_colla_sds', True, 2), ('config2_rgb_normal_sds', False, args.sds_steps)):
                 a2 = make_args()
                 a2.is_normal_guidance, a2.is_colla_guidance, a2.normalmap_render_factor = True, colla, 2
                 opt.is_normal_guidance, opt.is_colla_guidance, opt.normal_start = True, colla, 500
                 opt.text_normal = 'a normal map of a stone bench in a park'
                 legs = {}
                 for mode, prec in (('f32', 0), ('f16x3', 1)):
-                    # a trainer and an allocator pool of its own per leg: the legs must not time each other's leftovers.  (These legs
-                    # still read ~7 ms above the same iteration in a fresh process -- tools/config_step_profile.py, same box: 144.6 vs
-                    # 152 ms for configs[2] f16x3 -- in both arithmetics; one contributor was found and removed
-                    # (guidance/sd_utils._OffDefaultStream, mvip_nerf_amd/streams.py), the rest is not isolated: DESIGN.md 0b.)
+                    # a trainer and an allocator pool of its own per leg: the legs must not time each other's leftovers
                     tr2 = None
                     torch.cuda.empty_cache()
                     if os.environ.get('MVIP_BENCH_PER_STEP') == '1':
@@ -829,6 +795,54 @@ def main():
                                 'rays_with_grad_per_step_per_gpu': rays // nsteps,
                                 'sds_evaluations_per_step': 2 + (5 if colla else 0)}
                 del tr2
+            opt.is_normal_guidance = opt.is_colla_guidance = False
+            opt.text_normal = ''
+            n_sds = max(args.sds_steps, 3)
+            graphs_ok = world == 1 or os.environ.get('MVIP_GRAPHS_WITH_DIST', '0') == '1'    # eager next to a live multi-rank group unless asked
+            sds_times = timed_steps(sd, 1e-4, graphs_ok, n_sds)
+            dt_sds = float(np.median(sds_times)) * args.sds_steps
+            ms_eager32 = float(np.median(timed_steps(sd, 1e-4, False, n_sds))) * 1e3
+            # the reference's --fp16 mode (DS_NeRF/guidance/sd_utils.py:66) on the SAME hand-written kernels in their
+            # single-product instantiations (round 3; it used to fall onto MIOpen / CK / AOTriton kernels)
+            ms_graph16 = ms_eager16 = None
+            if world == 1:
+                try:
+                    sd16 = StableDiffusion(device, True, False)
+                    ms_graph16 = float(np.median(timed_steps(sd16, 1.0, True, n_sds))) * 1e3
+                    ms_eager16 = float(np.median(timed_steps(sd16, 1.0, False, n_sds))) * 1e3
+                    del sd16
+                except Exception as e:                            # reported, never fatal for the bench line
+                    print(f'[bench] fp16-mode leg skipped: {type(e).__name__}: {e}', file=sys.stderr)
+                torch.cuda.empty_cache()
+            sd.use_graphs = graphs_ok
+            opt = types.SimpleNamespace(is_rgb_guidance=True, is_colla_guidance=False, is_normal_guidance=False,
+                                        text='a stone bench in a park', text_normal='', rgb_guidance_scale=7.5,
+                                        colla_guidance_scale=7.5, normal_guidance_scale=1.5, normal_start=500,
+                                        lambda_guidance=1)
+            scene = SyntheticScene(H, W, FOCAL, NEAR, FAR, device=device)
+            full = SecondStageTrainer(make_args(), scene, device, guidance=Pretrain_Model(opt, device, {'SD': sd}),
+                                      world=world, rank=rank, dist=dist)
+            full.step(999)                 # two untimed iterations (allocator pool after the SDS leg's empty_cache)
+            full.step(1000)
+            barrier()
+            t3 = time.perf_counter()
+            for k in range(args.sds_steps):
+                full.step(1001 + k)
+            barrier()
+            dt_full = time.perf_counter() - t3
+            for n in (full.kw_train['network_fn'], full.kw_train['network_fine']):
+                n.train_precision = 1
+            full.step(2000)
+            barrier()
+            t4 = time.perf_counter()
+            for k in range(args.sds_steps):
+                full.step(2001 + k)
+            barrier()
+            dt_full16 = time.perf_counter() - t4
+            if dist is not None:
+                t = torch.tensor([dt_sds, dt_full, dt_full16], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_sds, dt_full, dt_full16 = float(t[0]), float(t[1]), float(t[2])
             opt.is_normal_guidance = opt.is_colla_guidance = False
             mg['train_with_sds_f16x3_ms'] = dt_full16 / args.sds_steps * 1e3
             result['train_with_sds_f16x3'] = {'ms_per_step': dt_full16 / args.sds_steps * 1e3,

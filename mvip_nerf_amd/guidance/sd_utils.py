@@ -154,15 +154,16 @@ class _NoiseFeed:
 
 
 class _OffDefaultStream:
-    """Captured SDS steps never capture or replay on the device's DEFAULT stream: a caller that is on it hops onto a pool
-    stream for the duration of the step (the default stream waits for it afterwards).  Why (round 6, same-box experiments,
-    DESIGN.md 0b): once ONE captured step had been captured / replayed from the default stream, the replays of two LATER graphs
-    on two other streams no longer overlapped for the rest of the process -- the BASELINE configs[2] iteration took 149.3 ms
-    instead of 142.5, whatever was released afterwards and with 4 or 8 hardware queues -- while the same earlier step issued
-    from a pool stream left the later concurrency intact (142.7 ms).  That is exactly what a configs[2] / configs[3] training run
-    does: iterations up to `normal_start` evaluate ONE term in line (default stream), every later one two or three terms on
-    streams of their own (nerf/utils.Pretrain_Model.cal_loss).  Cost: +0.4 ms on a single-term step (21.3 -> 21.7 ms: the stream
-    hand-over); MVIP_SDS_OFF_DEFAULT_STREAM=0 switches the hop off (A/B)."""
+    """Runs a block on a pool stream instead of the device's DEFAULT stream (the default stream waits for it afterwards).
+    Used by nerf/utils.Pretrain_Model.cal_loss for the single-term iterations of a model that is CONFIGURED for several terms.
+    Why (round 6, same-box experiments, profiles/r6_stream_experiments.json): once ONE captured step had been captured / replayed
+    from the default stream, the replays of two LATER graphs on two other streams no longer overlapped for the rest of the process
+    -- the BASELINE configs[2] iteration took 149.3 ms instead of 142.5, whatever was released afterwards and with 4 or 8 hardware
+    queues -- while the same earlier step issued from a pool stream left the later concurrency intact (142.7 ms).  That is what a
+    configs[2] / configs[3] run does: iterations up to `normal_start` evaluate ONE term in line, every later one two or three on
+    streams of their own.  The hop itself costs a single-term step 0.4-0.9 ms (21.3 -> 21.7-22.2 ms: a replay from a pool stream
+    is slower than from the default stream), so a model configured for ONE term (configs[1], the metric's configuration) and direct
+    callers of train_step_sd stay on the default stream.  MVIP_SDS_OFF_DEFAULT_STREAM=0 switches the hop off (A/B)."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -505,9 +506,7 @@ class StableDiffusion(nn.Module):
         return self._graphs[key]
 
     def _graphed(self, t, mask, prompt, pred, guidance_scale):
-        with _OffDefaultStream(pred.device) as hop:
-            d_pred = self._graph_for('single', mask, prompt, pred, guidance_scale).run(pred, mask, t)
-            hop.keep(d_pred)
+        d_pred = self._graph_for('single', mask, prompt, pred, guidance_scale).run(pred, mask, t)
         return _InjectGrad.apply(pred, d_pred)
 
     # -- the three step methods ---------------------------------------------------------------------
@@ -546,16 +545,12 @@ class StableDiffusion(nn.Module):
             t = self._timestep(k / 10000)
             last = k == NN - 1
             if self.use_graphs:
-                with _OffDefaultStream(pred_k.device) as hop:
-                    g = self._graph_for('last' if last else 'share', mask_k, prompt, pred_k, guidance_scale)
-                    if last:
-                        d_pred, grad = g.run(pred_k, mask_k, t, grad)
-                        hop.keep(d_pred, grad)
-                    else:
-                        grad = g.run(pred_k, mask_k, t, grad)
-                        hop.keep(grad)
+                g = self._graph_for('last' if last else 'share', mask_k, prompt, pred_k, guidance_scale)
                 if last:
+                    d_pred, grad = g.run(pred_k, mask_k, t, grad)
                     loss = _InjectGrad.apply(pred_k, d_pred)
+                else:
+                    grad = g.run(pred_k, mask_k, t, grad)
                 continue
             # `loss` of a non-final view is overwritten before anything reads it, so no gradient ever flows through that view:
             # it runs without an autograd graph (same draws, same values; no saved activations)

@@ -72,8 +72,23 @@ class Pretrain_Model(object):
                     grad_scale=opt.lambda_guidance, save_guidance_path=getattr(opt, 'save_guidance_path', None)))
             streams = self._term_streams(sd, len(terms))
             if streams is None:
-                for fn in terms:
-                    loss = loss + fn()
+                # a model configured for SEVERAL terms keeps even its single-term iterations (before normal_start, i == 0) off the
+                # default stream: a captured step replayed there would cost every later multi-term iteration its concurrency
+                # (guidance/sd_utils._OffDefaultStream; a one-term model stays on the default stream, which is faster for it)
+                hop = None
+                if ((getattr(opt, 'is_normal_guidance', False) or getattr(opt, 'is_colla_guidance', False))
+                        and getattr(sd, 'use_graphs', False) and torch.device(self.device).type == 'cuda'):
+                    from ..guidance.sd_utils import _OffDefaultStream
+                    hop = _OffDefaultStream(self.device)
+                if hop is None:
+                    for fn in terms:
+                        loss = loss + fn()
+                else:
+                    with hop:
+                        outs = [fn() for fn in terms]
+                        hop.keep(*outs)
+                    for out in outs:
+                        loss = loss + out
             else:
                 # The terms are independent diffusion-prior evaluations (the reference runs them one after the other,
                 # DS_NeRF/nerf/utils.py:280-302): each replays its captured step on a stream of its own -- thousands of small

@@ -7,7 +7,7 @@ created earlier in the process, the BASELINE configs[2] iteration -- whose SDS t
 had built several trainers and diffusion wrappers by then, 150-154 ms): the later objects' term streams had landed on occupied
 queues.  Every consumer therefore takes its streams from here: the count is bounded by the roles (<= 3 SDS terms + the
 masked-image encode + the graph-capture warm-up), whatever number of trainers, Pretrain_Model and StableDiffusion objects a
-process builds, and the term streams are the first ones created.
+process builds, and they are created in one fixed order (see `get`).
 """
 import torch
 
@@ -19,15 +19,24 @@ def _index(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
+_ORDER = (('encode', 0), ('term', 0), ('term', 1), ('term', 2), ('capture', 0))
+
+
 def get(device, role, k=0):
-    """The stream of (role, k) on `device` ('term' k = 0..2, 'encode', 'capture'); created on first use, then shared."""
-    key = (_index(device), role, int(k))
-    if (key[0], 'term', 0) not in _POOL:                 # the three term streams take their queues before any other role does
-        for t in range(3):
-            _POOL[(key[0], 'term', t)] = torch.cuda.Stream(device=torch.device('cuda', key[0]))
+    """The stream of (role, k) on `device` ('term' k = 0..2, 'encode', 'capture').  The first call on a device creates the whole
+    fixed set in ONE order -- encode, term 0, term 1, term 2, capture: with four hardware queues and the default stream on the
+    first, the masked-image encode (which overlaps a step running on the default stream or on a term stream) and two term streams
+    get queues of their own; term 2 lands on the default stream's (idle while the terms run) and the capture warm-up stream on the
+    encode stream's (used during captures only).  Measured: with the three term streams created BEFORE the encode stream the
+    single-term step was 0.35 ms slower (fp16 mode 15.9 -> 16.3 ms): its encode branch shared a queue."""
+    idx = _index(device)
+    if (idx, 'encode', 0) not in _POOL:
+        for r, j in _ORDER:
+            _POOL[(idx, r, j)] = torch.cuda.Stream(device=torch.device('cuda', idx))
+    key = (idx, role, int(k))
     s = _POOL.get(key)
     if s is None:
-        s = _POOL[key] = torch.cuda.Stream(device=torch.device('cuda', key[0]))
+        s = _POOL[key] = torch.cuda.Stream(device=torch.device('cuda', idx))
     return s
 
 

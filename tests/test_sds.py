@@ -1266,8 +1266,8 @@ def test_concurrent_terms_with_identical_prompt_scale_and_shape_do_not_share_a_g
             grads.append((rgb.grad.clone(), nrm.grad.clone()))
         out.setdefault(mode, []).append(grads)
     singles = [k for k in sd._graphs if k[0] == 'single']
-    # term stream 0 and term stream 1: the in-line evaluation's caller is on the DEFAULT stream and hops onto term stream 0
-    # (sd_utils._OffDefaultStream), where its two terms share one graph -- one after the other, which is safe
+    # term stream 0 and term stream 1: the in-line evaluation of this two-term model hops off the DEFAULT stream onto term stream 0
+    # (sd_utils._OffDefaultStream in cal_loss), where its two terms share one graph -- one after the other, which is safe
     assert len(singles) == 2 and len({k[-1] for k in singles}) == 2
     ref = out['in_line'][0]
     for run_ in out['streams']:
