@@ -115,6 +115,11 @@ struct DppF32 {
     template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ float f(float o, float v) { return dpp_f32<C, R, B>(o, v); }
     template <int C> static __device__ __forceinline__ float z(float v) { return dpp_f32<C>(0.f, v); }
 };
+struct DppF32Z {      // every step through mov_dpp with bound_ctrl: a lane without a source reads zero, no "old" value to put in place
+    template <int C> static __device__ __forceinline__ float z(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), C, 0xf, 0xf, true));
+    }
+};
 struct DppF64 {
     template <int C, int R = 0xf, int B = 0xf> static __device__ __forceinline__ double f(double o, double v) { return dpp_f64<C, R, B>(o, v); }
     template <int C> static __device__ __forceinline__ double z(double v) { return dpp_f64_zero<C>(v); }

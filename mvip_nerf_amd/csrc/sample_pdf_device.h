@@ -37,10 +37,10 @@ __device__ __forceinline__ int count_below(const float key, const float x) {
         const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cnt4 + (step - 1) * 4, __builtin_bit_cast(int, key)));
         cnt4 |= (STRICT ? c < x : c <= x) ? step * 4 : 0;
     }
-    int cnt = cnt4 >> 2;
+    const int cnt = cnt4 >> 2;
     const float c63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key), 63));   // the steps sum to at most 63
-    if (cnt == 63 && (STRICT ? c63 < x : c63 <= x)) cnt = 64;
-    return cnt;
+    // (arithmetic, not a branch: a lane-divergent `if` would split the basic block of rays_fast's interleaved chains)
+    return cnt + (int)((cnt == 63) & (STRICT ? c63 < x : c63 <= x));
 }
 
 // bins/wts in strided registers (nb bins, nb-1 weights).  u strided (nf samples).
@@ -366,5 +366,267 @@ __device__ __forceinline__ void sample_merge_ray(const float (&zc)[IT], const fl
         if (e < N) z_merged[ray * N + e] = v[i];
     }
 }
+
+// ---- N rays per wave, their dependent chains interleaved STEP BY STEP (round 6) ----------------------------------------
+// The one-ray kernel is bound by the LATENCY of a ray's dependent chain at the eight waves a SIMD holds (occupancy probe:
+// time x1.7 from 2 to 4 waves per SIMD, x1.5 from 4 to 8; fewer instructions or prefetched rows change nothing:
+// profiles/r6_sample_merge_occupancy_probe.json, r6_sample_merge_ab.jsonl).  rays_fast is sample_merge_ray<1>'s common route for
+// the reference configuration (64 coarse depths, 64 new samples) WITHOUT wave-uniform branches and lane predicates -- the exits
+// are collected in `ok`, the results stay in registers, the caller stores them -- written so that every step of every
+// primitive is issued for ray 0, ray 1, ... before the next step: the compiler keeps that order (two whole chains written
+// one after the other were NOT interleaved by the scheduler), and between two dependent instructions of one ray stands an
+// independent one of the other.  A ray whose `ok` is false is redone by sample_merge_ray<1>.  Arithmetic and results are those
+// of sample_merge_ray<1>, bit for bit (SORT: the new samples are always sorted -- a no-op for a row that already is -- and
+// located by the search; otherwise they must be sorted and are located by the interval hint).
+template <int N, class T, class Dpp>
+__device__ __forceinline__ void dpp_incl_scan_add_n(T (&v)[N], Dpp) {
+#define MVIP_STEP(EXPR) _Pragma("unroll") for (int r = 0; r < N; ++r) v[r] += EXPR;
+    MVIP_STEP(Dpp::template z<0x111>(v[r]))
+    MVIP_STEP(Dpp::template z<0x112>(v[r]))
+    MVIP_STEP(Dpp::template z<0x114>(v[r]))
+    MVIP_STEP(Dpp::template z<0x118>(v[r]))
+    MVIP_STEP((Dpp::template f<0x142, 0xa>((T)0, v[r])))
+    MVIP_STEP((Dpp::template f<0x143, 0xc>((T)0, v[r])))
+#undef MVIP_STEP
+}
+// Total over the wave (only lane 63 of the scan is read): the two cross-row steps run UNMASKED with bound_ctrl -- lane 63 receives
+// exactly the additions of the scan, the other rows hold values nobody reads, and no destination has to be zero-filled first
+// (two moves per masked step and 32-bit half).
+template <int N, class T, class Dpp>
+__device__ __forceinline__ void dpp_total_in_lane63_n(T (&v)[N], Dpp) {
+#define MVIP_STEP(EXPR) _Pragma("unroll") for (int r = 0; r < N; ++r) v[r] += EXPR;
+    MVIP_STEP(Dpp::template z<0x111>(v[r]))
+    MVIP_STEP(Dpp::template z<0x112>(v[r]))
+    MVIP_STEP(Dpp::template z<0x114>(v[r]))
+    MVIP_STEP(Dpp::template z<0x118>(v[r]))
+    MVIP_STEP(Dpp::template z<0x142>(v[r]))
+    MVIP_STEP(Dpp::template z<0x143>(v[r]))
+#undef MVIP_STEP
+}
+template <int N>
+__device__ __forceinline__ void dpp_wave_sum_n(double (&v)[N]) {
+    dpp_total_in_lane63_n<N, double>(v, DppF64{});
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const long long t = __builtin_bit_cast(long long, v[r]);
+        const int lo = __builtin_amdgcn_readlane((int)t, 63), hi = __builtin_amdgcn_readlane((int)(t >> 32), 63);
+        v[r] = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    }
+}
+template <int N>
+__device__ __forceinline__ void dpp_wave_sum_n(float (&v)[N]) {
+    dpp_total_in_lane63_n<N, float>(v, DppF32Z{});
+#pragma unroll
+    for (int r = 0; r < N; ++r) v[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r]), 63));
+}
+// (LAST_IS_INF: the caller's key of lane 63 is +inf, which no x reaches: the six steps already give the count)
+template <bool STRICT, int N, bool LAST_IS_INF = false>
+__device__ __forceinline__ void count_below_n(const float (&key)[N], const float (&x)[N], int (&cnt)[N]) {
+    int cnt4[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) cnt4[r] = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        float c[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            c[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cnt4[r] + (step - 1) * 4, __builtin_bit_cast(int, key[r])));
+#pragma unroll
+        for (int r = 0; r < N; ++r) cnt4[r] |= (STRICT ? c[r] < x[r] : c[r] <= x[r]) ? step * 4 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const int k = cnt4[r] >> 2;
+        if constexpr (LAST_IS_INF) { cnt[r] = k; continue; }
+        const float c63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[r]), 63));
+        cnt[r] = k + (int)((k == 63) & (STRICT ? c63 < x[r] : c63 <= x[r]));
+    }
+}
+// The 21-step network on SIGNED keys, N rays at a time.  A lane that keeps the maximum of (own, partner) in a step holds its
+// key NEGATED during that step: partners always have opposite roles, so with t = +-v both compute t' = min(t, -t_partner)
+// (min(v, p) on the one side, -max(v, p) on the other) -- ONE v_min_f32_dpp with a negated DPP operand instead of
+// v_min_dpp + v_max_dpp + v_cndmask; between steps ONE v_cndmask with a negated source and a constant lane mask moves every
+// lane to the next step's sign.  51 vector instructions per ray instead of 83; the values are those of bitonic_sort64 (NaNs are
+// excluded by the caller).  One assembly statement per step covers all N rays: the N - 1 instructions of the other rays stand
+// between the v_cndmask that writes a key and the DPP read of it (2 wait states: an s_nop 0 for N = 2, nothing for N >= 3).
+#define MVIP_FLIP(i) "v_cndmask_b32_e64 %" #i ", %" #i ", -%" #i ", %[m]\n\t"
+#define MVIP_MIN(i, CTRL) "v_min_f32_dpp %" #i ", -%" #i ", %" #i " " CTRL "\n\t"
+#define MVIP_MINO(o, i, CTRL) "v_min_f32_dpp %" #o ", -%" #i ", %" #i " " CTRL "\n\t"
+template <int N, unsigned long long FLIP, int J>
+__device__ __forceinline__ void signed_step_n(float (&t)[N]) {
+    static_assert(N >= 2 && N <= 4, "");
+#define MVIP_DPP_STEP(CTRL)                                                                                                              \
+    if constexpr (N == 2)                                                                                                                \
+        asm(MVIP_FLIP(0) MVIP_FLIP(1) "s_nop 0\n\t" MVIP_MIN(0, CTRL) MVIP_MIN(1, CTRL) : "+v"(t[0]), "+v"(t[1]) : [m] "s"(FLIP));         \
+    else if constexpr (N == 3)                                                                                                           \
+        asm(MVIP_FLIP(0) MVIP_FLIP(1) MVIP_FLIP(2) MVIP_MIN(0, CTRL) MVIP_MIN(1, CTRL) MVIP_MIN(2, CTRL)                                  \
+            : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]) : [m] "s"(FLIP));                                                                       \
+    else                                                                                                                                 \
+        asm(MVIP_FLIP(0) MVIP_FLIP(1) MVIP_FLIP(2) MVIP_FLIP(3) MVIP_MIN(0, CTRL) MVIP_MIN(1, CTRL) MVIP_MIN(2, CTRL) MVIP_MIN(3, CTRL)   \
+            : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : [m] "s"(FLIP));
+    if constexpr (J == 1) { MVIP_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") }
+    else if constexpr (J == 2) { MVIP_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") }
+    else if constexpr (J == 8) { MVIP_DPP_STEP("row_ror:8 row_mask:0xf bank_mask:0xf") }
+    else if constexpr (J == 4) {                             // banks 0, 2 take lane + 4, banks 1, 3 lane - 4: every lane of o is written once
+        float o[N];
+#define MVIP_A "row_shl:4 row_mask:0xf bank_mask:0x5"
+#define MVIP_B "row_shr:4 row_mask:0xf bank_mask:0xa"
+        if constexpr (N == 2)
+            asm(MVIP_FLIP(2) MVIP_FLIP(3) "s_nop 0\n\t" MVIP_MINO(0, 2, MVIP_A) MVIP_MINO(1, 3, MVIP_A) MVIP_MINO(0, 2, MVIP_B) MVIP_MINO(1, 3, MVIP_B)
+                : "=&v"(o[0]), "=&v"(o[1]), "+v"(t[0]), "+v"(t[1]) : [m] "s"(FLIP));
+        else if constexpr (N == 3)
+            asm(MVIP_FLIP(3) MVIP_FLIP(4) MVIP_FLIP(5) MVIP_MINO(0, 3, MVIP_A) MVIP_MINO(1, 4, MVIP_A) MVIP_MINO(2, 5, MVIP_A)
+                MVIP_MINO(0, 3, MVIP_B) MVIP_MINO(1, 4, MVIP_B) MVIP_MINO(2, 5, MVIP_B)
+                : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]) : [m] "s"(FLIP));
+        else
+            asm(MVIP_FLIP(4) MVIP_FLIP(5) MVIP_FLIP(6) MVIP_FLIP(7) MVIP_MINO(0, 4, MVIP_A) MVIP_MINO(1, 5, MVIP_A) MVIP_MINO(2, 6, MVIP_A)
+                MVIP_MINO(3, 7, MVIP_A) MVIP_MINO(0, 4, MVIP_B) MVIP_MINO(1, 5, MVIP_B) MVIP_MINO(2, 6, MVIP_B) MVIP_MINO(3, 7, MVIP_B)
+                : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : [m] "s"(FLIP));
+#undef MVIP_A
+#undef MVIP_B
+#pragma unroll
+        for (int r = 0; r < N; ++r) t[r] = o[r];
+    } else {                                                 // 16: ds_swizzle, 32: the half-wave swap (common.h::dpp_xor); 3 of the 21 steps
+#pragma unroll
+        for (int r = 0; r < N; ++r) asm("v_cndmask_b32_e64 %0, %0, -%0, %1" : "+v"(t[r]) : "s"(FLIP));
+        float other[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) other[r] = dpp_xor<J>(t[r]);
+#pragma unroll
+        for (int r = 0; r < N; ++r) asm("v_min_f32_e64 %0, %0, -%1" : "+v"(t[r]) : "v"(other[r]));
+    }
+#undef MVIP_DPP_STEP
+}
+#undef MVIP_FLIP
+#undef MVIP_MIN
+#undef MVIP_MINO
+template <int K, int J>
+constexpr unsigned long long bitonic_neg_mask() { return ~bitonic_min_mask<K, J>(); }      // lanes that keep the maximum: key held negated
+template <int N>
+__device__ __forceinline__ void bitonic_sort64_n(float (&v)[N]) {
+    // MVIP_STEP(K, J, PK, PJ): step (K, J) after step (PK, PJ); the flip mask is the XOR of the two sign masks
+#define MVIP_STEP(K, J, PK, PJ) signed_step_n<N, bitonic_neg_mask<K, J>() ^ bitonic_neg_mask<PK, PJ>(), J>(v);
+    signed_step_n<N, bitonic_neg_mask<2, 1>(), 1>(v);
+    MVIP_STEP(4, 2, 2, 1) MVIP_STEP(4, 1, 4, 2)
+    MVIP_STEP(8, 4, 4, 1) MVIP_STEP(8, 2, 8, 4) MVIP_STEP(8, 1, 8, 2)
+    MVIP_STEP(16, 8, 8, 1) MVIP_STEP(16, 4, 16, 8) MVIP_STEP(16, 2, 16, 4) MVIP_STEP(16, 1, 16, 2)
+    MVIP_STEP(32, 16, 16, 1) MVIP_STEP(32, 8, 32, 16) MVIP_STEP(32, 4, 32, 8) MVIP_STEP(32, 2, 32, 4) MVIP_STEP(32, 1, 32, 2)
+    MVIP_STEP(64, 32, 32, 1) MVIP_STEP(64, 16, 64, 32) MVIP_STEP(64, 8, 64, 16) MVIP_STEP(64, 4, 64, 8) MVIP_STEP(64, 2, 64, 4)
+    MVIP_STEP(64, 1, 64, 2)
+#undef MVIP_STEP
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm("v_cndmask_b32_e64 %0, %0, -%0, %1" : "+v"(v[r]) : "s"(bitonic_neg_mask<64, 1>()));
+}
+template <int N>
+__device__ __forceinline__ void dpp_incl_max_nonneg_n(int (&v)[N]) {
+#define MVIP_STEP(EXPR) _Pragma("unroll") for (int r = 0; r < N; ++r) v[r] = max(v[r], EXPR);
+    MVIP_STEP(dpp_i32<0x111>(0, v[r]))
+    MVIP_STEP(dpp_i32<0x112>(0, v[r]))
+    MVIP_STEP(dpp_i32<0x114>(0, v[r]))
+    MVIP_STEP(dpp_i32<0x118>(0, v[r]))
+    MVIP_STEP((dpp_i32<0x142, 0xa>(0, v[r])))
+    MVIP_STEP((dpp_i32<0x143, 0xc>(0, v[r])))
+#undef MVIP_STEP
+}
+
+template <int N>
+struct RaysFast {
+    float smp[N], cdf[N], zstd[N], b_key[N];
+    int ind[N], pa[N], pb[N];
+    bool ok[N];
+};
+#define MVIP_EACH _Pragma("unroll") for (int r = 0; r < N; ++r)
+template <bool SORT, int N>
+__device__ __forceinline__ void rays_fast(const float (&zc)[N], const float (&wts)[N], const float (&u)[N], int *lds_w, int row_words,
+                                          RaysFast<N> &o) {
+    constexpr int Nc = 64, Nf = 64, nb = 63, nw = 62;
+    const int l = lane_id();
+    float bins[N], w5[N], total[N], pdf[N], cdf[N], key[N], smp[N];
+    double acc[N];
+    int cnt[N], below[N], above[N];
+    bool ok[N];
+    MVIP_EACH bins[r] = .5f * (dpp_from_next(zc[r], 0.f) + zc[r]);
+    // ---- inverse CDF (inverse_cdf_fast) ----
+    MVIP_EACH w5[r] = wts[r] + 1e-5f;
+    MVIP_EACH acc[r] = l < nw ? (double)w5[r] : 0.0;
+    dpp_wave_sum_n<N>(acc);
+    MVIP_EACH total[r] = (float)acc[r];
+    MVIP_EACH pdf[r] = (w5[r] / total[r]) * (l < nw ? 1.f : 0.f);      // (x 1 / x 0 exact; a select became a branch around the division)
+    MVIP_EACH ok[r] = !__any(pdf[r] < 0.f);
+    MVIP_EACH acc[r] = (double)pdf[r];
+    dpp_incl_scan_add_n<N, double>(acc, DppF64{});
+    MVIP_EACH cdf[r] = dpp_from_prev((float)acc[r], 0.f);
+    MVIP_EACH key[r] = l < nb ? cdf[r] : INFINITY;
+    count_below_n<false, N, true>(key, u, cnt);                       // key[63] = +inf (63 midpoints)
+    MVIP_EACH { below[r] = max(0, cnt[r] - 1); above[r] = min(nb - 1, cnt[r]); }
+    float cb_[N], ca_[N], bb[N], ba[N];
+    MVIP_EACH { cb_[r] = lane_read(cdf[r], below[r]); ca_[r] = lane_read(cdf[r], above[r]); }
+    MVIP_EACH { bb[r] = lane_read(bins[r], below[r]); ba[r] = lane_read(bins[r], above[r]); }
+    MVIP_EACH {
+        float den = ca_[r] - cb_[r];
+        den = den < 1e-5f ? 1.f : den;
+        const float t = (u[r] - cb_[r]) / den;
+        smp[r] = bb[r] + t * (ba[r] - bb[r]);
+    }
+    // ---- z_std (sample_merge_ray) ----
+    const float inv_nf = __builtin_amdgcn_rcpf((float)Nf);
+    float red[N], dev[N];
+    MVIP_EACH red[r] = smp[r];
+    dpp_wave_sum_n<N>(red);
+    MVIP_EACH { dev[r] = smp[r] - red[r] * inv_nf; red[r] = dev[r] * dev[r]; }
+    dpp_wave_sum_n<N>(red);
+    MVIP_EACH o.zstd[r] = __builtin_amdgcn_sqrtf(red[r] * inv_nf);
+    // ---- merge by rank (rank_merge64) ----
+    float b_key[N];
+    int cbj[N];
+    MVIP_EACH b_key[r] = smp[r];
+    MVIP_EACH {
+        const float a_next = dpp_from_next(zc[r], zc[r]);
+        ok[r] = ok[r] & !__any((zc[r] != zc[r]) | (b_key[r] != b_key[r]) | ((l < 63) & (a_next < zc[r])));
+    }
+    if constexpr (SORT) {
+        bitonic_sort64_n<N>(b_key);
+        count_below_n<false, N>(zc, b_key, cbj);
+        MVIP_EACH cbj[r] = min(cbj[r], Nc);
+    } else {
+        MVIP_EACH {
+            const float b_next = dpp_from_next(b_key[r], b_key[r]);
+            ok[r] = ok[r] & !__any((l < 63) & (b_next < b_key[r]));
+        }
+        float e0[N], e1[N];
+        MVIP_EACH {
+            const int r0 = below[r] + 1;                         // a_0 .. a_{r0 - 1} <= b_j
+            const float a0 = lane_read(zc[r], r0 & 63), a1 = lane_read(zc[r], (r0 + 1) & 63);
+            e0[r] = r0 < 64 ? a0 : INFINITY;
+            e1[r] = r0 + 1 < 64 ? a1 : INFINITY;
+        }
+        MVIP_EACH {
+            ok[r] = ok[r] & !__any(!(e1[r] > b_key[r]));
+            cbj[r] = min(below[r] + 1 + (e0[r] <= b_key[r] ? 1 : 0), Nc);
+        }
+    }
+    int ca[N];
+    MVIP_EACH {
+        volatile __attribute__((address_space(3))) int *row = (volatile __attribute__((address_space(3))) int *)(lds_w + r * row_words);
+        row[l] = 0;
+        row[64 + (l & 7)] = 0;                                   // (every lane writes: no lane predicate, no branch)
+    }
+    MVIP_EACH {
+        volatile __attribute__((address_space(3))) int *row = (volatile __attribute__((address_space(3))) int *)(lds_w + r * row_words);
+        const int cb_next = dpp_i32<0x130>(-1, cbj[r]);
+        const bool last_of_run = (l == Nf - 1) | (cb_next != cbj[r]);
+        row[last_of_run ? cbj[r] : 72 + (l & 7)] = l + 1;        // the other lanes write a word nobody reads
+    }
+    MVIP_EACH {
+        volatile __attribute__((address_space(3))) int *row = (volatile __attribute__((address_space(3))) int *)(lds_w + r * row_words);
+        ca[r] = row[l];
+    }
+    dpp_incl_max_nonneg_n<N>(ca);
+    MVIP_EACH {
+        o.smp[r] = smp[r]; o.cdf[r] = cdf[r]; o.ind[r] = cnt[r]; o.b_key[r] = b_key[r];
+        o.pa[r] = l + ca[r]; o.pb[r] = l + cbj[r]; o.ok[r] = ok[r];
+    }
+}
+#undef MVIP_EACH
 
 }  // namespace mvip

@@ -2,6 +2,8 @@
   (1) the golden vectors captured from the real reference (tests/golden), and
   (2) the CPU oracle (oracle/nerf_oracle.py) on fresh seeded inputs.
 Tolerances are stated per test; integer outputs are compared exactly."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -309,6 +311,54 @@ def test_z_std_contract_non_power_of_two(cuda, Nf):
     zs, _, zstd, _, _ = ops.sample_pdf_merge(T(z, cuda), T(w, cuda), T(u, cuda))
     want = N(zs).astype(np.float64).std(-1)
     np.testing.assert_allclose(N(zstd).astype(np.float64), want, rtol=3e-6)
+
+
+_PAIR_CASE = r"""
+import sys, numpy as np, torch
+from mvip_nerf_amd import ops
+rs = np.random.RandomState(4099)
+B = 4099                                                          # not a multiple of 2, 3 or 4: the short tail of the last wave
+z = np.sort(rs.uniform(1.2, 7.7, size=(B, 64)), -1).astype(np.float32)
+w = (rs.uniform(0, 1, size=(B, 64)) ** 3).astype(np.float32)
+u = rs.uniform(0, 1, size=(B, 64)).astype(np.float32)
+k = rs.randint(2, 62, size=B // 2)
+w[:B // 2] = (np.exp(-0.5 * ((np.arange(64)[None] - k[:, None]) / 0.7) ** 2) + 1e-7).astype(np.float32)   # peaked rows
+w[7] = 0; w[11, 5] = -0.5; w[12, 30] = np.nan                     # flat, negative and NaN pdf entries
+z[20] = z[20, ::-1]; z[21, 9] = np.nan; z[22, 30:34] = z[22, 30]   # unsorted, NaN and coinciding depths
+u[30] = u[30, 0]; u[31, :4] = (0., 1., 1. - 2. ** -24, 2. ** -30); u[32, 3] = np.nan
+dev = torch.device('cuda', 0)
+out = {}
+for tag, uu in (('rand', u), ('row', np.linspace(0., 1., 64, dtype=np.float32))):
+    r = ops.sample_pdf_merge(torch.from_numpy(z).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(uu).to(dev), want_inds=True, want_cdf=True)
+    for name, t in zip(('zs', 'zm', 'zstd', 'inds', 'cdf'), r):
+        out[tag + '_' + name] = t.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_rays_per_wave_routes_are_bit_identical(cuda, tmp_path):
+    """Round 6's several-rays-per-wave kernel (csrc/sample_pdf.hip::sample_pdf_merge_pair_kernel: step-interleaved chains, signed-key
+    sorting network, unmasked wave totals) against the one-ray-per-wave kernel it replaces for 64 + 64 samples (MVIP_SAMPLE_PAIR=0),
+    each in its own process, EVERY output compared as bit patterns: samples, merged depths, z_std, interval indices, cdf -- on
+    random and peaked pdfs, and on the rows that leave the fast route (negative / NaN pdf entries, unsorted / NaN / coinciding
+    depths, equal and edge uniforms, NaN uniforms), random uniforms and the shared deterministic row, B = 4099."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ('0', '2', '3', '4'):
+        f = str(tmp_path / f'pair{mode}.npz')
+        env = dict(os.environ, MVIP_SAMPLE_PAIR=mode, PYTHONPATH=root)
+        subprocess.run([sys.executable, '-c', _PAIR_CASE, f], check=True, env=env, cwd=root, timeout=600)
+        got[mode] = dict(np.load(f))
+    for mode in ('2', '3', '4'):
+        for k, want in got['0'].items():
+            a, b = got[mode][k], want
+            assert a.shape == b.shape and a.dtype == b.dtype
+            if a.dtype == np.float32:                                 # a NaN equals a NaN (the z_std of the NaN-uniform row comes out with
+                nan = np.isnan(a) & np.isnan(b)                       # either sign bit, depending on the kernel the general route was inlined in)
+                a, b = np.where(nan, np.float32(0), a), np.where(nan, np.float32(0), b)
+                a, b = a.view(np.uint32), b.view(np.uint32)
+            np.testing.assert_array_equal(a, b, err_msg=f'{mode} rays per wave: {k}')
 
 
 def test_sample_pdf_merge_rank_paths(cuda):
