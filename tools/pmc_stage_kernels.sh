@@ -1,25 +1,28 @@
 # Where do the waves of the HBM-bound stage kernels spend their cycles, and how many instructions do they issue per ray?
-# Two PMC passes (8 SQ counters each) over tools/micro_bench.py, once per setting of MVIP_SAMPLE_COUNTING: the switch exists
-# only in the round-6 EXPERIMENT commit dbca558 (counting merge + rays-per-wave prefetch, measured no faster and reverted;
-# profiles/r6_pmc_stage_kernels.json was taken there); on any other build both settings run the same kernel.
-# -> gpurun_out/r6_pmc_stage_kernels.json
+# Two PMC passes (8 SQ counters each) over tools/micro_bench.py, once per setting of an A/B switch of the sample_pdf_merge kernel:
+#   default: MVIP_SAMPLE_PAIR = 2 (two step-interleaved rays per wave, what ships) vs 0 (the one-ray-per-wave kernel of round 5)
+#            -> gpurun_out/r6_pmc_stage_kernels_rays_per_wave.json
+#   MVIP_STAGE_VAR=MVIP_SAMPLE_COUNTING MVIP_STAGE_OUT=r6_pmc_stage_kernels.json: the switch of the round-6 EXPERIMENT commit
+#            dbca558 (counting merge + rays-per-wave prefetch, measured no faster and reverted; profiles/r6_pmc_stage_kernels.json
+#            was taken there).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-for CNT in 1 0; do
+VAR=${MVIP_STAGE_VAR:-MVIP_SAMPLE_PAIR}; SET=${MVIP_STAGE_SETTINGS:-2 0}; export MVIP_STAGE_VAR=$VAR MVIP_STAGE_SETTINGS="$SET" MVIP_STAGE_OUT=${MVIP_STAGE_OUT:-r6_pmc_stage_kernels_rays_per_wave.json}
+for CNT in $SET; do
   for P in A B; do
     if [ $P = A ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES";
     else C="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU"; fi
     D=gpurun_out/pmc_stage_${CNT}_$P; mkdir -p $D
-    export MVIP_SAMPLE_COUNTING=$CNT
+    export $VAR=$CNT
     timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o run -- python3 tools/micro_bench.py > $D/out.txt 2> $D/err.log
     find $D -name '*counter_collection.csv' | head -1 | xargs -I{} python3 tools/pmc_summary.py {} $D/summary.json > $D/summary_top.txt
     find $D -name '*.csv' -delete; find $D -name '*.db' -delete
   done
 done
 python3 - <<'PY'
-import json
+import json, os
 out = {'what': 'PMC view of the stage kernels over tools/micro_bench.py (21 timed + 1 warm-up launches per line of that script; counters summed over all launches of a kernel name): fractions of SQ_WAVE_CYCLES and instructions per wave', 'settings': {}}
-for cnt in ('1', '0'):
+for cnt in os.environ['MVIP_STAGE_SETTINGS'].split():
     a = {e['kernel']: e for e in json.load(open(f'gpurun_out/pmc_stage_{cnt}_A/summary.json'))}
     b = {e['kernel']: e for e in json.load(open(f'gpurun_out/pmc_stage_{cnt}_B/summary.json'))}
     rows = []
@@ -37,8 +40,9 @@ for cnt in ('1', '0'):
                      'salu_per_wave': round(f.get('SQ_INSTS_SALU', 0) / waves, 1),
                      'vmem_per_wave': round((f.get('SQ_INSTS_VMEM_RD', 0) + f.get('SQ_INSTS_VMEM_WR', 0)) / waves, 2),
                      'lds_bank_conflict_cycles_per_lds_inst': round(f.get('SQ_LDS_BANK_CONFLICT', 0) / max(f.get('SQ_INSTS_LDS', 1), 1), 2)})
-    out['settings'][f'MVIP_SAMPLE_COUNTING={cnt}'] = rows
+    out['settings'][f"{os.environ['MVIP_STAGE_VAR']}={cnt}"] = rows
     for r in rows:
         print(cnt, json.dumps(r))
-json.dump(out, open('gpurun_out/r6_pmc_stage_kernels.json', 'w'), indent=1)
+out['head'] = os.environ.get('MVIP_HEAD', 'unknown')
+json.dump(out, open('gpurun_out/' + os.environ['MVIP_STAGE_OUT'], 'w'), indent=1)
 PY
