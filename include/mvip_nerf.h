@@ -220,7 +220,10 @@ int mvip_composite_backward(const float *raw, const float *z, const float *rows,
  * z_std contract: two-pass (mean, then squared deviations) fp32 wave-tree sums; 1/Nf and the square root are
  * v_rcp_f32 / v_sqrt_f32 (<= 1 ulp each, 1/Nf exact for powers of two): within 3e-6 relative of
  * torch.std(z_samples, -1, unbiased=False) evaluated in fp64, not correctly rounded
- * (tests/test_hip_kernels.py::test_z_std_contract_non_power_of_two). */
+ * (tests/test_hip_kernels.py::test_z_std_contract_non_power_of_two).
+ * Nc = Nf = 64 (the reference configuration) runs two rays per wavefront; every output equals the one-ray-per-wavefront
+ * kernel's bit for bit (a NaN equals a NaN), also for rows with NaN / negative / unsorted entries, which take the general route
+ * (MVIP_SAMPLE_PAIR=0 selects the one-ray kernel for A/B; tests/test_hip_kernels.py::test_rays_per_wave_routes_are_bit_identical). */
 int mvip_sample_pdf_merge(const float *z, const float *weights, const float *u, int u_is_row,
                           int64_t B, int Nc, int Nf, float *z_samples, float *z_merged,
                           float *z_std, int64_t *inds, float *cdf, void *stream);
